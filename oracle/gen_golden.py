@@ -1,0 +1,356 @@
+"""Generates tests/golden/*.npz from the UNMODIFIED reference (run in the build
+container only; /root/reference does not exist on the GPU box).
+
+    python oracle/gen_golden.py            # rewrites every fixture
+
+Randomness inside the reference (torch.rand / torch.randn in NeRF/render.py:249,
+:330, :429) is replaced by seeded tensors that are stored in the fixture, by
+patching the two torch factory functions for the duration of the call; the
+indices returned by torch.searchsorted (:444) are recorded the same way.  Nothing
+in the reference's files is edited.
+
+TEST INFRASTRUCTURE ONLY.
+"""
+import argparse
+import contextlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle.ref_import import load_reference            # noqa: E402
+from oracle import scnerf_oracle as O                   # noqa: E402
+from oracle import synth                                # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+@contextlib.contextmanager
+def injected_randomness(rand_queue, randn_queue, record):
+    """torch.rand(shape) / torch.randn(shape) pop pre-drawn tensors; searchsorted
+    results are appended to record['inds'], its inputs to record['cdf'/'u']."""
+    real_rand, real_randn, real_ss = torch.rand, torch.randn, torch.searchsorted
+
+    def fake_rand(*a, **k):
+        t = rand_queue.pop(0)
+        shape = tuple(a[0]) if len(a) == 1 and not isinstance(a[0], int) else tuple(a)
+        assert tuple(t.shape) == shape, (t.shape, shape)
+        return t.clone()
+
+    def fake_randn(*a, **k):
+        t = randn_queue.pop(0)
+        shape = tuple(a[0]) if len(a) == 1 and not isinstance(a[0], int) else tuple(a)
+        assert tuple(t.shape) == shape, (t.shape, shape)
+        return t.clone()
+
+    def rec_ss(cdf, u, **k):
+        out = real_ss(cdf, u, **k)
+        record.setdefault("cdf", []).append(cdf.detach().clone())
+        record.setdefault("u", []).append(u.detach().clone())
+        record.setdefault("inds", []).append(out.clone())
+        return out
+
+    torch.rand, torch.randn, torch.searchsorted = fake_rand, fake_randn, rec_ss
+    try:
+        yield
+    finally:
+        torch.rand, torch.randn, torch.searchsorted = real_rand, real_randn, real_ss
+
+
+def np32(t):
+    return t.detach().cpu().numpy()
+
+
+def ref_network(ns, params, n_importance):
+    """Reference NeRF module carrying `params` + the reference query closure
+    (NeRF/create_nerf.py:42-69 without DataParallel)."""
+    embed_fn, input_ch = ns.helpers.get_embedder(10, 0)
+    embeddirs_fn, input_ch_views = ns.helpers.get_embedder(4, 0)
+    net = ns.helpers.NeRF(D=8, W=256, input_ch=input_ch, output_ch=5 if n_importance > 0 else 4,
+                          skips=[4], input_ch_views=input_ch_views, use_viewdirs=True)
+    net.load_state_dict(params)
+    query = lambda inputs, viewdirs, network_fn: ns.create_nerf.run_network(
+        inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
+        netchunk=1 << 20)
+    return net, query
+
+
+# ------------------------------------------------------------------ generators
+def gen_init_check(ns):
+    """Pins oracle.xavier_nerf_params(seed) == reference NeRF() under manual_seed."""
+    out = {}
+    for seed in (0, 3):
+        torch.manual_seed(seed)
+        net = ns.helpers.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4],
+                              input_ch_views=27, use_viewdirs=True)
+        sd = net.state_dict()
+        for k in ("pts_linears.0.weight", "rgb_linear.weight", "alpha_linear.weight"):
+            out["seed%d/%s" % (seed, k)] = np32(sd[k])
+        out["seed%d/sumsq" % seed] = np.array(
+            [float((v.double() ** 2).sum()) for v in sd.values()])
+    np.savez_compressed(os.path.join(GOLDEN, "init_check.npz"), **out)
+
+
+def gen_embedder(ns):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(97, 3, generator=g) * 1.3
+    x[0] = 0.0
+    x[1] = torch.tensor([1.5, -1.5, 0.25])
+    f10, d10 = ns.helpers.get_embedder(10, 0)
+    f4, d4 = ns.helpers.get_embedder(4, 0)
+    np.savez_compressed(os.path.join(GOLDEN, "embedder.npz"), x=np32(x),
+                        pe10=np32(f10(x)), pe4=np32(f4(x)))
+
+
+def gen_mlp(ns):
+    params = synth.network_params(seed=0)
+    net, _ = ref_network(ns, params, 128)
+    g = torch.Generator().manual_seed(5)
+    emb = torch.randn(200, 90, generator=g)
+    emb.requires_grad_(True)
+    y = net(emb)
+    gy = torch.randn(y.shape, generator=g)
+    (y * gy).sum().backward()
+    out = dict(emb=np32(emb), y=np32(y), gy=np32(gy), g_emb=np32(emb.grad))
+    for k, v in net.named_parameters():
+        if k.endswith(".bias") or k in ("pts_linears.0.weight", "pts_linears.5.weight",
+                                        "rgb_linear.weight", "alpha_linear.weight"):
+            out["g/" + k] = np32(v.grad)
+        else:
+            out["gnorm/" + k] = np.array(float(v.grad.double().norm()))
+    np.savez_compressed(os.path.join(GOLDEN, "mlp.npz"), **out)
+
+
+def gen_sample_pdf(ns):
+    """KATs for the inverse-CDF sampler incl. the edge cases of SURVEY 8c(1)."""
+    g = torch.Generator().manual_seed(21)
+    n, m, sf = 24, 62, 128
+    bins = torch.sort(torch.rand(n, m + 1, generator=g), dim=-1)[0]
+    w = torch.rand(n, m, generator=g) ** 4
+    w[0] = 1.0                                   # flat pdf
+    w[1] = 0.0
+    w[1, 17] = 1.0                               # single spike
+    w[2] = 0.0                                   # all zero -> 1e-5 pad path
+    w[3, :40] = 0.0                              # long empty prefix: denom < 1e-5 path
+    w[4] = torch.rand(m, generator=g) * 1e-7     # everything tiny
+    u = torch.rand(n, sf, generator=g)
+    out = {"bins": np32(bins), "weights": np32(w)}
+    for tag, det in (("rand", False), ("det", True)):
+        rec = {}
+        uq = [u.clone()] if not det else []
+        with injected_randomness(uq, [], rec):
+            s = ns.render.sample_pdf(bins, w, sf, det=det)
+        out[tag + "/u"] = np32(rec["u"][0])
+        out[tag + "/cdf"] = np32(rec["cdf"][0])
+        out[tag + "/inds"] = rec["inds"][0].numpy()
+        out[tag + "/samples"] = np32(s)
+    # u exactly on cdf knots (ties must resolve like side='right')
+    cdf = torch.from_numpy(out["rand/cdf"])
+    u_knot = cdf[:, torch.arange(0, 63, 63 // 32)[:32]].repeat(1, 4)[:, :sf].contiguous()
+    u_knot = torch.clamp(u_knot, max=float(np.nextafter(np.float32(1), np.float32(0))))
+    rec = {}
+    with injected_randomness([u_knot.clone()], [], rec):
+        s = ns.render.sample_pdf(bins, w, sf, det=False)
+    out["knot/u"] = np32(u_knot)
+    out["knot/cdf"] = np32(rec["cdf"][0])
+    out["knot/inds"] = rec["inds"][0].numpy()
+    out["knot/samples"] = np32(s)
+    np.savez_compressed(os.path.join(GOLDEN, "sample_pdf.npz"), **out)
+
+
+def gen_composite(ns):
+    g = torch.Generator().manual_seed(31)
+    out = {}
+    for tag, s in (("s64", 64), ("s192", 192)):
+        n = 20
+        raw = torch.randn(n, s, 4, generator=g) * 2.0
+        raw[0, :, 3] = -5.0                         # zero density everywhere
+        raw[1, :, 3] = 60.0                         # saturated alpha from the first sample
+        raw[2, : s // 2, 3] = -1.0
+        raw[2, s // 2, 3] = 1e4                      # wall in the middle
+        z = torch.sort(torch.rand(n, s, generator=g), dim=-1)[0]
+        z[3] = z[3, 0]                              # degenerate: all samples coincide
+        rays_d = torch.randn(n, 3, generator=g)
+        noise = torch.randn(n, s, generator=g)
+        for wb in (False, True):
+            for with_noise in (False, True):
+                r = raw.clone().requires_grad_(True)
+                d = rays_d.clone().requires_grad_(True)
+                with injected_randomness([], [noise.clone()] if with_noise else [], {}):
+                    rgb, disp, acc, w, depth = ns.render.raw2outputs(
+                        r, z, d, raw_noise_std=1.0 if with_noise else 0.0, white_bkgd=wb)
+                g_rgb = torch.randn(rgb.shape, generator=torch.Generator().manual_seed(7))
+                g_disp = torch.randn(disp.shape, generator=torch.Generator().manual_seed(8)) * 1e-2
+                g_acc = torch.randn(acc.shape, generator=torch.Generator().manual_seed(9))
+                g_depth = torch.randn(acc.shape, generator=torch.Generator().manual_seed(10))
+                ((rgb * g_rgb).sum() + (disp * g_disp).sum() + (acc * g_acc).sum()
+                 + (depth * g_depth).sum()).backward()
+                key = "%s/wb%d_n%d/" % (tag, wb, with_noise)
+                out.update({key + "rgb": np32(rgb), key + "disp": np32(disp),
+                            key + "acc": np32(acc), key + "weights": np32(w),
+                            key + "depth": np32(depth), key + "g_raw": np32(r.grad),
+                            key + "g_rays_d": np32(d.grad)})
+        out.update({tag + "/raw": np32(raw), tag + "/z": np32(z), tag + "/rays_d": np32(rays_d),
+                    tag + "/noise": np32(noise), tag + "/g_rgb": np32(g_rgb),
+                    tag + "/g_disp": np32(g_disp), tag + "/g_acc": np32(g_acc),
+                    tag + "/g_depth": np32(g_depth)})
+    np.savez_compressed(os.path.join(GOLDEN, "composite.npz"), **out)
+
+
+def gen_render_rays(ns):
+    """Full render_rays (+ clamp of batchify_rays) at small N, outputs and grads."""
+    out = {}
+    cases = [
+        # tag, N, S_c, S_f, perturb, raw_noise_std, lindisp, white_bkgd
+        ("c64_f0_det", 24, 64, 0, 0.0, 0.0, False, False),
+        ("c64_f0_pert", 24, 64, 0, 1.0, 1.0, False, False),
+        ("c64_f128_pert", 24, 64, 128, 1.0, 1.0, False, False),
+        ("c64_f128_det", 16, 64, 128, 0.0, 0.0, False, True),
+        ("c64_f64_lindisp", 16, 64, 64, 1.0, 0.0, True, False),
+    ]
+    for tag, n, sc, sf, perturb, rns, lindisp, wb in cases:
+        pc = synth.network_params(seed=0)
+        pf = synth.network_params(seed=1)
+        net_c, query = ref_network(ns, pc, sf)
+        net_f, _ = ref_network(ns, pf, sf)
+        rays = synth.ray_batch(n, seed=1, lindisp=lindisp)
+        target = synth.target_rgb(n, seed=2)
+        rnd = synth.render_randoms(n, sc, sf, seed=3)
+        rays_req = rays.clone().requires_grad_(True)
+        rand_q, randn_q = [], []
+        if perturb > 0:
+            rand_q.append(rnd["t_rand"])
+        if rns > 0:
+            randn_q.append(rnd["noise_c"] / 1.0)
+        if sf > 0:
+            if perturb > 0:
+                rand_q.append(rnd["u"])
+            if rns > 0:
+                randn_q.append(rnd["noise_f"])
+        rec = {}
+        with injected_randomness(rand_q, randn_q, rec):
+            ret = ns.render.batchify_rays(
+                rays_req, chunk=1 << 15, network_fn=net_c, network_query_fn=query,
+                N_samples=sc, retraw=True, lindisp=lindisp, perturb=perturb,
+                N_importance=sf, network_fine=net_f if sf > 0 else None,
+                white_bkgd=wb, raw_noise_std=rns)
+        assert not rand_q and not randn_q
+        loss = torch.mean((ret["rgb_map"] - target) ** 2)
+        if sf > 0:
+            loss = loss + torch.mean((ret["rgb0"] - target) ** 2)
+        loss.backward()
+        k = tag + "/"
+        out[k + "cfg"] = np.array([n, sc, sf, perturb, rns, int(lindisp), int(wb)], dtype=np.float64)
+        for name in ("rgb_map", "disp_map", "acc_map", "raw", "rgb0", "disp0", "acc0", "z_std"):
+            if name in ret:
+                out[k + name] = np32(ret[name])
+        if sf > 0:
+            out[k + "inds"] = rec["inds"][0].numpy()
+            out[k + "cdf"] = np32(rec["cdf"][0])
+        out[k + "loss"] = np.array(float(loss.detach()))
+        out[k + "rays"] = np32(rays)
+        out[k + "target"] = np32(target)
+        for rk, rv in rnd.items():
+            out[k + "rnd/" + rk] = np32(rv)
+        out[k + "g_rays"] = np32(rays_req.grad)
+        for netname, net in (("coarse", net_c), ("fine", net_f)):
+            if netname == "fine" and sf == 0:
+                continue
+            for pn, v in net.named_parameters():
+                if v.grad is None:
+                    continue
+                if pn.endswith(".bias") or pn in ("pts_linears.0.weight", "rgb_linear.weight",
+                                                  "alpha_linear.weight"):
+                    out[k + "g/%s/%s" % (netname, pn)] = np32(v.grad)
+                else:
+                    out[k + "gnorm/%s/%s" % (netname, pn)] = np.array(float(v.grad.double().norm()))
+    np.savez_compressed(os.path.join(GOLDEN, "render_rays.npz"), **out)
+
+
+def gen_camera(ns):
+    out = {}
+    H, W = 378, 504
+    for tag, cls_name, mult in (("plain_add", "PinholeModelRotNoiseLearning10kRayoRayd", False),
+                                ("plain_mul", "PinholeModelRotNoiseLearning10kRayoRayd", True),
+                                ("dist_mul", "PinholeModelRotNoiseLearning10kRayoRaydDistortion", True)):
+        spec = synth.camera_spec(H, W, n_cams=5, seed=4, multiplicative=mult)
+        args = types.SimpleNamespace(
+            camera_model="pinhole_rot_noise_10k_rayo_rayd", grid_size=10,
+            ray_o_noise_scale=spec["ray_o_noise_scale"], ray_d_noise_scale=spec["ray_d_noise_scale"],
+            extrinsics_noise_scale=spec["extrinsics_noise_scale"],
+            intrinsics_noise_scale=spec["intrinsics_noise_scale"], multiplicative_noise=mult,
+            distortion_noise_scale=1e-2)
+        cls = getattr(ns.camera_model, cls_name)
+        cm = cls(spec["K_init"], list(spec["poses"].numpy()), args, H, W)
+        with torch.no_grad():
+            cm.intrinsics_noise.copy_(spec["intrinsics_noise"])
+            cm.extrinsics_noise.copy_(spec["extrinsics_noise"])
+            cm.ray_o_noise.copy_(spec["ray_o_noise"])
+            if cm.ray_d_noise.data_ptr() != cm.ray_o_noise.data_ptr():
+                cm.ray_d_noise.copy_(spec["ray_d_noise"])
+        kps, idx = synth.keypoints(H, W, 64, n_cams=5, seed=6)
+        ro, rd = ns.get_rays.get_rays_kps_use_camera(H, W, cm, kps, idx_in_camera_param=idx)
+        g_o = torch.randn(ro.shape, generator=torch.Generator().manual_seed(12))
+        g_d = torch.randn(rd.shape, generator=torch.Generator().manual_seed(13))
+        ((ro * g_o).sum() + (rd * g_d).sum()).backward()
+        k = tag + "/"
+        out.update({k + "rays_o": np32(ro), k + "rays_d": np32(rd), k + "g_o": np32(g_o),
+                    k + "g_d": np32(g_d), k + "kps": np32(kps), k + "idx": idx.numpy(),
+                    k + "K": np32(cm.get_intrinsic()), k + "E": np32(cm.get_extrinsic()),
+                    k + "g_intrinsics_noise": np32(cm.intrinsics_noise.grad),
+                    k + "g_extrinsics_noise": np32(cm.extrinsics_noise.grad),
+                    k + "g_ray_o_noise": np32(cm.ray_o_noise.grad),
+                    k + "g_ray_d_noise": np32(cm.ray_d_noise.grad),
+                    k + "aliased": np.array(int(cm.ray_d_noise.data_ptr() == cm.ray_o_noise.data_ptr()))})
+        # shared-extrinsic branch (extrinsic.dim()==2) + NDC through the camera model
+        for p in cm.parameters():
+            p.grad = None
+        E = cm.get_extrinsic()[2]
+        ro2, rd2 = ns.get_rays.get_rays_kps_use_camera(H, W, cm, kps, extrinsic=E)
+        no, nd = ns.render.ndc_rays_camera(H, W, cm, 1.0, ro2, rd2)
+        ((no * g_o).sum() + (nd * g_d).sum()).backward()
+        out.update({k + "shared/rays_o": np32(ro2), k + "shared/rays_d": np32(rd2),
+                    k + "shared/ndc_o": np32(no), k + "shared/ndc_d": np32(nd),
+                    k + "shared/g_intrinsics_noise": np32(cm.intrinsics_noise.grad),
+                    k + "shared/g_extrinsics_noise": np32(cm.extrinsics_noise.grad),
+                    k + "shared/g_ray_o_noise": np32(cm.ray_o_noise.grad)})
+    # pinhole without camera model + plain ndc_rays
+    c2w = synth.camera_spec(H, W, n_cams=5, seed=4)["poses"][1]
+    kps, _ = synth.keypoints(H, W, 64, n_cams=5, seed=6)
+    kps3 = torch.cat([kps, torch.ones_like(kps[:, :1])], -1)
+    ro, rd = ns.get_rays.get_rays_kps_no_camera(H, W, 400.0, c2w, kps3)
+    no, nd = ns.render.ndc_rays(H, W, 400.0, 1.0, ro, rd)
+    out.update({"pinhole/c2w": np32(c2w), "pinhole/kps": np32(kps), "pinhole/rays_o": np32(ro),
+                "pinhole/rays_d": np32(rd), "pinhole/ndc_o": np32(no), "pinhole/ndc_d": np32(nd)})
+    np.savez_compressed(os.path.join(GOLDEN, "camera.npz"), **out)
+
+
+def gen_rowsum(ns):
+    """Pins the explicit ATen-AVX512 row-sum restatement against torch.sum here."""
+    g = torch.Generator().manual_seed(41)
+    w = torch.rand(512, 62, generator=g) ** 3 + 1e-5
+    np.savez_compressed(os.path.join(GOLDEN, "rowsum.npz"), w=np32(w),
+                        tot=np32(torch.sum(w, -1)),
+                        capability=np.array(torch.backends.cpu.get_cpu_capability()))
+
+
+ALL = dict(init=gen_init_check, embedder=gen_embedder, mlp=gen_mlp, sample_pdf=gen_sample_pdf,
+           composite=gen_composite, render_rays=gen_render_rays, camera=gen_camera,
+           rowsum=gen_rowsum)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", nargs="*", default=list(ALL))
+    a = ap.parse_args()
+    os.makedirs(GOLDEN, exist_ok=True)
+    torch.set_num_threads(8)
+    ns = load_reference()
+    for name in a.which:
+        print("generating", name)
+        ALL[name](ns)
+    for f in sorted(os.listdir(GOLDEN)):
+        print("%9d  %s" % (os.path.getsize(os.path.join(GOLDEN, f)), f))

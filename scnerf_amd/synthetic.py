@@ -1,0 +1,133 @@
+"""Deterministic synthetic inputs shaped like BASELINE.md section 2 (there are no datasets
+in the build or GPU containers): rays, targets, injected randomness, network
+weights with the reference initialisation, and a fern-like camera rig.
+
+Pure torch-CPU generators (mt19937 streams are stable across hosts); callers move
+the tensors to the device they need.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+
+Tensor = torch.Tensor
+
+
+def xavier_nerf_params(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4,
+                       skips=(4,), use_viewdirs=True, seed=0) -> Dict[str, Tensor]:
+    """Weights drawn exactly like the reference's `NeRF(...)` constructed under
+    torch.manual_seed(seed) (xavier_uniform, relu/linear gain, zero bias; creation
+    order pts_linears, views_linears, feature, alpha, rgb:
+    /root/reference NeRF/run_nerf_helpers.py:13-21, :88-103)."""
+    g = torch.Generator().manual_seed(seed)
+    p: Dict[str, Tensor] = {}
+
+    def dense(name, fan_in, fan_out, act):
+        gain = math.sqrt(2.0) if act == "relu" else 1.0
+        bound = math.sqrt(3.0) * gain * math.sqrt(2.0 / float(fan_in + fan_out))
+        p[name + ".weight"] = torch.empty(fan_out, fan_in).uniform_(-bound, bound, generator=g)
+        p[name + ".bias"] = torch.zeros(fan_out)
+
+    dense("pts_linears.0", input_ch, W, "relu")
+    for i in range(D - 1):
+        dense("pts_linears.%d" % (i + 1), W + input_ch if i in skips else W, W, "relu")
+    dense("views_linears.0", input_ch_views + W, W // 2, "relu")
+    if use_viewdirs:
+        dense("feature_linear", W, W, "linear")
+        dense("alpha_linear", W, 1, "linear")
+        dense("rgb_linear", W // 2, 3, "linear")
+    else:
+        dense("output_linear", W, output_ch, "linear")
+    return p
+
+
+def network_params(seed=0, bias_scale=0.1, alpha_bias=0.5, **kw) -> Dict[str, Tensor]:
+    """xavier weights + *non-zero* biases (so that bias handling is exercised) and a
+    positive density bias (so that rays are neither empty nor fully opaque)."""
+    p = xavier_nerf_params(seed=seed, **kw)
+    g = torch.Generator().manual_seed(1000 + seed)
+    for k in sorted(p):
+        if k.endswith(".bias"):
+            p[k] = (torch.rand(p[k].shape, generator=g) * 2 - 1) * bias_scale
+    if "alpha_linear.bias" in p:
+        p["alpha_linear.bias"] = p["alpha_linear.bias"] + alpha_bias
+    return p
+
+
+def ray_batch(n: int, seed=1, lindisp=False) -> Tensor:
+    """[n, 11] = [o, d, near, far, viewdirs]: o ~ N(0, 0.1^2), d ~ N(0,1) with
+    d_z <- -(|d_z| + 0.5) (forward-facing, NDC-like), near 0 / far 1."""
+    g = torch.Generator().manual_seed(seed)
+    o = torch.randn(n, 3, generator=g) * 0.1
+    d = torch.randn(n, 3, generator=g)
+    d[:, 2] = -(d[:, 2].abs() + 0.5)
+    near = torch.full((n, 1), 0.25 if lindisp else 0.0)
+    far = torch.full((n, 1), 1.5 if lindisp else 1.0)
+    v = d / torch.norm(d, dim=-1, keepdim=True)
+    return torch.cat([o, d, near, far, v], dim=-1)
+
+
+def target_rgb(n: int, seed=2) -> Tensor:
+    return torch.rand(n, 3, generator=torch.Generator().manual_seed(seed))
+
+
+def render_randoms(n: int, s_c: int, s_f: int, seed=3) -> Dict[str, Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    out = {"t_rand": torch.rand(n, s_c, generator=g),
+           "noise_c": torch.randn(n, s_c, generator=g)}
+    if s_f > 0:
+        out["u"] = torch.rand(n, s_f, generator=g)
+        out["noise_f"] = torch.randn(n, s_c + s_f, generator=g)
+    return out
+
+
+def _rot(axis: Tensor, angle: float) -> Tensor:
+    a = axis / axis.norm()
+    K = torch.tensor([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return torch.eye(3) + math.sin(angle) * K + (1 - math.cos(angle)) * (K @ K)
+
+
+def camera_spec(H: int, W: int, n_cams=17, seed=4, multiplicative=True, grid_size=10,
+                focal=400.0) -> Dict[str, object]:
+    """A fern-like rig: n_cams poses within 30 degrees of identity, t ~ N(0, 0.3^2),
+    K = [[f,0,W/2],[0,f,H/2]], N(0,1)-filled ray noise grids (scale 1e-3) and small
+    non-zero intrinsic / extrinsic residuals so every learnable path is live."""
+    g = torch.Generator().manual_seed(seed)
+    poses = torch.zeros(n_cams, 4, 4)
+    for c in range(n_cams):
+        axis = torch.randn(3, generator=g)
+        ang = float(torch.rand(1, generator=g)) * math.pi / 6
+        poses[c, :3, :3] = _rot(axis, ang)
+        poses[c, :3, 3] = torch.randn(3, generator=g) * 0.3
+        poses[c, 3, 3] = 1.0
+    K = torch.tensor([[focal, 0, W / 2, 0], [0, focal, H / 2, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]])
+    gh, gw = H // grid_size, W // grid_size
+    return {
+        "K_init": K, "poses": poses,
+        "intrinsics_noise": torch.randn(4, generator=g) * 1e-2,
+        "extrinsics_noise": torch.randn(n_cams, 9, generator=g) * 1e-2,
+        "ray_o_noise": torch.randn(gh, gw, 3, generator=g),
+        "ray_d_noise": torch.randn(gh, gw, 3, generator=g),
+        "ray_o_noise_scale": 1e-3, "ray_d_noise_scale": 1e-3,
+        "extrinsics_noise_scale": 1.0, "intrinsics_noise_scale": 1.0,
+        "multiplicative_noise": multiplicative, "grid_size": grid_size,
+    }
+
+
+def keypoints(H: int, W: int, n: int, n_cams: int, seed=6, integer=False):
+    """kps [n,2] float (x,y) uniform over the image (sub-pixel unless `integer`), with
+    the corner pixels forced in; idx [n] int64 camera ids."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(n, generator=g) * (W - 1)
+    y = torch.rand(n, generator=g) * (H - 1)
+    kps = torch.stack([x, y], dim=-1)
+    kps[0] = torch.tensor([0.0, 0.0])
+    kps[1] = torch.tensor([W - 1.0, H - 1.0])
+    kps[2] = torch.tensor([W - 1.0, 0.0])
+    kps[3] = torch.tensor([0.0, H - 1.0])
+    if integer:
+        kps = kps.floor()
+    idx = torch.randint(0, n_cams, (n,), generator=g)
+    return kps, idx
