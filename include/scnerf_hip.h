@@ -1,0 +1,67 @@
+/* scnerf_hip.h -- C ABI of libscnerf_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the per-ray render path + camera ray generator of SCNeRF.
+ * The reference has no FFI on this path (it is torch tensor code); its only
+ * native boundary, the unused torchsearchsorted extension, takes caller-allocated outputs
+ * and raw tensors (NeRF/torchsearchsorted/src/cuda/searchsorted_cuda_wrapper.cpp:9-16).
+ * This ABI keeps that convention:
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's allocator);
+ *   - nothing is allocated, freed or synchronised inside; work is enqueued on `stream`
+ *     (a hipStream_t passed as void*);
+ *   - the return value is 0 on success, otherwise a hipError_t / a negative argument error;
+ *   - fp32 everywhere, int64 for sample indices, row-major contiguous unless a stride is named.
+ *
+ * Each entry cites the reference code it replaces (paths relative to /root/reference).
+ */
+#ifndef SCNERF_HIP_H
+#define SCNERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCNERF_ABI_VERSION 1
+
+int scnerf_abi_version(void);
+
+/* ------------------------------------------------------------------ sampling --------- */
+
+/* Batched binary search, out[r, j] = number of a[r, :] elements <= v[r, j] (side 'right') or
+ * < v[r, j] (side_left != 0); int64 output.  Replaces torch.searchsorted(cdf, u, right=True)
+ * (NeRF/render.py:444) and the function of the vendored extension
+ * (NeRF/torchsearchsorted/src/cuda/searchsorted_cuda_kernel.cu:85-107, wrapper .cpp:9-16).
+ * a: [nrow_a, na] with nrow_a in {1, nrow}; v: [nrow_v, nv] with nrow_v in {1, nrow}. */
+int scnerf_searchsorted(const float* a, const float* v, int64_t* out, int nrow, int nrow_a,
+                        int nrow_v, int na, int nv, int side_left, void* stream);
+
+/* Inverse-CDF sampling, NeRF/render.py:417-460 (sample_pdf) with the uniform variates given:
+ * bins [n, nb], weights [n, nb-1], u [n, ns] (u_row_stride = ns) or one shared row
+ * (u_row_stride = 0, the det=True linspace).  Outputs: samples [n, ns]; optional (may be
+ * NULL) inds int64 [n, ns] (the searchsorted result of :444) and cdf [n, nb]. */
+int scnerf_sample_pdf(const float* bins, const float* weights, const float* u, int u_row_stride,
+                      float* samples, int64_t* inds, float* cdf, int n, int nb, int ns,
+                      void* stream);
+
+/* Stratified coarse samples + points, NeRF/render.py:235-259.
+ * rays [n, ray_stride] = [o(3) d(3) near far ...]; t_vals [s] = linspace(0,1,s) (host made);
+ * t_rand [n, s] in [0,1) or NULL (perturb == 0).  Outputs z [n, s], pts [n, s, 3]. */
+int scnerf_coarse_sample(const float* rays, int ray_stride, const float* t_vals,
+                         const float* t_rand, float* z, float* pts, int n, int s, int lindisp,
+                         void* stream);
+
+/* Hierarchical stage between the two networks, NeRF/render.py:268-277:
+ * z_mid, sample_pdf(z_mid, w[1:-1], sf), sort(cat(z_c, z_samples)), pts = o + d*z.
+ * z_c, w_c [n, sc]; u as in scnerf_sample_pdf.  Outputs z_f [n, sc+sf] (sorted),
+ * pts_f [n, sc+sf, 3], z_samples [n, sf], z_std [n] (population std of z_samples, :294);
+ * optional inds int64 [n, sf] and cdf [n, sc-1]. */
+int scnerf_fine_sample(const float* rays, int ray_stride, const float* z_c, const float* w_c,
+                       const float* u, int u_row_stride, float* z_f, float* pts_f,
+                       float* z_samples, float* z_std, int64_t* inds, float* cdf, int n, int sc,
+                       int sf, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCNERF_HIP_H */

@@ -1,0 +1,57 @@
+"""ctypes prototypes of the C ABI declared in include/scnerf_hip.h.
+
+`load()` opens the in-tree libscnerf_hip.so (built by scnerf_amd.csrc.build) and fails
+loudly when it is missing -- there is no CPU fallback in this package."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_int, c_int64, c_void_p, c_float
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscnerf_hip.so")
+
+P = c_void_p
+I = c_int
+
+# name -> argument ctypes (every function returns int)
+PROTOTYPES = {
+    "scnerf_abi_version": [],
+    "scnerf_searchsorted": [P, P, P, I, I, I, I, I, I, P],
+    "scnerf_sample_pdf": [P, P, P, I, P, P, P, I, I, I, P],
+    "scnerf_coarse_sample": [P, I, P, P, P, P, I, I, I, P],
+    "scnerf_fine_sample": [P, I, P, P, P, I, P, P, P, P, P, P, I, I, I, P],
+}
+
+
+def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
+    for name, args in PROTOTYPES.items():
+        fn = getattr(lib, name)      # AttributeError == a declared symbol is missing
+        fn.argtypes = args
+        fn.restype = c_int
+    return lib
+
+
+_lib = None
+
+
+class ScnerfLibraryError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise ScnerfLibraryError(
+                "libscnerf_hip.so is not built (%s). Run `python -m scnerf_amd.csrc.build` "
+                "(or __graft_entry__.build()); scnerf_amd has no CPU fallback." % LIB_PATH)
+        _lib = bind(ctypes.CDLL(LIB_PATH))
+        if _lib.scnerf_abi_version() != 1:
+            raise ScnerfLibraryError("ABI version mismatch")
+    return _lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        raise RuntimeError("%s failed with status %d" % (what, status))

@@ -1,0 +1,56 @@
+// scn_wave.h -- the small CDNA4 (gfx950, wave64) vocabulary the kernels are written in.
+//
+// Everything cross-lane or matrix-core goes through these wrappers so that the kernel
+// sources read as plain HIP.  This is the device implementation (the only one shipped).
+// tests/emu/shim/ holds a same-named header that the CPU SIMT interpreter used by the
+// `-m "not gpu"` logic tests puts first on the include path; the product never sees it.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace scn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+
+// D[32x32] += A[32x2] * B[2x32], exact fp32 (a k-ordered fmaf chain), 64 cycles/SIMD.
+// lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; it receives column
+// j = l&31 of D, rows (r&3) + 8*(r>>2) + 4*(l>>5) for r = 0..15.
+__device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float shfl(float v, int src_lane) { return __shfl(v, src_lane, 64); }
+__device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ float shfl_up(float v, int delta) { return __shfl_up(v, delta, 64); }
+__device__ __forceinline__ float shfl_down(float v, int delta) { return __shfl_down(v, delta, 64); }
+__device__ __forceinline__ double shfl(double v, int src_lane) { return __shfl(v, src_lane, 64); }
+__device__ __forceinline__ double shfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ double shfl_up(double v, int delta) { return __shfl_up(v, delta, 64); }
+__device__ __forceinline__ double shfl_down(double v, int delta) { return __shfl_down(v, delta, 64); }
+__device__ __forceinline__ int shfl(int v, int src_lane) { return __shfl(v, src_lane, 64); }
+__device__ __forceinline__ int shfl_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ int shfl_up(int v, int delta) { return __shfl_up(v, delta, 64); }
+
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ int popcount64(unsigned long long m) { return __popcll(m); }
+
+__device__ __forceinline__ void block_sync() { __syncthreads(); }
+
+// Dynamic LDS of the launch (16-byte aligned; no static __shared__ anywhere, so the
+// dynamic region starts at offset 0: cdna_hip_programming.md guideline 17).
+template <typename T>
+__device__ __forceinline__ T* dynamic_lds() {
+    extern __shared__ __attribute__((aligned(16))) char scn_lds_raw[];
+    return reinterpret_cast<T*>(scn_lds_raw);
+}
+
+__device__ __forceinline__ float atomic_add(float* p, float v) { return atomicAdd(p, v); }
+
+__device__ __forceinline__ void sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+
+}  // namespace scn

@@ -1,0 +1,95 @@
+// TEST INFRASTRUCTURE -- CPU SIMT-interpreter implementation of the scn:: wave vocabulary
+// (same names and semantics as scnerf_amd/csrc/device/scn_wave.h; put FIRST on the include
+// path by tests/emu/build_emu.py, never by the product build).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cmath>
+
+namespace scn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+
+inline int lane_id() { return simt::cur_lane(); }
+inline int wave_id() { return (int)(threadIdx.x >> 6); }
+
+// v_mfma_f32_32x32x2_f32: lane l gives A[l&31][l>>5], B[l>>5][l&31]; receives column l&31,
+// rows (r&3)+8*(r>>2)+4*(l>>5); D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) (k-ordered chain).
+inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
+    uint64_t pack;
+    uint32_t ua, ub;
+    std::memcpy(&ua, &a, 4);
+    std::memcpy(&ub, &b, 4);
+    pack = (uint64_t)ua | ((uint64_t)ub << 32);
+    const uint64_t* x = simt::wave_exchange(pack);
+    const int l = simt::cur_lane();
+    const int j = l & 31, hi = l >> 5;
+    auto A = [&](int i, int k) { uint32_t u = (uint32_t)(x[i + 32 * k] & 0xffffffffu); float f; std::memcpy(&f, &u, 4); return f; };
+    auto B = [&](int k, int jj) { uint32_t u = (uint32_t)(x[jj + 32 * k] >> 32); float f; std::memcpy(&f, &u, 4); return f; };
+    const float b0 = B(0, j), b1 = B(1, j);
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        c[r] = std::fmaf(A(i, 1), b1, std::fmaf(A(i, 0), b0, c[r]));
+    }
+    return c;
+}
+
+template <typename T>
+inline T exchange_read(T v, int src) {
+    static_assert(sizeof(T) <= 8, "");
+    uint64_t u = 0;
+    std::memcpy(&u, &v, sizeof(T));
+    const uint64_t* x = simt::wave_exchange(u);
+    T out;
+    const uint64_t s = x[src & 63];
+    std::memcpy(&out, &s, sizeof(T));
+    return out;
+}
+template <typename T> inline T shfl_t(T v, int src) { return exchange_read(v, src); }
+template <typename T> inline T shfl_xor_t(T v, int m) { return exchange_read(v, simt::cur_lane() ^ m); }
+template <typename T> inline T shfl_up_t(T v, int d) { int l = simt::cur_lane(); return exchange_read(v, l - d >= 0 ? l - d : l); }
+template <typename T> inline T shfl_down_t(T v, int d) { int l = simt::cur_lane(); return exchange_read(v, l + d < 64 ? l + d : l); }
+
+inline float shfl(float v, int s) { return shfl_t(v, s); }
+inline float shfl_xor(float v, int m) { return shfl_xor_t(v, m); }
+inline float shfl_up(float v, int d) { return shfl_up_t(v, d); }
+inline float shfl_down(float v, int d) { return shfl_down_t(v, d); }
+inline double shfl(double v, int s) { return shfl_t(v, s); }
+inline double shfl_xor(double v, int m) { return shfl_xor_t(v, m); }
+inline double shfl_up(double v, int d) { return shfl_up_t(v, d); }
+inline double shfl_down(double v, int d) { return shfl_down_t(v, d); }
+inline int shfl(int v, int s) { return shfl_t(v, s); }
+inline int shfl_xor(int v, int m) { return shfl_xor_t(v, m); }
+inline int shfl_up(int v, int d) { return shfl_up_t(v, d); }
+
+inline unsigned long long ballot(bool p) {
+    const uint64_t* x = simt::wave_exchange(p ? 1u : 0u);
+    unsigned long long m = 0;
+    for (int i = 0; i < 64; ++i) m |= (unsigned long long)(x[i] & 1u) << i;
+    return m;
+}
+inline int popcount64(unsigned long long m) { return __builtin_popcountll(m); }
+
+inline void block_sync() { simt::block_barrier(); }
+
+template <typename T>
+inline T* dynamic_lds() { return reinterpret_cast<T*>(simt::block_lds()); }
+
+inline float atomic_add(float* p, float v) {
+    uint32_t* u = reinterpret_cast<uint32_t*>(p);
+    uint32_t old = __atomic_load_n(u, __ATOMIC_RELAXED);
+    for (;;) {
+        float f;
+        std::memcpy(&f, &old, 4);
+        const float nf = f + v;
+        uint32_t nu;
+        std::memcpy(&nu, &nf, 4);
+        if (__atomic_compare_exchange_n(u, &old, nu, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return f;
+    }
+}
+
+inline void sincos(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
+
+}  // namespace scn
