@@ -61,6 +61,27 @@ int scnerf_fine_sample(const float* rays, int ray_stride, const float* z_c, cons
                        float* z_samples, float* z_std, int64_t* inds, float* cdf, int n, int sc,
                        int sf, void* stream);
 
+/* ------------------------------------------------------------------ NeRF MLP --------- */
+
+/* dst[i] = idx[i] >= 0 ? src[idx[i]] : 0 -- packs the flat parameter buffer of one NeRF
+ * (reference parameter order, NeRF/run_nerf_helpers.py:88-103) into the MFMA streaming
+ * order described by the index tables of scnerf_amd/mlp_layout.py. */
+int scnerf_gather_f32(const float* src, const int* idx, float* dst, long long n, void* stream);
+
+/* Layout constants compiled into the kernels (checked against mlp_layout.py at load). */
+int scnerf_mlp_layout_info(int* out, int n);
+
+/* Fused positional encoding + NeRF.forward for the standard network (D=8, W=256, skips=[4],
+ * use_viewdirs, multires 10/4): replaces run_network + Embedder + NeRF.forward
+ * (NeRF/create_nerf.py:18-32, NeRF/run_nerf_helpers.py:24-72, :105-128).
+ * pts [n_samples, 3]; viewdirs [n_rays, 3] with ray(p) = p / samples_per_ray;
+ * wpacked = forward packed buffer (scnerf_gather_f32 with mlp_layout.forward_index());
+ * raw [n_samples, 4] = (rgb logits, sigma).  save: NULL (inference) or the activation
+ * workspace of mlp_layout.SAVE_FLOATS_PER_SAMPLE * n_samples floats (training). */
+int scnerf_mlp_fwd(const float* pts, const float* viewdirs, int samples_per_ray,
+                   const float* wpacked, float* raw, float* save, long long n_samples,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,13 +6,14 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_int, c_int64, c_void_p, c_float
+from ctypes import c_int, c_int64, c_longlong, c_void_p, c_float
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscnerf_hip.so")
 
 P = c_void_p
 I = c_int
+LL = c_longlong
 
 # name -> argument ctypes (every function returns int)
 PROTOTYPES = {
@@ -21,6 +22,9 @@ PROTOTYPES = {
     "scnerf_sample_pdf": [P, P, P, I, P, P, P, I, I, I, P],
     "scnerf_coarse_sample": [P, I, P, P, P, P, I, I, I, P],
     "scnerf_fine_sample": [P, I, P, P, P, I, P, P, P, P, P, P, I, I, I, P],
+    "scnerf_gather_f32": [P, P, P, LL, P],
+    "scnerf_mlp_layout_info": [P, I],
+    "scnerf_mlp_fwd": [P, P, I, P, P, P, LL, P],
 }
 
 

@@ -1,0 +1,285 @@
+"""Host-side description of how the NeRF MLP's weights are laid out for the fused MFMA
+kernels (scnerf_amd/csrc/mlp_fwd.hip, mlp_bwd.hip).
+
+Design recap (DESIGN.md section "MLP kernels"): a wave owns 32 samples and keeps the whole
+activation vector of those samples in registers, in the accumulator layout of
+v_mfma_f32_32x32x2_f32 computed *transposed* (D[feature][sample]): lane (m, h) = (l & 31,
+l >> 5) holds, for sample m, the features  feat_of(t, r, h) = 32 t + (r & 3) + 8 (r >> 2) + 4 h
+of n-tile t in accumulator register r.  Because the contraction order of a dot product is
+free, those same registers are fed straight back as the B operand of the next layer: MFMA
+step s = 16 t + r contracts features (feat_of(t,r,0), feat_of(t,r,1)).  Only the weights
+move: they are pre-gathered ("packed") into the exact order the A operand is consumed in,
+streamed L2 -> LDS in chunks and read with ds_read_b128 (4 consecutive steps per lane).
+
+The packing is a pure gather from the flat parameter buffer, so it is expressed as int32
+index tables built here once per model; the device side is one gather kernel
+(scnerf_gather_f32) run whenever the weights changed.
+
+Positional-encoding inputs use "slots": slot s of lane-half h is one embedding column
+(pe_col) chosen so that a lane needs one sincos per angle.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+W = 256
+D = 8
+SKIP = 4
+L_PTS = 10
+L_VIEWS = 4
+IN_PTS = 3 + 6 * L_PTS        # 63
+IN_VIEWS = 3 + 6 * L_VIEWS    # 27
+E_PTS_SLOTS = 32              # steps of the encoded-point part (K = 64 incl. 1 pad)
+E_VIEWS_SLOTS = 16            # steps of the encoded-view part (K = 32 incl. 5 pads)
+
+# reference registration order (NeRF/run_nerf_helpers.py:88-103) == flat buffer order
+PARAM_SHAPES: List[Tuple[str, Tuple[int, ...]]] = []
+for _i in range(D):
+    _fan_in = IN_PTS if _i == 0 else (W + IN_PTS if (_i - 1) == SKIP else W)
+    PARAM_SHAPES.append(("pts_linears.%d.weight" % _i, (W, _fan_in)))
+    PARAM_SHAPES.append(("pts_linears.%d.bias" % _i, (W,)))
+PARAM_SHAPES += [
+    ("views_linears.0.weight", (W // 2, IN_VIEWS + W)), ("views_linears.0.bias", (W // 2,)),
+    ("feature_linear.weight", (W, W)), ("feature_linear.bias", (W,)),
+    ("alpha_linear.weight", (1, W)), ("alpha_linear.bias", (1,)),
+    ("rgb_linear.weight", (3, W // 2)), ("rgb_linear.bias", (3,)),
+]
+PARAM_OFFSETS: Dict[str, int] = {}
+_o = 0
+for _n, _s in PARAM_SHAPES:
+    PARAM_OFFSETS[_n] = _o
+    _o += int(np.prod(_s))
+N_PARAMS = _o                 # 595 844
+
+
+def feat_of(t, r, h):
+    return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def row_to_rh(i):
+    """inverse of feat_of within a tile: row i (0..31) -> (r, h)."""
+    return (i & 3) + 4 * (i >> 3), (i >> 2) & 1
+
+
+def pe_col(L: int, s: int, h: int) -> int:
+    """Embedding column (torch order [x, sin f0, cos f0, sin f1, ...], run_nerf_helpers.py:33-55)
+    carried by PE slot s on lane-half h; -1 = zero pad."""
+    if s < 3 * L:
+        f, j = divmod(s, 3)
+        if j == 0:
+            return 3 + 6 * f + h               # sin of x (h=0) / y (h=1)
+        if j == 1:
+            return 3 + 6 * f + 3 + h           # cos of x / y
+        return 3 + 6 * f + (2 if h == 0 else 5)  # z: sin on h=0, cos on h=1
+    if s == 3 * L:
+        return h                               # raw x / y
+    if s == 3 * L + 1:
+        return 2 if h == 0 else -1             # raw z / pad
+    return -1
+
+
+@dataclass
+class Part:
+    name: str
+    nstep: int
+    nt: int
+    cs: int                  # steps per LDS chunk
+
+    @property
+    def floats(self):
+        return self.nstep * self.nt * 64
+
+    @property
+    def chunk_floats(self):
+        return self.cs * self.nt * 64
+
+
+FWD_PARTS = ([Part("E0", 32, 8, 16)] + [Part("H%d" % l, 128, 8, 16) for l in (1, 2, 3, 4)]
+             + [Part("E5", 32, 8, 16), Part("H5", 128, 8, 16), Part("H6", 128, 8, 16),
+                Part("H7", 128, 8, 16), Part("HF", 128, 8, 16), Part("VF", 128, 4, 32),
+                Part("VE", 16, 4, 16), Part("RGB", 64, 1, 64)])
+BWD_PARTS = ([Part("RGBT", 4, 4, 4), Part("VT", 64, 9, 16), Part("FT", 128, 8, 16),
+              Part("L7T", 128, 8, 16), Part("L6T", 128, 8, 16), Part("L5T", 128, 10, 16)]
+             + [Part("L%dT" % l, 128, 8, 16) for l in (4, 3, 2, 1)] + [Part("L0T", 128, 2, 64)])
+
+FWD_STREAM = sum(p.floats for p in FWD_PARTS)        # 598 016
+BWD_STREAM = sum(p.floats for p in BWD_PARTS)
+# tail sections of the packed forward buffer (half-pair layout [(16 t + r) * 2 + h])
+FWD_BIAS = FWD_STREAM                                 # 8 trunk layers x 256
+FWD_BIAS_F = FWD_BIAS + 8 * 256
+FWD_BIAS_V = FWD_BIAS_F + 256
+FWD_BIAS_RGB = FWD_BIAS_V + 128
+FWD_ALPHA_W = FWD_BIAS_RGB + 32
+FWD_ALPHA_B = FWD_ALPHA_W + 256
+FWD_TOTAL = FWD_ALPHA_B + 4
+BWD_ALPHA_W = BWD_STREAM
+BWD_TOTAL = BWD_ALPHA_W + 256
+
+
+def _part_index(part: Part, src) -> np.ndarray:
+    """index array of one part; src(tile, row_i, step, half) -> flat param index or -1.
+    Layout: [chunk][tile][group of 4 steps][lane][4]."""
+    nc = part.nstep // part.cs
+    c, t, g, lane, j = np.meshgrid(np.arange(nc), np.arange(part.nt), np.arange(part.cs // 4),
+                                   np.arange(64), np.arange(4), indexing="ij")
+    step = c * part.cs + 4 * g + j
+    half = lane >> 5
+    i = lane & 31
+    f = np.vectorize(src, otypes=[np.int64])
+    return f(t, i, step, half).reshape(-1).astype(np.int32)
+
+
+def _feat_step(step, half):
+    return feat_of(step // 16, step % 16, half)
+
+
+def build_forward_index() -> np.ndarray:
+    po = PARAM_OFFSETS
+    out = []
+
+    def dense(wname, ld, n_valid, kcol):
+        base = po[wname]
+
+        def src(t, i, step, half):
+            n = 32 * t + i
+            col = kcol(step, half)
+            return base + n * ld + col if (n < n_valid and col >= 0) else -1
+        return src
+
+    for p in FWD_PARTS:
+        if p.name == "E0":
+            s = dense("pts_linears.0.weight", IN_PTS, W, lambda st, h: pe_col(L_PTS, st, h))
+        elif p.name == "E5":       # skip layer: encoded points are columns 0..62 (helpers.py:111-112)
+            s = dense("pts_linears.5.weight", W + IN_PTS, W, lambda st, h: pe_col(L_PTS, st, h))
+        elif p.name == "H5":
+            s = dense("pts_linears.5.weight", W + IN_PTS, W, lambda st, h: IN_PTS + _feat_step(st, h))
+        elif p.name.startswith("H") and p.name != "HF":
+            s = dense("pts_linears.%s.weight" % p.name[1:], W, W, _feat_step)
+        elif p.name == "HF":
+            s = dense("feature_linear.weight", W, W, _feat_step)
+        elif p.name == "VF":       # views layer input = [feature(256), encoded dir(27)] (:117)
+            s = dense("views_linears.0.weight", W + IN_VIEWS, W // 2, _feat_step)
+        elif p.name == "VE":
+            def kc(st, h):
+                c = pe_col(L_VIEWS, st, h)
+                return W + c if c >= 0 else -1
+            s = dense("views_linears.0.weight", W + IN_VIEWS, W // 2, kc)
+        elif p.name == "RGB":
+            s = dense("rgb_linear.weight", W // 2, 3, _feat_step)
+        else:
+            raise AssertionError(p.name)
+        out.append(_part_index(p, s))
+
+    def halfpair(bname, n_valid, ntiles):
+        base = po[bname]
+        idx = np.full(ntiles * 16 * 2, -1, np.int32)
+        for t in range(ntiles):
+            for r in range(16):
+                for h in range(2):
+                    n = feat_of(t, r, h)
+                    if n < n_valid:
+                        idx[(16 * t + r) * 2 + h] = base + n
+        return idx
+
+    for l in range(D):
+        out.append(halfpair("pts_linears.%d.bias" % l, W, 8))
+    out.append(halfpair("feature_linear.bias", W, 8))
+    out.append(halfpair("views_linears.0.bias", W // 2, 4))
+    out.append(halfpair("rgb_linear.bias", 3, 1))
+    out.append(halfpair("alpha_linear.weight", W, 8))
+    out.append(np.array([po["alpha_linear.bias"], -1, -1, -1], np.int32))
+    idx = np.concatenate(out)
+    assert idx.shape[0] == FWD_TOTAL, (idx.shape, FWD_TOTAL)
+    return idx
+
+
+def build_backward_index() -> np.ndarray:
+    """dgrad stream: the A operand is W^T -- row i of tile t is an *input* column of the
+    layer, the contraction runs over the layer's outputs (held in registers as dZ)."""
+    po = PARAM_OFFSETS
+    out = []
+
+    def dense_t(wname, ld, ocol, krow):
+        base = po[wname]
+
+        def src(t, i, step, half):
+            col = ocol(t, i)
+            row = krow(step, half)
+            return base + row * ld + col if (col >= 0 and row >= 0) else -1
+        return src
+
+    def ident(limit, off=0):
+        return lambda t, i: (off + 32 * t + i) if (32 * t + i) < limit else -1
+
+    def pe_rows(L, t_base, off=0):
+        def f(t, i):
+            r, h = row_to_rh(i)
+            c = pe_col(L, 16 * (t - t_base) + r, h)
+            return off + c if c >= 0 else -1
+        return f
+
+    for p in BWD_PARTS:
+        if p.name == "RGBT":        # out: hv features (128); contraction: rgb channel 2s+h (<3)
+            s = dense_t("rgb_linear.weight", W // 2, ident(W // 2),
+                        lambda st, h: (2 * st + h) if (2 * st + h) < 3 else -1)
+        elif p.name == "VT":        # out: [feature 256 | encoded dir slots]; contraction: hv (128)
+            fo, eo = ident(W), pe_rows(L_VIEWS, 8, off=W)
+            s = dense_t("views_linears.0.weight", W + IN_VIEWS,
+                        lambda t, i: fo(t, i) if t < 8 else eo(t, i), _feat_step)
+        elif p.name == "FT":
+            s = dense_t("feature_linear.weight", W, ident(W), _feat_step)
+        elif p.name == "L5T":       # out: [h (cols 63..318) | encoded point slots (cols 0..62)]
+            fo, eo = ident(W, off=IN_PTS), pe_rows(L_PTS, 8)
+            s = dense_t("pts_linears.5.weight", W + IN_PTS,
+                        lambda t, i: fo(t, i) if t < 8 else eo(t, i), _feat_step)
+        elif p.name == "L0T":
+            s = dense_t("pts_linears.0.weight", IN_PTS, pe_rows(L_PTS, 0), _feat_step)
+        else:
+            l = int(p.name[1])
+            s = dense_t("pts_linears.%d.weight" % l, W, ident(W), _feat_step)
+        out.append(_part_index(p, s))
+    idx = np.full(256, -1, np.int32)
+    for t in range(8):
+        for r in range(16):
+            for h in range(2):
+                idx[(16 * t + r) * 2 + h] = po["alpha_linear.weight"] + feat_of(t, r, h)
+    out.append(idx)
+    idx = np.concatenate(out)
+    assert idx.shape[0] == BWD_TOTAL
+    return idx
+
+
+_cache: Dict[str, np.ndarray] = {}
+
+
+def forward_index() -> np.ndarray:
+    if "f" not in _cache:
+        _cache["f"] = build_forward_index()
+    return _cache["f"]
+
+
+def backward_index() -> np.ndarray:
+    if "b" not in _cache:
+        _cache["b"] = build_backward_index()
+    return _cache["b"]
+
+
+# --- activation workspace saved by the training forward, read by dgrad / wgrad -----------
+# all row-major [P][ld] fp32; section order fixed, offsets in floats as multiples of P
+SAVE_SECTIONS = [("act%d" % l, W) for l in range(D)] + [("feat", W), ("hv", W // 2),
+                                                        ("epts", 64), ("eviews", 32)]
+SAVE_FLOATS_PER_SAMPLE = sum(w for _, w in SAVE_SECTIONS)      # 2592 -> 10 368 B / sample
+# gradients written by the dgrad kernel for the wgrad GEMMs
+GRAD_SECTIONS = [("dz%d" % l, W) for l in range(D)] + [("dfeat", W), ("dzv", W // 2)]
+GRAD_FLOATS_PER_SAMPLE = sum(w for _, w in GRAD_SECTIONS)      # 2432
+
+
+def section_offsets(sections, P):
+    off, out = 0, {}
+    for name, w in sections:
+        out[name] = off
+        off += w * P
+    return out, off

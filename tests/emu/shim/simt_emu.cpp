@@ -14,7 +14,7 @@
 namespace simt {
 namespace {
 
-constexpr size_t kStack = 256 * 1024;
+constexpr size_t kStack = 4u << 20;   // virtual, committed lazily (the unrolled MLP kernels have big frames)
 
 struct Wave {
     int gen = 0, arrived = 0, active = 0;

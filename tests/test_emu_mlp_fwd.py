@@ -1,0 +1,71 @@
+"""Fused MLP forward (HIP source under the CPU SIMT interpreter) vs the oracle network."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import scnerf_oracle as O
+from scnerf_amd import mlp_layout as ML
+from scnerf_amd import synthetic as synth
+from tests.emu import harness as H
+from tests.emu_mlp_util import pack_forward, save_views, oracle_activations
+
+pytestmark = pytest.mark.emu
+
+
+def test_layout_constants_match_kernel():
+    out = np.zeros(32, np.int32)
+    H.call("scnerf_mlp_layout_info", out, 32)
+    exp = [ML.FWD_STREAM, ML.FWD_BIAS, ML.FWD_BIAS_F, ML.FWD_BIAS_V, ML.FWD_BIAS_RGB, ML.FWD_ALPHA_W,
+           ML.FWD_ALPHA_B, ML.FWD_TOTAL, ML.BWD_STREAM, ML.BWD_ALPHA_W, ML.BWD_TOTAL,
+           ML.SAVE_FLOATS_PER_SAMPLE, ML.GRAD_FLOATS_PER_SAMPLE]
+    assert out[:len(exp)].tolist() == exp
+    so, _ = ML.section_offsets(ML.SAVE_SECTIONS, 1)
+    go, _ = ML.section_offsets(ML.GRAD_SECTIONS, 1)
+    assert out[13:19].tolist() == [so["feat"], so["hv"], so["epts"], so["eviews"], go["dfeat"], go["dzv"]]
+    assert ML.N_PARAMS == 595844
+
+
+def test_forward_index_is_a_permutation_of_the_weights():
+    idx = ML.forward_index()
+    used = idx[idx >= 0]
+    # every parameter is referenced exactly once by the forward buffer
+    cnt = np.bincount(used, minlength=ML.N_PARAMS)
+    assert cnt.min() == 1 and cnt.max() == 1
+    bidx = ML.backward_index()
+    cntb = np.bincount(bidx[bidx >= 0], minlength=ML.N_PARAMS)
+    po = ML.PARAM_OFFSETS
+    for name, shape in ML.PARAM_SHAPES:
+        sl = slice(po[name], po[name] + int(np.prod(shape)))
+        if name.endswith(".weight"):
+            # alpha_linear.weight appears once in the dgrad stream too (VALU table)
+            assert cntb[sl].min() == 1 and cntb[sl].max() == 1, name
+        else:
+            assert cntb[sl].max() == 0, name
+
+
+@pytest.mark.parametrize("n_rays,spr,save", [(5, 32, True), (3, 64, False)])
+def test_mlp_forward_matches_oracle(n_rays, spr, save):
+    p = synth.network_params(seed=0)
+    wpk = pack_forward(p)
+    P = n_rays * spr           # 160: one full workgroup + a ragged one;  192: 1.5 workgroups
+    g = torch.Generator().manual_seed(3)
+    pts = (torch.rand(P, 3, generator=g) * 3 - 1.5)
+    vd = torch.randn(n_rays, 3, generator=g)
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+    raw = np.full((P, 4), np.nan, np.float32)
+    sv = np.full(ML.SAVE_FLOATS_PER_SAMPLE * P, np.nan, np.float32) if save else None
+    H.call("scnerf_mlp_fwd", pts.numpy(), vd.numpy(), spr, wpk, raw, sv, P, None)
+    ref = O.query_network(p, pts.reshape(n_rays, spr, 3), vd).reshape(P, 4)
+    np.testing.assert_allclose(raw, ref.numpy(), rtol=2e-5, atol=2e-5)
+    if save:
+        vps = vd[:, None, :].expand(n_rays, spr, 3).reshape(P, 3)
+        oa = oracle_activations(p, pts, vps)
+        s = save_views(sv, P)
+        np.testing.assert_allclose(s["epts"][:, :63], oa["e"].numpy(), rtol=0, atol=2e-6)
+        assert np.all(s["epts"][:, 63] == 0)
+        np.testing.assert_allclose(s["eviews"][:, :27], oa["ev"].numpy(), rtol=0, atol=2e-6)
+        assert np.all(s["eviews"][:, 27:] == 0)
+        for l in range(8):
+            np.testing.assert_allclose(s["act%d" % l], oa["acts"][l].numpy(), rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(s["feat"], oa["feat"].numpy(), rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(s["hv"], oa["hv"].numpy(), rtol=2e-5, atol=2e-5)
