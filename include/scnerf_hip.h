@@ -82,6 +82,22 @@ int scnerf_mlp_fwd(const float* pts, const float* viewdirs, int samples_per_ray,
                    const float* wpacked, float* raw, float* save, long long n_samples,
                    void* stream);
 
+/* Workspace sizes (floats) for n_samples samples: activations saved by the training forward
+ * (rows + ReLU bit masks) and the per-layer output gradients written by scnerf_mlp_bwd. */
+long long scnerf_mlp_save_floats(long long n_samples);
+long long scnerf_mlp_grad_floats(long long n_samples);
+
+/* Data-gradient chain of the fused network (what autograd derives from NeRF.forward,
+ * Embedder and run_network: NeRF/run_nerf_helpers.py:105-128, :24-72, create_nerf.py:18-32).
+ * d_raw [n_samples, 4]; wpacked_bwd = backward packed buffer (mlp_layout.backward_index());
+ * save = workspace filled by scnerf_mlp_fwd on the same inputs.  Outputs: grads workspace
+ * (dZ of the 8 trunk layers, d feature, dZ of the views layer: row-major, consumed by
+ * scnerf_wgrad), d_pts [n_samples, 3], d_views [n_samples, 3] (per sample, not yet summed
+ * per ray). */
+int scnerf_mlp_bwd(const float* d_raw, const float* pts, const float* viewdirs,
+                   int samples_per_ray, const float* wpacked_bwd, const float* save,
+                   float* grads, float* d_pts, float* d_views, long long n_samples, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

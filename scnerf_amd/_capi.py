@@ -25,7 +25,12 @@ PROTOTYPES = {
     "scnerf_gather_f32": [P, P, P, LL, P],
     "scnerf_mlp_layout_info": [P, I],
     "scnerf_mlp_fwd": [P, P, I, P, P, P, LL, P],
+    "scnerf_mlp_bwd": [P, P, P, I, P, P, P, P, P, LL, P],
 }
+
+
+# functions returning long long instead of a status
+SIZE_FUNCS = {"scnerf_mlp_save_floats": [LL], "scnerf_mlp_grad_floats": [LL]}
 
 
 def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
@@ -33,6 +38,10 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
         fn = getattr(lib, name)      # AttributeError == a declared symbol is missing
         fn.argtypes = args
         fn.restype = c_int
+    for name, args in SIZE_FUNCS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = c_longlong
     return lib
 
 

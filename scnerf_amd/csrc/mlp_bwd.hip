@@ -1,0 +1,195 @@
+// mlp_bwd.hip -- fused data-gradient chain of the NeRF MLP for gfx950 (the "dgrad" half of the
+// backward pass; the weight gradients are GEMMs over the tensors this kernel and the training
+// forward leave in HBM: wgrad.hip).
+//
+// Mirror image of mlp_fwd.hip: a wave owns the same 32 samples as in the forward launch, the
+// gradient w.r.t. a layer's output lives in registers in the MFMA accumulator layout and is fed
+// straight back as the B operand of the transposed layer; W^T streams through LDS from the
+// backward packed buffer (mlp_layout.backward_index()).  ReLU masks come from the lane-native
+// bit masks the forward saved (16 bytes per lane and layer).
+//
+// Gradient of: NeRF.forward + Embedder + run_network
+//   /root/reference NeRF/run_nerf_helpers.py:105-128, :24-72, NeRF/create_nerf.py:18-32
+// (what autograd derives there).  Outputs: dZ of every layer (row-major, for wgrad), d pts,
+// d viewdirs (per sample; summed per ray by ray_reduce).
+#include <scn_wave.h>
+
+#include "launch.h"
+#include "mlp_common.h"
+#include "scnerf_hip.h"
+
+namespace {
+
+using namespace scn;
+using namespace scn::mlp;
+
+__device__ __forceinline__ u32x4 load_mask(const float* save, long P, int section, long wave_tile, int lane) {
+    return *reinterpret_cast<const u32x4*>(mask_ptr(const_cast<float*>(save), P, section, wave_tile, lane));
+}
+
+// dst[16 t + r] = bit ? acc[t][r] : 0
+template <int NT>
+__device__ __forceinline__ void mask_to_regs(const f32x16 (&acc)[NT], u32x4 bits, float (&dst)[16 * NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = 16 * t + r;
+            dst[i] = ((bits[i >> 5] >> (i & 31)) & 1u) ? acc[t][r] : 0.f;
+        }
+}
+
+// Gradient of the positional encoding held in slot layout (mlp_common.h pe_slots): returns the
+// lane's contribution (d/d(h ? y : x), d/dz); the caller combines the two halves.
+template <int L, int NS>
+__device__ __forceinline__ void pe_backward(float x, float y, float z, int h, const float (&de)[NS],
+                                            float* d_xy, float* d_z) {
+    const float xy = h ? y : x;
+    float gxy = de[3 * L];
+    float gz = h ? 0.f : de[3 * L + 1];
+    float freq = 1.f;
+#pragma unroll
+    for (int f = 0; f < L; ++f) {
+        float s0, c0, s1, c1;
+        sincos(xy * freq, &s0, &c0);
+        sincos(z * freq, &s1, &c1);
+        gxy += freq * (c0 * de[3 * f] - s0 * de[3 * f + 1]);
+        gz += freq * ((h ? -s1 : c1) * de[3 * f + 2]);
+        freq *= 2.f;
+    }
+    *d_xy = gxy;
+    *d_z = gz;
+}
+
+__global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
+    const float* __restrict__ d_raw, const float* __restrict__ pts, const float* __restrict__ viewdirs,
+    int samples_per_ray, const float* __restrict__ wbk, const float* __restrict__ save,
+    float* __restrict__ grads, float* __restrict__ d_pts, float* __restrict__ d_views, long P) {
+    const int lane = lane_id();
+    const int m = lane & 31, h = lane >> 5;
+    const long wave_tile = (long)blockIdx.x * 4 + wave_id();
+    const long p = wave_tile * kSamplesPerWave + m;
+    const bool live = p < P;
+    const long pc = live ? p : P - 1;
+
+    WStream ws;
+    ws.g = reinterpret_cast<const f32x4*>(wbk);
+    ws.buf[0] = dynamic_lds<float>();
+    ws.buf[1] = ws.buf[0] + kMaxChunkBwd;
+    stream_prime<1>(ws);           // RGBT: 4 tiles x 4 steps = 1024 floats
+
+    // dead lanes (p >= P) must contribute exact zeros: their d_raw is forced to 0
+    f32x4 dr = *reinterpret_cast<const f32x4*>(d_raw + pc * 4);
+    if (!live) dr = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float dsigma = dr[3];
+
+    // ---- rgb_linear^T : d hv = W_rgb^T d rgb  (contraction over the 3 channels) ----------
+    float brgb[4] = {h ? dr[1] : dr[0], h ? 0.f : dr[2], 0.f, 0.f};
+    f32x16 acc4[4];
+    zero_acc<4>(acc4);
+    mfma_part<4, 4, 4, 8>(brgb, acc4, ws);
+    float dzv[64];
+    mask_to_regs<4>(acc4, load_mask(save, P, 8, wave_tile, lane), dzv);
+    store_rows<4>(dzv, grads + (long)kGradDzv * P, pc, 128, h, live);
+
+    // ---- views layer^T : [d feature | d encoded dir] = W_v^T dZ_v ------------------------
+    f32x16 acc[8];
+    zero_acc<8>(acc);
+    mfma_part<64, 8, 16, 4>(dzv, acc, ws);
+    f32x16 acce1[1];
+    zero_acc<1>(acce1);
+    mfma_part<64, 1, 64, 8>(dzv, acce1, ws);
+    float dz[128];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dz[16 * t + r] = acc[t][r];          // d feature (linear layer)
+    store_rows<8>(dz, grads + (long)kGradDfeat * P, pc, 256, h, live);
+    {
+        float dev[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dev[r] = acce1[0][r];
+        const long ray = pc / samples_per_ray;
+        float gxy, gz;
+        pe_backward<4, 16>(viewdirs[ray * 3 + 0], viewdirs[ray * 3 + 1], viewdirs[ray * 3 + 2], h, dev, &gxy, &gz);
+        const float oxy = shfl_xor(gxy, 32), oz = shfl_xor(gz, 32);
+        if (live && h == 0) {
+            d_views[p * 3 + 0] = gxy;
+            d_views[p * 3 + 1] = oxy;
+            d_views[p * 3 + 2] = gz + oz;
+        }
+    }
+
+    // ---- feature_linear^T + alpha_linear^T : d h8 = W_f^T d feature + w_alpha d sigma -----
+    {
+        const float* wa = wbk + kBwdAlphaW;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = 16 * t + r;
+                const float w0 = wa[2 * i], w1 = wa[2 * i + 1];
+                acc[t][r] = (h ? w1 : w0) * dsigma;
+            }
+    }
+    mfma_part<128, 8, 16, 8>(dz, acc, ws);
+    mask_to_regs<8>(acc, load_mask(save, P, 7, wave_tile, lane), dz);      // dZ of trunk layer 7
+    store_rows<8>(dz, grads + (long)(kGradDz + 7 * 256) * P, pc, 256, h, live);
+
+    // ---- trunk layers 7..1 : d h_{l-1} = W_l^T dZ_l, then the ReLU mask of layer l-1 ------
+    float de[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) de[s] = 0.f;
+#pragma unroll 1
+    for (int l = 7; l >= 1; --l) {
+        zero_acc<8>(acc);
+        mfma_part<128, 8, 16, 8>(dz, acc, ws);
+        if (l == 5) {
+            // skip connection: layer 5 also consumed the encoded point (columns 0..62)
+            f32x16 acce[2];
+            zero_acc<2>(acce);
+            mfma_part<128, 2, 64, 8>(dz, acce, ws);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) de[16 * t + r] = acce[t][r];
+        }
+        mask_to_regs<8>(acc, load_mask(save, P, l - 1, wave_tile, lane), dz);
+        store_rows<8>(dz, grads + (long)(kGradDz + (l - 1) * 256) * P, pc, 256, h, live);
+    }
+
+    // ---- layer 0^T : d encoded point, then the encoding's own gradient -> d pts ------------
+    {
+        f32x16 acce[2];
+        zero_acc<2>(acce);
+        mfma_part<128, 2, 64, 0>(dz, acce, ws);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) de[16 * t + r] += acce[t][r];
+        float gxy, gz;
+        pe_backward<10, 32>(pts[pc * 3 + 0], pts[pc * 3 + 1], pts[pc * 3 + 2], h, de, &gxy, &gz);
+        const float oxy = shfl_xor(gxy, 32), oz = shfl_xor(gz, 32);
+        if (live && h == 0) {
+            d_pts[p * 3 + 0] = gxy;
+            d_pts[p * 3 + 1] = oxy;
+            d_pts[p * 3 + 2] = gz + oz;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int scnerf_mlp_bwd(const float* d_raw, const float* pts, const float* viewdirs,
+                              int samples_per_ray, const float* wpacked_bwd, const float* save,
+                              float* grads, float* d_pts, float* d_views, long long n_samples,
+                              void* stream) {
+    SCN_RETURN_IF(!d_raw || !pts || !viewdirs || !wpacked_bwd || !save || !grads || !d_pts || !d_views, SCN_EINVAL);
+    SCN_RETURN_IF(samples_per_ray < 1 || n_samples < 0, SCN_EINVAL);
+    if (n_samples == 0) return 0;
+    const size_t lds = (size_t)2 * kMaxChunkBwd * sizeof(float);
+    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(scn_ceil_div(n_samples, kSamplesPerBlock)), dim3(kThreads), lds,
+                       (hipStream_t)stream, d_raw, pts, viewdirs, samples_per_ray, wpacked_bwd, save, grads,
+                       d_pts, d_views, (long)n_samples);
+    return scn_launch_status();
+}

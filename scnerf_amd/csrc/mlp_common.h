@@ -34,7 +34,7 @@ constexpr int kBwdAlphaW = kBwdStream;
 constexpr int kBwdTotal = kBwdAlphaW + 256;
 
 constexpr int kMaxChunkFwd = 8192;      // floats: 32 KB, x2 buffers = 64 KB LDS
-constexpr int kMaxChunkBwd = 10240;     // floats: 40 KB, x2 buffers = 80 KB LDS
+constexpr int kMaxChunkBwd = 8192;      // floats: 32 KB, x2 buffers = 64 KB LDS
 
 // activation / gradient workspace section widths (row-major [P][width])
 constexpr int kSaveAct = 0;             // 8 x [P][256]
@@ -43,6 +43,10 @@ constexpr int kSaveHv = kSaveFeat + 256;
 constexpr int kSaveEpts = kSaveHv + 128;
 constexpr int kSaveEviews = kSaveEpts + 64;
 constexpr int kSavePerSample = kSaveEviews + 32;   // 2592
+// after the row sections: ReLU bit masks, lane-native: [9 sections][wave tile][64 lanes][4 words]
+// (sections 0..7 = trunk layers, 8 = views layer); 8 words per (padded) sample and section.
+constexpr int kMaskSections = 9;
+constexpr int kMaskWordsPerSample = kMaskSections * 8;   // 72
 constexpr int kGradDz = 0;              // 8 x [P][256]
 constexpr int kGradDfeat = 8 * 256;
 constexpr int kGradDzv = kGradDfeat + 256;
@@ -205,6 +209,26 @@ __device__ __forceinline__ void store_rows(const float* regs, float* __restrict_
                        regs[16 * t + 4 * q + 3]};
             *reinterpret_cast<f32x4*>(row + 32 * t + 8 * q) = v;
         }
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline long padded_samples(long P) {
+    return (P + kSamplesPerBlock - 1) / kSamplesPerBlock * kSamplesPerBlock;
+}
+
+// bit i of the lane's mask = (v[i] > 0); N <= 128 registers -> 4 words
+template <int N>
+__device__ __forceinline__ u32x4 relu_bits(const float (&v)[N]) {
+    u32x4 bits = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < N; ++i) bits[i >> 5] |= (v[i] > 0.f ? 1u : 0u) << (i & 31);
+    return bits;
+}
+
+__device__ __forceinline__ unsigned int* mask_ptr(float* save, long P, int section, long wave_tile, int lane) {
+    unsigned int* base = reinterpret_cast<unsigned int*>(save + (long)kSavePerSample * P);
+    return base + ((long)section * (padded_samples(P) / 32) + wave_tile) * 256 + lane * 4;
 }
 
 }  // namespace mlp

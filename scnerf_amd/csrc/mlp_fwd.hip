@@ -53,7 +53,8 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     const float* __restrict__ wpk, float* __restrict__ raw, float* __restrict__ save, long P) {
     const int lane = lane_id();
     const int m = lane & 31, h = lane >> 5;
-    const long p = ((long)blockIdx.x * 4 + wave_id()) * kSamplesPerWave + m;
+    const long wave_tile = (long)blockIdx.x * 4 + wave_id();
+    const long p = wave_tile * kSamplesPerWave + m;
     const bool live = p < P;
     const long pc = live ? p : P - 1;
 
@@ -79,7 +80,10 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
         if (l == 0 || l == 5) mfma_part<32, 8, 16, 8>(e, acc, ws);
         if (l != 0) mfma_part<128, 8, 16, 8>(hreg, acc, ws);   // every chunk that can follow is 8 x 16 B / thread
         relu_to_regs<128>(acc, hreg, l < 8);
-        if (save) store_rows<8>(hreg, save + (long)(l < 8 ? kSaveAct + 256 * l : kSaveFeat) * P, pc, 256, h, live);
+        if (save) {
+            store_rows<8>(hreg, save + (long)(l < 8 ? kSaveAct + 256 * l : kSaveFeat) * P, pc, 256, h, live);
+            if (l < 8) *reinterpret_cast<u32x4*>(mask_ptr(save, P, l, wave_tile, lane)) = relu_bits<128>(hreg);
+        }
         if (l == 7) {
             // density head on the VALU: sigma = w_alpha . h8 + b  (half of the features per lane)
             const float* wa = wpk + kFwdAlphaW;
@@ -102,7 +106,10 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     mfma_part<16, 4, 16, 4>(ev, accv, ws);      // then RGB: 1 tile x 64 steps = 4 f4
     float hv[64];
     relu_to_regs<64>(accv, hv, true);
-    if (save) store_rows<4>(hv, save + (long)kSaveHv * P, pc, 128, h, live);
+    if (save) {
+        store_rows<4>(hv, save + (long)kSaveHv * P, pc, 128, h, live);
+        *reinterpret_cast<u32x4*>(mask_ptr(save, P, 8, wave_tile, lane)) = relu_bits<64>(hv);
+    }
 
     f32x16 accc[1];
     init_bias<1>(accc, wpk + kFwdBiasRGB, h);
@@ -137,11 +144,19 @@ extern "C" int scnerf_gather_f32(const float* src, const int* idx, float* dst, l
 extern "C" int scnerf_mlp_layout_info(int* out, int n) {
     const int v[] = {kFwdStream, kFwdBias, kFwdBiasF, kFwdBiasV, kFwdBiasRGB, kFwdAlphaW, kFwdAlphaB,
                      kFwdTotal, kBwdStream, kBwdAlphaW, kBwdTotal, kSavePerSample, kGradPerSample,
-                     kSaveFeat, kSaveHv, kSaveEpts, kSaveEviews, kGradDfeat, kGradDzv};
+                     kSaveFeat, kSaveHv, kSaveEpts, kSaveEviews, kGradDfeat, kGradDzv, kMaskWordsPerSample};
     const int cnt = (int)(sizeof(v) / sizeof(v[0]));
     SCN_RETURN_IF(!out || n < cnt, SCN_EINVAL);
     for (int i = 0; i < cnt; ++i) out[i] = v[i];
     return 0;
+}
+
+extern "C" long long scnerf_mlp_save_floats(long long n_samples) {
+    return (long long)kSavePerSample * n_samples + (long long)kMaskWordsPerSample * padded_samples(n_samples);
+}
+
+extern "C" long long scnerf_mlp_grad_floats(long long n_samples) {
+    return (long long)kGradPerSample * n_samples;
 }
 
 extern "C" int scnerf_mlp_fwd(const float* pts, const float* viewdirs, int samples_per_ray,

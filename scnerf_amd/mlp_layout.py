@@ -101,8 +101,9 @@ FWD_PARTS = ([Part("E0", 32, 8, 16)] + [Part("H%d" % l, 128, 8, 16) for l in (1,
              + [Part("E5", 32, 8, 16), Part("H5", 128, 8, 16), Part("H6", 128, 8, 16),
                 Part("H7", 128, 8, 16), Part("HF", 128, 8, 16), Part("VF", 128, 4, 32),
                 Part("VE", 16, 4, 16), Part("RGB", 64, 1, 64)])
-BWD_PARTS = ([Part("RGBT", 4, 4, 4), Part("VT", 64, 9, 16), Part("FT", 128, 8, 16),
-              Part("L7T", 128, 8, 16), Part("L6T", 128, 8, 16), Part("L5T", 128, 10, 16)]
+BWD_PARTS = ([Part("RGBT", 4, 4, 4), Part("VTF", 64, 8, 16), Part("VTE", 64, 1, 64),
+              Part("FT", 128, 8, 16), Part("L7T", 128, 8, 16), Part("L6T", 128, 8, 16),
+              Part("L5TH", 128, 8, 16), Part("L5TE", 128, 2, 64)]
              + [Part("L%dT" % l, 128, 8, 16) for l in (4, 3, 2, 1)] + [Part("L0T", 128, 2, 64)])
 
 FWD_STREAM = sum(p.floats for p in FWD_PARTS)        # 598 016
@@ -225,16 +226,16 @@ def build_backward_index() -> np.ndarray:
         if p.name == "RGBT":        # out: hv features (128); contraction: rgb channel 2s+h (<3)
             s = dense_t("rgb_linear.weight", W // 2, ident(W // 2),
                         lambda st, h: (2 * st + h) if (2 * st + h) < 3 else -1)
-        elif p.name == "VT":        # out: [feature 256 | encoded dir slots]; contraction: hv (128)
-            fo, eo = ident(W), pe_rows(L_VIEWS, 8, off=W)
-            s = dense_t("views_linears.0.weight", W + IN_VIEWS,
-                        lambda t, i: fo(t, i) if t < 8 else eo(t, i), _feat_step)
+        elif p.name == "VTF":       # out: feature (views-layer input cols 0..255); contraction: hv (128)
+            s = dense_t("views_linears.0.weight", W + IN_VIEWS, ident(W), _feat_step)
+        elif p.name == "VTE":       # out: encoded view-direction slots (cols 256..282)
+            s = dense_t("views_linears.0.weight", W + IN_VIEWS, pe_rows(L_VIEWS, 0, off=W), _feat_step)
         elif p.name == "FT":
             s = dense_t("feature_linear.weight", W, ident(W), _feat_step)
-        elif p.name == "L5T":       # out: [h (cols 63..318) | encoded point slots (cols 0..62)]
-            fo, eo = ident(W, off=IN_PTS), pe_rows(L_PTS, 8)
-            s = dense_t("pts_linears.5.weight", W + IN_PTS,
-                        lambda t, i: fo(t, i) if t < 8 else eo(t, i), _feat_step)
+        elif p.name == "L5TH":      # out: h (cols 63..318 of the skip layer)
+            s = dense_t("pts_linears.5.weight", W + IN_PTS, ident(W, off=IN_PTS), _feat_step)
+        elif p.name == "L5TE":      # out: encoded point slots (cols 0..62)
+            s = dense_t("pts_linears.5.weight", W + IN_PTS, pe_rows(L_PTS, 0), _feat_step)
         elif p.name == "L0T":
             s = dense_t("pts_linears.0.weight", IN_PTS, pe_rows(L_PTS, 0), _feat_step)
         else:
@@ -273,6 +274,17 @@ SAVE_SECTIONS = [("act%d" % l, W) for l in range(D)] + [("feat", W), ("hv", W //
                                                         ("epts", 64), ("eviews", 32)]
 SAVE_FLOATS_PER_SAMPLE = sum(w for _, w in SAVE_SECTIONS)      # 2592 -> 10 368 B / sample
 # gradients written by the dgrad kernel for the wgrad GEMMs
+MASK_WORDS_PER_SAMPLE = 9 * 8     # lane-native ReLU bit masks behind the row sections
+
+
+def padded_samples(P: int) -> int:
+    return (P + 127) // 128 * 128
+
+
+def save_floats(P: int) -> int:
+    return SAVE_FLOATS_PER_SAMPLE * P + MASK_WORDS_PER_SAMPLE * padded_samples(P)
+
+
 GRAD_SECTIONS = [("dz%d" % l, W) for l in range(D)] + [("dfeat", W), ("dzv", W // 2)]
 GRAD_FLOATS_PER_SAMPLE = sum(w for _, w in GRAD_SECTIONS)      # 2432
 

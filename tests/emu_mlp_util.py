@@ -31,8 +31,8 @@ def pack_backward(p):
 
 def save_views(save, P):
     off, total = ML.section_offsets(ML.SAVE_SECTIONS, P)
-    assert save.shape[0] == total
-    out = {}
+    assert save.shape[0] == ML.save_floats(P)
+    out = {"mask": save[total:].view(np.uint32).reshape(9, ML.padded_samples(P) // 32, 64, 4)}
     for name, w in ML.SAVE_SECTIONS:
         out[name] = save[off[name]: off[name] + w * P].reshape(P, w)
     return out

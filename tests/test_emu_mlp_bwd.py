@@ -1,0 +1,79 @@
+"""Fused dgrad chain (HIP source under the CPU SIMT interpreter) vs torch autograd on the
+oracle network."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import scnerf_oracle as O
+from scnerf_amd import mlp_layout as ML
+from scnerf_amd import synthetic as synth
+from tests.emu import harness as H
+from tests.emu_mlp_util import pack_forward, pack_backward
+
+pytestmark = pytest.mark.emu
+
+
+def oracle_backward(p, pts, vd, spr, d_raw):
+    """autograd on the oracle formulas with every pre-activation retained."""
+    pts = pts.clone().requires_grad_(True)
+    vd = vd.clone().requires_grad_(True)
+    P = pts.shape[0]
+    n_rays = P // spr
+    vps = vd[:, None, :].expand(n_rays, spr, 3).reshape(P, 3)
+    e = O.positional_encoding(pts, 10)
+    ev = O.positional_encoding(vps, 4)
+    zs = []
+    h = e
+    for i in range(8):
+        z = F.linear(h, p["pts_linears.%d.weight" % i], p["pts_linears.%d.bias" % i])
+        z.retain_grad()
+        zs.append(z)
+        h = F.relu(z)
+        if i == 4:
+            h = torch.cat([e, h], -1)
+    sigma = F.linear(h, p["alpha_linear.weight"], p["alpha_linear.bias"])
+    feat = F.linear(h, p["feature_linear.weight"], p["feature_linear.bias"])
+    feat.retain_grad()
+    zv = F.linear(torch.cat([feat, ev], -1), p["views_linears.0.weight"], p["views_linears.0.bias"])
+    zv.retain_grad()
+    rgb = F.linear(F.relu(zv), p["rgb_linear.weight"], p["rgb_linear.bias"])
+    raw = torch.cat([rgb, sigma], -1)
+    (raw * d_raw).sum().backward()
+    return dict(dz=[z.grad for z in zs], dfeat=feat.grad, dzv=zv.grad, d_pts=pts.grad, d_vd=vd.grad)
+
+
+@pytest.mark.parametrize("n_rays,spr", [(5, 32), (1, 70)])
+def test_mlp_dgrad_matches_autograd(n_rays, spr):
+    p = synth.network_params(seed=2)
+    wpk, wbk = pack_forward(p), pack_backward(p)
+    P = n_rays * spr
+    g = torch.Generator().manual_seed(9)
+    pts = torch.rand(P, 3, generator=g) * 2.4 - 1.2
+    vd = torch.randn(n_rays, 3, generator=g)
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+    d_raw = torch.randn(P, 4, generator=g)
+    raw = np.zeros((P, 4), np.float32)
+    save = np.full(ML.save_floats(P), np.nan, np.float32)
+    H.call("scnerf_mlp_fwd", pts.numpy(), vd.numpy(), spr, wpk, raw, save, P, None)
+    grads = np.full(ML.GRAD_FLOATS_PER_SAMPLE * P, np.nan, np.float32)
+    d_pts = np.full((P, 3), np.nan, np.float32)
+    d_views = np.full((P, 3), np.nan, np.float32)
+    H.call("scnerf_mlp_bwd", d_raw.numpy(), pts.numpy(), vd.numpy(), spr, wbk, save, grads, d_pts, d_views, P, None)
+    ref = oracle_backward(p, pts, vd, spr, d_raw)
+    off, _ = ML.section_offsets(ML.GRAD_SECTIONS, P)
+
+    def sec(name, w):
+        return grads[off[name]: off[name] + w * P].reshape(P, w)
+
+    def close(a, b, what):
+        scale = float(np.abs(b).max()) + 1e-12
+        err = float(np.abs(a - b).max())
+        assert err <= 2e-5 * scale + 1e-7, "%s: max err %g vs scale %g" % (what, err, scale)
+
+    close(sec("dzv", 128), ref["dzv"].numpy(), "dzv")
+    close(sec("dfeat", 256), ref["dfeat"].numpy(), "dfeat")
+    for l in range(7, -1, -1):
+        close(sec("dz%d" % l, 256), ref["dz"][l].numpy(), "dz%d" % l)
+    close(d_pts, ref["d_pts"].numpy(), "d_pts")
+    close(d_views.reshape(n_rays, spr, 3).sum(1), ref["d_vd"].numpy(), "d_viewdirs")

@@ -53,7 +53,7 @@ def test_mlp_forward_matches_oracle(n_rays, spr, save):
     vd = torch.randn(n_rays, 3, generator=g)
     vd = vd / vd.norm(dim=-1, keepdim=True)
     raw = np.full((P, 4), np.nan, np.float32)
-    sv = np.full(ML.SAVE_FLOATS_PER_SAMPLE * P, np.nan, np.float32) if save else None
+    sv = np.full(ML.save_floats(P), np.nan, np.float32) if save else None
     H.call("scnerf_mlp_fwd", pts.numpy(), vd.numpy(), spr, wpk, raw, sv, P, None)
     ref = O.query_network(p, pts.reshape(n_rays, spr, 3), vd).reshape(P, 4)
     np.testing.assert_allclose(raw, ref.numpy(), rtol=2e-5, atol=2e-5)
@@ -69,3 +69,14 @@ def test_mlp_forward_matches_oracle(n_rays, spr, save):
             np.testing.assert_allclose(s["act%d" % l], oa["acts"][l].numpy(), rtol=2e-5, atol=2e-5)
         np.testing.assert_allclose(s["feat"], oa["feat"].numpy(), rtol=2e-5, atol=2e-5)
         np.testing.assert_allclose(s["hv"], oa["hv"].numpy(), rtol=2e-5, atol=2e-5)
+        # lane-native ReLU bit masks: bit (16 t + r) of lane (m, h) <-> feature feat_of(t, r, h)
+        for sec, ref, ntile in [(l, s["act%d" % l], 8) for l in range(8)] + [(8, s["hv"], 4)]:
+            for p_ in (0, 31, 77, P - 1):
+                wt, m = divmod(p_, 32)
+                for hh in (0, 1):
+                    words = s["mask"][sec, wt, m + 32 * hh]
+                    for t_ in range(ntile):
+                        for r in range(16):
+                            i = 16 * t_ + r
+                            bit = (int(words[i >> 5]) >> (i & 31)) & 1
+                            assert bit == int(ref[p_, ML.feat_of(t_, r, hh)] > 0)

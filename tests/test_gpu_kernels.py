@@ -1,0 +1,120 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu): the HIP kernels, called through
+the C ABI, against the CPU oracle on the same seeded inputs and against the committed golden
+vectors of the reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import scnerf_oracle as O
+from scnerf_amd import mlp_layout as ML
+from scnerf_amd import synthetic as synth
+from conftest import t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from scnerf_amd import ops as _ops
+    _ops.check_layout()
+    return _ops
+
+
+def dev(x):
+    return x.contiguous().cuda()
+
+
+@pytest.mark.parametrize("tag", ["rand", "knot", "det"])
+def test_sample_pdf_golden_bit_exact(ops, golden, tag):
+    g = golden("sample_pdf")
+    u = t(g[tag + "/u"])
+    if tag == "det":
+        u = u[0].contiguous()
+    s, inds, cdf = ops.sample_pdf(dev(t(g["bins"])), dev(t(g["weights"])), dev(u), True, True)
+    np.testing.assert_array_equal(cdf.cpu().numpy(), g[tag + "/cdf"])
+    np.testing.assert_array_equal(inds.cpu().numpy(), g[tag + "/inds"])
+    np.testing.assert_array_equal(s.cpu().numpy(), g[tag + "/samples"])
+    assert inds.dtype == torch.int64
+
+
+@pytest.mark.parametrize("side", ["left", "right"])
+@pytest.mark.parametrize("Ba,Bv,A,V", [(1, 1, 1, 1), (1, 100, 50, 12), (100, 1, 50, 12), (200, 200, 1, 120),
+                                       (100, 100, 63, 128), (100, 100, 500, 120)])
+def test_searchsorted_matches_numpy(ops, side, Ba, Bv, A, V):
+    rng = np.random.default_rng(Ba + Bv + A + V)
+    a = np.sort(rng.random((Ba, A), dtype=np.float32), -1)
+    v = rng.random((Bv, V), dtype=np.float32)
+    out = ops.searchsorted(dev(t(a)), dev(t(v)), side).cpu().numpy()
+    for r in range(max(Ba, Bv)):
+        np.testing.assert_array_equal(out[r], np.searchsorted(a[0 if Ba == 1 else r], v[0 if Bv == 1 else r], side=side))
+
+
+@pytest.mark.parametrize("lindisp,perturb", [(0, 0), (0, 1), (1, 1)])
+def test_coarse_sample_bit_exact(ops, lindisp, perturb):
+    n, s = 1001, 64
+    rays = synth.ray_batch(n, seed=5, lindisp=bool(lindisp))
+    t_rand = synth.render_randoms(n, s, 0, seed=6)["t_rand"]
+    t_vals = torch.linspace(0.0, 1.0, steps=s)
+    z, pts = ops.coarse_sample(dev(rays), dev(t_vals), dev(t_rand) if perturb else None, bool(lindisp))
+    zo = O.stratified_z(rays[:, 6:7], rays[:, 7:8], s, bool(lindisp), t_rand if perturb else None)
+    po = rays[:, None, 0:3] + rays[:, None, 3:6] * zo[:, :, None]
+    np.testing.assert_array_equal(z.cpu().numpy(), zo.numpy())
+    np.testing.assert_array_equal(pts.cpu().numpy(), po.numpy())
+
+
+@pytest.mark.parametrize("sc,sf,det,n", [(64, 128, False, 1023), (64, 64, False, 100), (64, 128, True, 100)])
+def test_fine_sample_bit_exact(ops, sc, sf, det, n):
+    g = torch.Generator().manual_seed(sc + sf)
+    rays = synth.ray_batch(n, seed=7)
+    z_c = O.stratified_z(rays[:, 6:7], rays[:, 7:8], sc, False, torch.rand(n, sc, generator=g))
+    w_c = torch.rand(n, sc, generator=g) ** 5
+    w_c[1] = 0.0
+    w_c[2, : sc // 2] = 0.0
+    u = O.deterministic_u(n, sf) if det else torch.rand(n, sf, generator=g)
+    ud = dev(u[0]) if det else dev(u)
+    z_f, pts_f, z_s, z_std, inds, cdf = ops.fine_sample(dev(rays), dev(z_c), dev(w_c), ud, True, True)
+    z_mid = 0.5 * (z_c[:, 1:] + z_c[:, :-1])
+    so, io, co = O.sample_pdf(z_mid, w_c[:, 1:-1], u.contiguous(), rowsum="aten")
+    zf_o = torch.sort(torch.cat([z_c, so], -1), -1)[0]
+    pts_o = rays[:, None, 0:3] + rays[:, None, 3:6] * zf_o[:, :, None]
+    np.testing.assert_array_equal(cdf.cpu().numpy(), co.numpy())
+    np.testing.assert_array_equal(inds.cpu().numpy(), io.numpy())
+    np.testing.assert_array_equal(z_s.cpu().numpy(), so.numpy())
+    np.testing.assert_array_equal(z_f.cpu().numpy(), zf_o.numpy())
+    np.testing.assert_array_equal(pts_f.cpu().numpy(), pts_o.numpy())
+    np.testing.assert_allclose(z_std.cpu().numpy(), torch.std(so, -1, unbiased=False).numpy(), rtol=1e-5, atol=1e-8)
+
+
+def _flat(p):
+    return torch.cat([p[name].reshape(-1) for name, _ in ML.PARAM_SHAPES])
+
+
+@pytest.mark.parametrize("n_rays,spr,save", [(37, 64, True), (16, 192, False)])
+def test_mlp_forward_matches_oracle(ops, n_rays, spr, save):
+    from tests.emu_mlp_util import oracle_activations
+    p = synth.network_params(seed=0)
+    wpk = ops.pack_weights(dev(_flat(p)), "fwd")
+    idx = ML.forward_index()
+    src = _flat(p).numpy()
+    np.testing.assert_array_equal(wpk.cpu().numpy(), np.where(idx >= 0, src[np.maximum(idx, 0)], 0).astype(np.float32))
+    P = n_rays * spr
+    g = torch.Generator().manual_seed(3)
+    pts = torch.rand(P, 3, generator=g) * 3 - 1.5
+    vd = torch.randn(n_rays, 3, generator=g)
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+    sv = torch.full((ML.save_floats(P),), float("nan"), device="cuda") if save else None
+    raw = ops.mlp_fwd(dev(pts), dev(vd), spr, wpk, sv).cpu()
+    ref = O.query_network(p, pts.reshape(n_rays, spr, 3), vd).reshape(P, 4)
+    np.testing.assert_allclose(raw.numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+    if save:
+        from tests.emu_mlp_util import save_views
+        vps = vd[:, None, :].expand(n_rays, spr, 3).reshape(P, 3)
+        oa = oracle_activations(p, pts, vps)
+        s = save_views(sv.cpu().numpy(), P)
+        np.testing.assert_allclose(s["epts"][:, :63], oa["e"].numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(s["eviews"][:, :27], oa["ev"].numpy(), rtol=0, atol=2e-6)
+        for l in range(8):
+            np.testing.assert_allclose(s["act%d" % l], oa["acts"][l].numpy(), rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(s["feat"], oa["feat"].numpy(), rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(s["hv"], oa["hv"].numpy(), rtol=2e-5, atol=2e-5)
