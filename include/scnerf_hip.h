@@ -61,6 +61,35 @@ int scnerf_fine_sample(const float* rays, int ray_stride, const float* z_c, cons
                        float* z_samples, float* z_std, int64_t* inds, float* cdf, int n, int sc,
                        int sf, void* stream);
 
+/* ------------------------------------------------------------------ compositing ------ */
+
+/* raw2outputs, NeRF/render.py:302-355.  raw [n, s, 4]; z [n, s]; rays [n, ray_stride] (columns
+ * 3:6 = rays_d, only its norm is used); noise [n, s] = the already scaled density noise of
+ * :329-336, or NULL.  Outputs rgb_map [n,3], disp_map [n], acc_map [n]; optional depth_map [n]
+ * and weights [n, s] (needed by the hierarchical sampler). */
+int scnerf_composite_fwd(const float* raw, const float* z, const float* rays, int ray_stride,
+                         const float* noise, int white_bkgd, float* rgb_map, float* disp_map,
+                         float* acc_map, float* depth_map, float* weights, int n, int s,
+                         void* stream);
+
+/* Gradient of raw2outputs.  g_rgb [n,3], g_disp, g_acc, g_depth [n] (each may be NULL = zero);
+ * g_raw_in [n,s,4] optional gradient arriving directly at raw.  Outputs d_raw [n,s,4] and
+ * d_rays_d [n,3] (through |rays_d| of :325; may be NULL).  z_vals get no gradient (the
+ * reference detaches z_samples, :274, and near/far are constants in run_nerf.py). */
+int scnerf_composite_bwd(const float* raw, const float* z, const float* rays, int ray_stride,
+                         const float* noise, int white_bkgd, const float* g_rgb,
+                         const float* g_disp, const float* g_acc, const float* g_depth,
+                         const float* g_raw_in, float* d_raw, float* d_rays_d, int n, int s,
+                         void* stream);
+
+/* d ray_batch from the per-sample point / view-direction gradients of scnerf_mlp_bwd
+ * (pts = o + d z, NeRF/render.py:259,277; viewdirs broadcast, create_nerf.py:25):
+ * d_rays[:,0:3] = sum_s d_pts, [:,3:6] = sum_s d_pts z + extra_d, [:,8:11] = sum_s d_views,
+ * [:,6:8] = 0; accumulate != 0 adds into d_rays instead (second network). */
+int scnerf_ray_reduce(const float* d_pts, const float* d_views, const float* z,
+                      const float* extra_d, float* d_rays, int ray_stride, int accumulate, int n,
+                      int s, void* stream);
+
 /* ------------------------------------------------------------------ NeRF MLP --------- */
 
 /* dst[i] = idx[i] >= 0 ? src[idx[i]] : 0 -- packs the flat parameter buffer of one NeRF
@@ -97,6 +126,21 @@ long long scnerf_mlp_grad_floats(long long n_samples);
 int scnerf_mlp_bwd(const float* d_raw, const float* pts, const float* viewdirs,
                    int samples_per_ray, const float* wpacked_bwd, const float* save,
                    float* grads, float* d_pts, float* d_views, long long n_samples, void* stream);
+
+/* Weight / bias gradient of one nn.Linear as a GEMM reduced over the samples (what autograd
+ * derives for the layers of NeRF/run_nerf_helpers.py:88-128):
+ *   dW[n * ldo + col0 + k] = sum_p dz[p * lda + n] * x[p * ldb + k]     n < n_out, k < k_out
+ *   db[n] = sum_p dz[p * lda + n]                                         (db may be NULL)
+ *   dv[k] = sum_p vec[p * vec_stride] * x[p * ldb + k], *dvsum = sum_p vec[...]   (vec may be NULL)
+ * Columns < n_load / k_load (multiples of 4, <= 256) are read with 16-byte loads, so dz and x
+ * must be 16-byte aligned with lda, ldb multiples of 4.  The samples are split into n_chunks
+ * workgroups whose partial results are summed in a fixed order; `workspace` holds
+ * scnerf_wgrad_workspace_floats(n_load, k_load, n_chunks) floats. */
+long long scnerf_wgrad_workspace_floats(int n_load, int k_load, int n_chunks);
+int scnerf_wgrad(const float* dz, int lda, int n_load, int n_out, const float* x, int ldb,
+                 int k_load, int k_out, const float* vec, int vec_stride, long long n_samples,
+                 int n_chunks, float* workspace, float* dW, int ldo, int col0, float* db,
+                 float* dv, float* dvsum, void* stream);
 
 #ifdef __cplusplus
 }
