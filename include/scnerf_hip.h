@@ -103,11 +103,12 @@ int scnerf_mlp_layout_info(int* out, int n);
 /* Fused positional encoding + NeRF.forward for the standard network (D=8, W=256, skips=[4],
  * use_viewdirs, multires 10/4): replaces run_network + Embedder + NeRF.forward
  * (NeRF/create_nerf.py:18-32, NeRF/run_nerf_helpers.py:24-72, :105-128).
- * pts [n_samples, 3]; viewdirs [n_rays, 3] with ray(p) = p / samples_per_ray;
+ * pts [n_samples, 3]; viewdirs row r at viewdirs + r * vd_stride (3 for a packed [n_rays, 3]
+ * tensor, 11 with viewdirs = ray_batch + 8), ray(p) = p / samples_per_ray;
  * wpacked = forward packed buffer (scnerf_gather_f32 with mlp_layout.forward_index());
  * raw [n_samples, 4] = (rgb logits, sigma).  save: NULL (inference) or the activation
  * workspace of mlp_layout.SAVE_FLOATS_PER_SAMPLE * n_samples floats (training). */
-int scnerf_mlp_fwd(const float* pts, const float* viewdirs, int samples_per_ray,
+int scnerf_mlp_fwd(const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
                    const float* wpacked, float* raw, float* save, long long n_samples,
                    void* stream);
 
@@ -123,7 +124,7 @@ long long scnerf_mlp_grad_floats(long long n_samples);
  * (dZ of the 8 trunk layers, d feature, dZ of the views layer: row-major, consumed by
  * scnerf_wgrad), d_pts [n_samples, 3], d_views [n_samples, 3] (per sample, not yet summed
  * per ray). */
-int scnerf_mlp_bwd(const float* d_raw, const float* pts, const float* viewdirs,
+int scnerf_mlp_bwd(const float* d_raw, const float* pts, const float* viewdirs, int vd_stride,
                    int samples_per_ray, const float* wpacked_bwd, const float* save,
                    float* grads, float* d_pts, float* d_views, long long n_samples, void* stream);
 
@@ -141,6 +142,17 @@ int scnerf_wgrad(const float* dz, int lda, int n_load, int n_out, const float* x
                  int k_load, int k_out, const float* vec, int vec_stride, long long n_samples,
                  int n_chunks, float* workspace, float* dW, int ldo, int col0, float* db,
                  float* dv, float* dvsum, void* stream);
+
+/* All weight and bias gradients of one standard NeRF, written into a flat gradient buffer in
+ * the reference's parameter order (scnerf_nerf_param_count() floats; NeRF/run_nerf_helpers.py:
+ * 88-103): 12 scnerf_wgrad calls over the workspaces of scnerf_mlp_fwd (save) and
+ * scnerf_mlp_bwd (grads) and d_raw [n_samples, 4].  workspace:
+ * scnerf_nerf_wgrad_workspace_floats(n_chunks) floats. */
+int scnerf_nerf_param_count(void);
+long long scnerf_nerf_wgrad_workspace_floats(int n_chunks);
+int scnerf_nerf_wgrad(const float* save, const float* grads, const float* d_raw,
+                      long long n_samples, int n_chunks, float* workspace, float* flat_grad,
+                      void* stream);
 
 #ifdef __cplusplus
 }

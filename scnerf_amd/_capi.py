@@ -27,15 +27,18 @@ PROTOTYPES = {
     "scnerf_ray_reduce": [P, P, P, P, P, I, I, I, I, P],
     "scnerf_gather_f32": [P, P, P, LL, P],
     "scnerf_mlp_layout_info": [P, I],
-    "scnerf_mlp_fwd": [P, P, I, P, P, P, LL, P],
-    "scnerf_mlp_bwd": [P, P, P, I, P, P, P, P, P, LL, P],
+    "scnerf_mlp_fwd": [P, P, I, I, P, P, P, LL, P],
+    "scnerf_mlp_bwd": [P, P, P, I, I, P, P, P, P, P, LL, P],
+    "scnerf_nerf_param_count": [],
+    "scnerf_nerf_wgrad": [P, P, P, LL, I, P, P, P],
     "scnerf_wgrad": [P, I, I, I, P, I, I, I, P, I, LL, I, P, P, I, I, P, P, P, P],
 }
 
 
 # functions returning long long instead of a status
 SIZE_FUNCS = {"scnerf_mlp_save_floats": [LL], "scnerf_mlp_grad_floats": [LL],
-              "scnerf_wgrad_workspace_floats": [I, I, I]}
+              "scnerf_wgrad_workspace_floats": [I, I, I],
+              "scnerf_nerf_wgrad_workspace_floats": [I]}
 
 
 def bind(lib: ctypes.CDLL) -> ctypes.CDLL:

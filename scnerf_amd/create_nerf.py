@@ -1,0 +1,149 @@
+"""Mirror of the reference's `create_nerf` module (/root/reference NeRF/create_nerf.py) for the
+render path: `run_network`, `batchify`, `create_nerf` (the render_kwargs contract, :71-93).
+
+The reference hides the embedders inside an opaque lambda (`network_query_fn`, :67-69); here it
+is a `FusedNetworkQuery` object that carries the embedder configuration so `render_rays` can check
+that the fused kernels (multires 10 / 4 compiled in) match what the caller asked for, and that can
+still be *called* like the reference's closure: query(pts, viewdirs, network_fn) -> raw."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import mlp_layout as ML
+from . import ops
+from .run_nerf_helpers import NeRF, get_embedder
+
+
+def _unwrap(net):
+    return net.module if isinstance(net, nn.DataParallel) else net
+
+
+class _QueryFunction(torch.autograd.Function):
+    """raw = network(pts, viewdirs) as one differentiable node (fused PE + MLP)."""
+
+    @staticmethod
+    def forward(ctx, pts, viewdirs, net, *params):
+        shape = pts.shape
+        spr = int(shape[-2]) if pts.dim() >= 3 else 1
+        p = pts.reshape(-1, 3).contiguous().float()
+        v = viewdirs.reshape(-1, 3).contiguous().float()
+        if p.shape[0] != v.shape[0] * spr:
+            raise ValueError("pts [..., S, 3] and viewdirs [..., 3] disagree: %s vs %s" % (tuple(shape), tuple(viewdirs.shape)))
+        train = any(ctx.needs_input_grad)
+        flat = net.flat_parameters()
+        save = ops.save_workspace(p.shape[0], p.device) if train else None
+        raw = ops.mlp_fwd(p, v, spr, ops.pack_weights(flat, "fwd"), save)
+        ctx.state = (p, v, spr, save, ops.pack_weights(flat, "bwd") if train else None, shape, viewdirs.shape)
+        return raw.view(*shape[:-1], 4)
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        p, v, spr, save, wbk, shape, vshape = ctx.state
+        d_raw = g_raw.reshape(-1, 4).contiguous().float()
+        grads, d_pts, d_views = ops.mlp_bwd(d_raw, p, v, spr, wbk, save)
+        flat_grad = ops.nerf_wgrad(save, grads, d_raw, p.shape[0])
+        d_v = d_views.view(-1, spr, 3).sum(1).view(vshape)
+        gs = [flat_grad[ML.PARAM_OFFSETS[n]: ML.PARAM_OFFSETS[n] + int(torch.Size(s).numel())].view(s)
+              for n, s in ML.PARAM_SHAPES]
+        ctx.state = None
+        return (d_pts.view(shape), d_v, None, *gs)
+
+
+def run_network(inputs, viewdirs, fn, embed_fn=None, embeddirs_fn=None, netchunk=1024 * 64):
+    """Prepares inputs and applies network `fn` (reference :18-32).  inputs [N, S, 3], viewdirs
+    [N, 3] -> [N, S, 4].  The encodings and the MLP run as one fused kernel, so `netchunk` (a memory
+    workaround of the reference) is accepted and ignored."""
+    net = _unwrap(fn)
+    if not isinstance(net, NeRF):
+        raise TypeError("run_network needs a scnerf_amd.NeRF")
+    net.require_standard()
+    for emb, want in ((embed_fn, ML.L_PTS), (embeddirs_fn, ML.L_VIEWS)):
+        if emb is not None and getattr(emb, "num_freqs", want) != want:
+            raise NotImplementedError("fused kernels are built for multires %d / %d" % (ML.L_PTS, ML.L_VIEWS))
+    if viewdirs is None:
+        raise NotImplementedError("the fused network is the use_viewdirs=True one")
+    return _QueryFunction.apply(inputs, viewdirs, net, *net.ordered_parameters())
+
+
+class FusedNetworkQuery:
+    """Callable stand-in for the reference's `network_query_fn` closure (:67-69)."""
+    is_fused_query = True
+
+    def __init__(self, embed_fn, embeddirs_fn, netchunk=None):
+        self.embed_fn, self.embeddirs_fn, self.netchunk = embed_fn, embeddirs_fn, netchunk
+
+    def check(self, net: NeRF):
+        net.require_standard()
+        if getattr(self.embed_fn, "num_freqs", None) != ML.L_PTS or \
+                getattr(self.embeddirs_fn, "num_freqs", None) != ML.L_VIEWS:
+            raise NotImplementedError("fused kernels are built for multires %d / multires_views %d"
+                                      % (ML.L_PTS, ML.L_VIEWS))
+
+    def __call__(self, inputs, viewdirs, network_fn):
+        return run_network(inputs, viewdirs, network_fn, self.embed_fn, self.embeddirs_fn, self.netchunk)
+
+
+def batchify(fn, chunk):
+    """Kept for API parity (reference :187-196); the fused kernel needs no chunking."""
+    if chunk is None:
+        return fn
+
+    def ret(inputs):
+        return torch.cat([fn(inputs[i:i + chunk]) for i in range(0, inputs.shape[0], chunk)], 0)
+    return ret
+
+
+def create_nerf(args, noisy_focal, noisy_poses, H, W, mode="train", device="cuda"):
+    """Instantiate the coarse / fine networks, the query object, the render kwargs, the camera model
+    and the optimizer with the reference's structure and return order (:34-184):
+    (render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer, camera_model).
+    Checkpoint reloading (:142-172) is left to the caller's driver."""
+    camera_model = None
+    embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
+    input_ch_views = 0
+    embeddirs_fn = None
+    if args.use_viewdirs:
+        embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
+    output_ch = 5 if args.N_importance > 0 else 4
+    skips = [4]
+    model = NeRF(D=args.netdepth, W=args.netwidth, input_ch=input_ch, output_ch=output_ch, skips=skips,
+                 input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs)
+    model = nn.DataParallel(model).to(device)       # container only: keeps the 'module.' checkpoint keys
+    grad_vars = list(model.parameters())
+    model_fine = None
+    if args.N_importance > 0:
+        model_fine = NeRF(D=args.netdepth_fine, W=args.netwidth_fine, input_ch=input_ch, output_ch=output_ch,
+                          skips=skips, input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs)
+        model_fine = nn.DataParallel(model_fine).to(device)
+        grad_vars += list(model_fine.parameters())
+
+    network_query_fn = FusedNetworkQuery(embed_fn, embeddirs_fn,
+                                         getattr(args, "netchunk_per_gpu", 0) * getattr(args, "n_gpus", 1))
+    render_kwargs_train = {
+        'network_query_fn': network_query_fn, 'perturb': args.perturb, 'N_importance': args.N_importance,
+        'network_fine': model_fine, 'N_samples': args.N_samples, 'network_fn': model,
+        'use_viewdirs': args.use_viewdirs, 'white_bkgd': args.white_bkgd, 'raw_noise_std': args.raw_noise_std,
+    }
+    if args.dataset_type != 'llff' or args.no_ndc:
+        render_kwargs_train['ndc'] = False
+        render_kwargs_train['lindisp'] = args.lindisp
+    render_kwargs_test = {k: render_kwargs_train[k] for k in render_kwargs_train}
+    render_kwargs_test['perturb'] = False
+    render_kwargs_test['raw_noise_std'] = 0.
+
+    if args.camera_model != "none":
+        from .camera_dict import camera_dict
+        cw_init, ch_init = W / 2, H / 2
+        fx_init = W if args.run_without_colmap != "none" else noisy_focal
+        fy_init = H if args.run_without_colmap != "none" else noisy_focal
+        intrinsic_init = torch.tensor([[fx_init, 0, cw_init, 0], [0, fy_init, ch_init, 0],
+                                       [0, 0, 1, 0], [0, 0, 0, 1]])
+        with torch.no_grad():
+            camera_model = camera_dict[args.camera_model](
+                intrinsics=intrinsic_init, extrinsics=noisy_poses, args=args, H=H, W=W).to(device)
+        grad_vars += list(camera_model.parameters())
+
+    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    start = 0
+    return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer, camera_model

@@ -63,7 +63,7 @@ __device__ __forceinline__ void pe_backward(float x, float y, float z, int h, co
 
 __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
     const float* __restrict__ d_raw, const float* __restrict__ pts, const float* __restrict__ viewdirs,
-    int samples_per_ray, const float* __restrict__ wbk, const float* __restrict__ save,
+    int vd_stride, int samples_per_ray, const float* __restrict__ wbk, const float* __restrict__ save,
     float* __restrict__ grads, float* __restrict__ d_pts, float* __restrict__ d_views, long P) {
     const int lane = lane_id();
     const int m = lane & 31, h = lane >> 5;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
         for (int r = 0; r < 16; ++r) dev[r] = acce1[0][r];
         const long ray = pc / samples_per_ray;
         float gxy, gz;
-        pe_backward<4, 16>(viewdirs[ray * 3 + 0], viewdirs[ray * 3 + 1], viewdirs[ray * 3 + 2], h, dev, &gxy, &gz);
+        pe_backward<4, 16>(viewdirs[ray * vd_stride + 0], viewdirs[ray * vd_stride + 1], viewdirs[ray * vd_stride + 2], h, dev, &gxy, &gz);
         const float oxy = shfl_xor(gxy, 32), oz = shfl_xor(gz, 32);
         if (live && h == 0) {
             d_views[p * 3 + 0] = gxy;
@@ -180,16 +180,16 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
 
 }  // namespace
 
-extern "C" int scnerf_mlp_bwd(const float* d_raw, const float* pts, const float* viewdirs,
+extern "C" int scnerf_mlp_bwd(const float* d_raw, const float* pts, const float* viewdirs, int vd_stride,
                               int samples_per_ray, const float* wpacked_bwd, const float* save,
                               float* grads, float* d_pts, float* d_views, long long n_samples,
                               void* stream) {
     SCN_RETURN_IF(!d_raw || !pts || !viewdirs || !wpacked_bwd || !save || !grads || !d_pts || !d_views, SCN_EINVAL);
-    SCN_RETURN_IF(samples_per_ray < 1 || n_samples < 0, SCN_EINVAL);
+    SCN_RETURN_IF(samples_per_ray < 1 || vd_stride < 3 || n_samples < 0, SCN_EINVAL);
     if (n_samples == 0) return 0;
     const size_t lds = (size_t)2 * kMaxChunkBwd * sizeof(float);
     hipLaunchKernelGGL(mlp_bwd_kernel, dim3(scn_ceil_div(n_samples, kSamplesPerBlock)), dim3(kThreads), lds,
-                       (hipStream_t)stream, d_raw, pts, viewdirs, samples_per_ray, wpacked_bwd, save, grads,
+                       (hipStream_t)stream, d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads,
                        d_pts, d_views, (long)n_samples);
     return scn_launch_status();
 }

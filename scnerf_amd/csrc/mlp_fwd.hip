@@ -49,7 +49,7 @@ __device__ __forceinline__ void store_pe(const float (&e)[NS], float* __restrict
 }
 
 __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
-    const float* __restrict__ pts, const float* __restrict__ viewdirs, int samples_per_ray,
+    const float* __restrict__ pts, const float* __restrict__ viewdirs, int vd_stride, int samples_per_ray,
     const float* __restrict__ wpk, float* __restrict__ raw, float* __restrict__ save, long P) {
     const int lane = lane_id();
     const int m = lane & 31, h = lane >> 5;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     // colour head: views layer on [feature | encoded view direction]
     const long ray = pc / samples_per_ray;
     float ev[16];
-    pe_slots<4, 16>(viewdirs[ray * 3 + 0], viewdirs[ray * 3 + 1], viewdirs[ray * 3 + 2], h, ev);
+    pe_slots<4, 16>(viewdirs[ray * vd_stride + 0], viewdirs[ray * vd_stride + 1], viewdirs[ray * vd_stride + 2], h, ev);
     if (save) store_pe<4, 16>(ev, save + (long)kSaveEviews * P, pc, 32, h, live);
     f32x16 accv[4];
     init_bias<4>(accv, wpk + kFwdBiasV, h);
@@ -159,14 +159,14 @@ extern "C" long long scnerf_mlp_grad_floats(long long n_samples) {
     return (long long)kGradPerSample * n_samples;
 }
 
-extern "C" int scnerf_mlp_fwd(const float* pts, const float* viewdirs, int samples_per_ray,
+extern "C" int scnerf_mlp_fwd(const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
                               const float* wpacked, float* raw, float* save, long long n_samples,
                               void* stream) {
-    SCN_RETURN_IF(!pts || !viewdirs || !wpacked || !raw || samples_per_ray < 1 || n_samples < 0, SCN_EINVAL);
+    SCN_RETURN_IF(!pts || !viewdirs || !wpacked || !raw || samples_per_ray < 1 || vd_stride < 3 || n_samples < 0, SCN_EINVAL);
     if (n_samples == 0) return 0;
     const size_t lds = (size_t)2 * kMaxChunkFwd * sizeof(float);
     hipLaunchKernelGGL(mlp_fwd_kernel, dim3(scn_ceil_div(n_samples, kSamplesPerBlock)), dim3(kThreads), lds,
-                       (hipStream_t)stream, pts, viewdirs, samples_per_ray, wpacked, raw, save,
+                       (hipStream_t)stream, pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save,
                        (long)n_samples);
     return scn_launch_status();
 }

@@ -15,6 +15,7 @@
 #include <scn_wave.h>
 
 #include "launch.h"
+#include "mlp_common.h"
 #include "scnerf_hip.h"
 
 namespace {
@@ -270,4 +271,61 @@ extern "C" int scnerf_wgrad(const float* dz, int lda, int n_load, int n_out, con
                        a.part_b, a.part_v, G, s.BN, s.BK, n_out, k_out, dW, ldo, col0, db,
                        vec ? dv : nullptr, vec ? dvsum : nullptr);
     return scn_launch_status();
+}
+
+// ---- all weight gradients of one standard NeRF (D=8, W=256, skip 4, view-dependent head) ----
+namespace {
+// flat parameter offsets, reference registration order (mirrors mlp_layout.PARAM_OFFSETS)
+constexpr int kW0 = 0, kB0 = kW0 + 256 * 63;
+constexpr int kTrunk1 = kB0 + 256;                       // layers 1..7: weight then bias
+constexpr int trunk_w(int l) { return l <= 5 ? kTrunk1 + (l - 1) * (256 * 256 + 256) : kTrunk1 + 4 * (256 * 256 + 256) + (256 * 319 + 256) + (l - 6) * (256 * 256 + 256); }
+constexpr int trunk_b(int l) { return trunk_w(l) + (l == 5 ? 256 * 319 : 256 * 256); }
+constexpr int kWV = trunk_b(7) + 256, kBV = kWV + 128 * 283;
+constexpr int kWF = kBV + 128, kBF = kWF + 256 * 256;
+constexpr int kWA = kBF + 256, kBA = kWA + 256;
+constexpr int kWRGB = kBA + 1, kBRGB = kWRGB + 3 * 128;
+constexpr int kNParams = kBRGB + 3;
+static_assert(kNParams == 595844, "parameter count of the standard NeRF");
+}  // namespace
+
+extern "C" int scnerf_nerf_param_count(void) { return kNParams; }
+
+extern "C" int scnerf_nerf_wgrad(const float* save, const float* grads, const float* d_raw,
+                                 long long n_samples, int n_chunks, float* workspace, float* flat_grad,
+                                 void* stream) {
+    using namespace scn::mlp;
+    SCN_RETURN_IF(!save || !grads || !d_raw || !workspace || !flat_grad || n_samples < 1 || n_chunks < 1, SCN_EINVAL);
+    const long long P = n_samples;
+    auto S = [&](int sec) { return save + (long long)sec * P; };
+    auto G = [&](int sec) { return grads + (long long)sec * P; };
+    auto act = [&](int l) { return S(kSaveAct + 256 * l); };
+    auto dz = [&](int l) { return G(kGradDz + 256 * l); };
+    float* g = flat_grad;
+    int rc;
+#define SCN_WG(...)                          \
+    rc = scnerf_wgrad(__VA_ARGS__, stream);  \
+    if (rc != 0) return rc;
+    // layer 0: X = encoded points (63 valid of 64 columns)
+    SCN_WG(dz(0), 256, 256, 256, S(kSaveEpts), 64, 64, 63, nullptr, 0, P, n_chunks, workspace, g + kW0, 63, 0, g + kB0, nullptr, nullptr)
+    for (int l = 1; l <= 7; ++l) {
+        if (l == 5) {
+            SCN_WG(dz(5), 256, 256, 256, S(kSaveEpts), 64, 64, 63, nullptr, 0, P, n_chunks, workspace, g + trunk_w(5), 319, 0, nullptr, nullptr, nullptr)
+            SCN_WG(dz(5), 256, 256, 256, act(4), 256, 256, 256, nullptr, 0, P, n_chunks, workspace, g + trunk_w(5), 319, 63, g + trunk_b(5), nullptr, nullptr)
+        } else {
+            SCN_WG(dz(l), 256, 256, 256, act(l - 1), 256, 256, 256, nullptr, 0, P, n_chunks, workspace, g + trunk_w(l), 256, 0, g + trunk_b(l), nullptr, nullptr)
+        }
+    }
+    // feature_linear (+ alpha_linear as the rank-1 side product with v = d sigma = d_raw[:, 3])
+    SCN_WG(G(kGradDfeat), 256, 256, 256, act(7), 256, 256, 256, d_raw + 3, 4, P, n_chunks, workspace, g + kWF, 256, 0, g + kBF, g + kWA, g + kBA)
+    // views layer: [feature | encoded direction]
+    SCN_WG(G(kGradDzv), 128, 128, 128, S(kSaveFeat), 256, 256, 256, nullptr, 0, P, n_chunks, workspace, g + kWV, 283, 0, g + kBV, nullptr, nullptr)
+    SCN_WG(G(kGradDzv), 128, 128, 128, S(kSaveEviews), 32, 32, 27, nullptr, 0, P, n_chunks, workspace, g + kWV, 283, 256, nullptr, nullptr, nullptr)
+    // rgb_linear: dZ = d_raw[:, 0:3]
+    SCN_WG(d_raw, 4, 4, 3, S(kSaveHv), 128, 128, 128, nullptr, 0, P, n_chunks, workspace, g + kWRGB, 128, 0, g + kBRGB, nullptr, nullptr)
+#undef SCN_WG
+    return 0;
+}
+
+extern "C" long long scnerf_nerf_wgrad_workspace_floats(int n_chunks) {
+    return scnerf_wgrad_workspace_floats(256, 256, n_chunks);
 }

@@ -14,6 +14,51 @@ from . import mlp_layout as ML
 Tensor = torch.Tensor
 
 
+class _Profile:
+    """HIP-event timers around the heavy launches (off unless bench.py switches it on).  Events are
+    recorded on torch's current stream, which is the stream the kernels are enqueued on."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}
+
+    def reset(self, enabled=False):
+        self.records = {}
+        self.enabled = enabled
+
+    class _Region:
+        def __init__(self, prof, name, flop, group):
+            self.prof, self.name, self.flop, self.group = prof, name, flop, group
+
+        def __enter__(self):
+            if self.prof.enabled:
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e1 = torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+            return self
+
+        def __exit__(self, *exc):
+            if self.prof.enabled:
+                self.e1.record()
+                self.prof.records.setdefault(self.name, []).append((self.e0, self.e1, self.flop, self.group))
+            return False
+
+    def region(self, name, flop=0, group=False):
+        return _Profile._Region(self, name, flop, group)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _, _ in recs]
+            out[name] = {"launches": len(recs), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms),
+                         "flop_per_launch": recs[0][2], "group": recs[0][3]}
+        return out
+
+
+PROFILE = _Profile()
+
+
 def _p(t: Optional[Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -130,9 +175,20 @@ def pack_weights(flat_params: Tensor, kind: str = "fwd", out: Optional[Tensor] =
     return out
 
 
+def _vd(viewdirs: Tensor):
+    """(pointer, row stride) of a [n,3] fp32 view-direction tensor that may be a column slice
+    of the packed ray batch (ray_batch[:, 8:11])."""
+    if viewdirs.dtype != torch.float32 or not viewdirs.is_cuda or viewdirs.dim() != 2 or viewdirs.shape[1] != 3:
+        raise TypeError("viewdirs must be a CUDA fp32 [n,3] tensor")
+    if viewdirs.stride(1) != 1:
+        raise ValueError("viewdirs rows must be dense")
+    return viewdirs.data_ptr(), int(viewdirs.stride(0)) if viewdirs.shape[0] > 1 else 3
+
+
 def mlp_fwd(pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked: Tensor,
             save: Optional[Tensor] = None) -> Tensor:
-    _f(pts, "pts"), _f(viewdirs, "viewdirs"), _f(wpacked, "wpacked")
+    _f(pts, "pts"), _f(wpacked, "wpacked")
+    vptr, vstride = _vd(viewdirs)
     P = pts.numel() // 3
     if wpacked.numel() != ML.FWD_TOTAL:
         raise ValueError("wpacked has the wrong size")
@@ -141,7 +197,99 @@ def mlp_fwd(pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked: Tensor
         if save.numel() < ML.save_floats(P):
             raise ValueError("activation workspace too small")
     raw = torch.empty((P, 4), dtype=torch.float32, device=pts.device)
-    st = _capi.load().scnerf_mlp_fwd(_p(pts), _p(viewdirs), int(samples_per_ray), _p(wpacked), _p(raw),
-                                     _p(save), P, _stream())
+    with PROFILE.region("mlp_fwd_kernel/P=%d/%s" % (P, "train" if save is not None else "infer"), 2 * 593408 * P):
+        st = _capi.load().scnerf_mlp_fwd(_p(pts), vptr, vstride, int(samples_per_ray), _p(wpacked), _p(raw),
+                                         _p(save), P, _stream())
     _capi.check(st, "scnerf_mlp_fwd")
     return raw
+
+
+def save_workspace(P: int, device) -> Tensor:
+    return torch.empty(ML.save_floats(P), dtype=torch.float32, device=device)
+
+
+def mlp_bwd(d_raw: Tensor, pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked_bwd: Tensor,
+            save: Tensor):
+    """-> (grads workspace, d_pts [P,3], d_views [P,3])."""
+    _f(d_raw, "d_raw"), _f(pts, "pts"), _f(wpacked_bwd, "wpacked_bwd"), _f(save, "save")
+    vptr, vstride = _vd(viewdirs)
+    P = pts.numel() // 3
+    if wpacked_bwd.numel() != ML.BWD_TOTAL:
+        raise ValueError("wpacked_bwd has the wrong size")
+    dev = pts.device
+    grads = torch.empty(ML.GRAD_FLOATS_PER_SAMPLE * P, dtype=torch.float32, device=dev)
+    d_pts = torch.empty((P, 3), dtype=torch.float32, device=dev)
+    d_views = torch.empty((P, 3), dtype=torch.float32, device=dev)
+    with PROFILE.region("mlp_bwd_kernel/P=%d" % P, 2 * 593408 * P):
+        st = _capi.load().scnerf_mlp_bwd(_p(d_raw), _p(pts), vptr, vstride, int(samples_per_ray), _p(wpacked_bwd),
+                                         _p(save), _p(grads), _p(d_pts), _p(d_views), P, _stream())
+    _capi.check(st, "scnerf_mlp_bwd")
+    return grads, d_pts, d_views
+
+
+def wgrad_chunks(P: int) -> int:
+    """workgroups the sample axis is split into (one per CU at full size)."""
+    return int(max(1, min(256, P // 256)))
+
+
+_wgrad_ws = {}
+
+
+def nerf_wgrad(save: Tensor, grads: Tensor, d_raw: Tensor, P: int, flat_grad: Optional[Tensor] = None) -> Tensor:
+    """All parameter gradients of one network -> flat buffer (reference parameter order)."""
+    lib = _capi.load()
+    chunks = wgrad_chunks(P)
+    key = (chunks, str(save.device))
+    if key not in _wgrad_ws:
+        _wgrad_ws[key] = torch.empty(lib.scnerf_nerf_wgrad_workspace_floats(chunks), dtype=torch.float32,
+                                     device=save.device)
+    if flat_grad is None:
+        flat_grad = torch.empty(ML.N_PARAMS, dtype=torch.float32, device=save.device)
+    with PROFILE.region("wgrad(12 GEMMs + reduces)/P=%d" % P, 2 * 593408 * P, group=True):
+        st = lib.scnerf_nerf_wgrad(_p(save), _p(grads), _p(d_raw), P, chunks, _p(_wgrad_ws[key]), _p(flat_grad),
+                                   _stream())
+    _capi.check(st, "scnerf_nerf_wgrad")
+    return flat_grad
+
+
+def composite_fwd(raw: Tensor, z: Tensor, rays: Tensor, noise: Optional[Tensor], white_bkgd: bool,
+                  want_weights=True):
+    _f(raw, "raw"), _f(z, "z"), _f(rays, "rays")
+    if noise is not None:
+        _f(noise, "noise")
+    n, s = z.shape
+    dev = z.device
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    disp = torch.empty((n,), dtype=torch.float32, device=dev)
+    acc = torch.empty((n,), dtype=torch.float32, device=dev)
+    depth = torch.empty((n,), dtype=torch.float32, device=dev)
+    w = torch.empty((n, s), dtype=torch.float32, device=dev) if want_weights else None
+    st = _capi.load().scnerf_composite_fwd(_p(raw), _p(z), _p(rays), rays.shape[1], _p(noise),
+                                           int(bool(white_bkgd)), _p(rgb), _p(disp), _p(acc), _p(depth),
+                                           _p(w), n, s, _stream())
+    _capi.check(st, "scnerf_composite_fwd")
+    return rgb, disp, acc, w, depth
+
+
+def composite_bwd(raw, z, rays, noise, white_bkgd, g_rgb, g_disp, g_acc, g_depth, g_raw_in, want_d_rays_d=True):
+    n, s = z.shape
+    dev = z.device
+    for name, t_ in (("g_rgb", g_rgb), ("g_disp", g_disp), ("g_acc", g_acc), ("g_depth", g_depth),
+                     ("g_raw_in", g_raw_in)):
+        if t_ is not None:
+            _f(t_, name)
+    d_raw = torch.empty((n, s, 4), dtype=torch.float32, device=dev)
+    d_rd = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_d_rays_d else None
+    st = _capi.load().scnerf_composite_bwd(_p(raw), _p(z), _p(rays), rays.shape[1], _p(noise),
+                                           int(bool(white_bkgd)), _p(g_rgb), _p(g_disp), _p(g_acc),
+                                           _p(g_depth), _p(g_raw_in), _p(d_raw), _p(d_rd), n, s, _stream())
+    _capi.check(st, "scnerf_composite_bwd")
+    return d_raw, d_rd
+
+
+def ray_reduce(d_pts, d_views, z, extra_d, d_rays, accumulate: bool):
+    n, s = z.shape
+    st = _capi.load().scnerf_ray_reduce(_p(d_pts), _p(d_views), _p(z), _p(extra_d), _p(d_rays),
+                                        d_rays.shape[1], int(bool(accumulate)), n, s, _stream())
+    _capi.check(st, "scnerf_ray_reduce")
+    return d_rays

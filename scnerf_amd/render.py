@@ -1,0 +1,245 @@
+"""MI355X-native drop-in for the reference's `render` module (/root/reference NeRF/render.py):
+same function names, arguments, return structures and quirks, with the work done by the HIP
+kernels behind include/scnerf_hip.h.
+
+    render(...)            :18-141     render_path(...)   :143-183
+    render_rays(...)       :186-300    raw2outputs(...)   :302-355
+    ndc_rays / ndc_rays_camera :357-396
+    batchify_rays(...)     :398-413    sample_pdf(...)    :417-460
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .functional import RawToOutputsFunction, RenderConfig, RenderRaysFunction, host_linspace
+from .get_rays import (get_rays_full_image_no_camera, get_rays_full_image_use_camera,
+                       get_rays_kps_no_camera, get_rays_kps_use_camera, ndc_rays, ndc_rays_camera)
+from .run_nerf_helpers import NeRF
+
+to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)
+
+# The reference prints a warning when an output holds NaN/Inf (:296-298), which costs 7 device->host
+# synchronisations per chunk.  Off by default here; SCNERF_CHECK_NUMERICS=1 or verbose=True restores it.
+CHECK_NUMERICS = os.environ.get("SCNERF_CHECK_NUMERICS", "0") == "1"
+
+
+def _unwrap(net):
+    """create_nerf wraps the networks in nn.DataParallel for checkpoint-key compatibility
+    (reference create_nerf.py:56,64); the kernels want the module itself."""
+    return net.module if isinstance(net, nn.DataParallel) else net
+
+
+def _device_rand(shape, device, pytest):
+    if pytest:                                    # the reference's fixed numpy stream (:252-255, :432-440)
+        np.random.seed(0)
+        return torch.Tensor(np.random.rand(*shape)).to(device)
+    return torch.rand(shape, device=device)
+
+
+def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False,
+                perturb=0., N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0.,
+                verbose=False, pytest=False, _randoms=None):
+    """Volumetric rendering of a ray batch; see the reference docstring (:199-231) for the
+    arguments and the returned dict (rgb_map, disp_map, acc_map[, raw][, rgb0, disp0, acc0, z_std]).
+
+    `network_query_fn` must be the FusedNetworkQuery made by scnerf_amd.create_nerf (it carries the
+    embedder configuration the fused kernels were built for).  `_randoms` (tests only) injects
+    dict(t_rand=, u=, noise_c=, noise_f=) instead of drawing them."""
+    net_c = _unwrap(network_fn)
+    net_f = _unwrap(network_fine) if network_fine is not None else None
+    if not isinstance(net_c, NeRF) or (net_f is not None and not isinstance(net_f, NeRF)):
+        raise TypeError("render_rays needs scnerf_amd.NeRF networks (got %s)" % type(net_c).__name__)
+    if not getattr(network_query_fn, "is_fused_query", False):
+        raise TypeError("network_query_fn must come from scnerf_amd.create_nerf (FusedNetworkQuery)")
+    network_query_fn.check(net_c)
+    if not ray_batch.is_cuda:
+        raise RuntimeError("ray_batch must be on the GPU: scnerf_amd has no CPU path")
+    n = ray_batch.shape[0]
+    dev = ray_batch.device
+    r = _randoms or {}
+    t_rand = u = noise_c = noise_f = None
+    if perturb > 0.:
+        t_rand = r["t_rand"] if "t_rand" in r else _device_rand((n, N_samples), dev, pytest)
+    if raw_noise_std > 0.:
+        if "noise_c" in r:
+            noise_c = r["noise_c"]
+        elif pytest:                              # uniform, not normal, in this mode (:333-336)
+            np.random.seed(0)
+            noise_c = torch.Tensor(np.random.rand(n, N_samples) * raw_noise_std).to(dev)
+        else:
+            noise_c = torch.randn((n, N_samples), device=dev) * raw_noise_std
+    if N_importance > 0:
+        if perturb > 0.:
+            u = r["u"] if "u" in r else _device_rand((n, N_importance), dev, pytest)
+        if raw_noise_std > 0.:
+            tot = N_samples + N_importance
+            if "noise_f" in r:
+                noise_f = r["noise_f"]
+            elif pytest:
+                np.random.seed(0)
+                noise_f = torch.Tensor(np.random.rand(n, tot) * raw_noise_std).to(dev)
+            else:
+                noise_f = torch.randn((n, tot), device=dev) * raw_noise_std
+    cfg = RenderConfig(int(N_samples), int(N_importance), bool(lindisp), bool(white_bkgd))
+    params = list(net_c.ordered_parameters()) + (list(net_f.ordered_parameters()) if net_f is not None else [])
+    (rgb_map, disp_map, acc_map, depth_map, raw, rgb0, disp0, acc0, depth0, z_std, z_vals,
+     z_samples) = RenderRaysFunction.apply(ray_batch, cfg, t_rand, u, noise_c, noise_f, net_c, net_f, *params)
+
+    ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map}
+    if retraw:
+        ret['raw'] = raw
+    if N_importance > 0:
+        ret['rgb0'] = rgb0
+        ret['disp0'] = disp0
+        ret['acc0'] = acc0
+        ret['z_std'] = z_std
+    if CHECK_NUMERICS or verbose:
+        for k in ret:
+            if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():
+                print(f"! [Numerical Error] {k} contains nan or inf.")
+    return ret
+
+
+def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
+    """Render rays in chunks (reference :398-413), including its in-place saturation of the colour
+    outputs at 1 -- which also zeroes the gradient of saturated pixels."""
+    all_ret = {}
+    for i in range(0, rays_flat.shape[0], chunk):
+        ret = render_rays(rays_flat[i:i + chunk], **kwargs)
+        for key in ["rgb0", "rgb1", "rgb_map"]:
+            if key in ret.keys():
+                ret[key][ret[key] >= 1.0] = 1.0
+        for k in ret:
+            all_ret.setdefault(k, []).append(ret[k])
+    return {k: (torch.cat(all_ret[k], 0) if len(all_ret[k]) > 1 else all_ret[k][0]) for k in all_ret}
+
+
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False, _noise=None):
+    """raw [N,S,4|5], z_vals [N,S], rays_d [N,3] -> (rgb_map, disp_map, acc_map, weights, depth_map)
+    (reference :302-355)."""
+    noise = _noise
+    if noise is None and raw_noise_std > 0.:
+        shape = tuple(raw[..., 3].shape)
+        if pytest:
+            np.random.seed(0)
+            noise = torch.Tensor(np.random.rand(*shape) * raw_noise_std).to(raw.device)
+        else:
+            noise = torch.randn(shape, device=raw.device) * raw_noise_std
+    return RawToOutputsFunction.apply(raw, z_vals, rays_d, noise, bool(white_bkgd))
+
+
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False, _u=None):
+    """Hierarchical sampling (reference :417-460); bins [N,B], weights [N,B-1] -> samples [N,N_samples].
+    The samples are returned detached (render_rays detaches them anyway, :274)."""
+    n = bins.shape[0]
+    dev = bins.device
+    if _u is not None:
+        u = _u
+    elif det:
+        u = host_linspace(N_samples, dev)
+    elif pytest:
+        np.random.seed(0)
+        u = torch.Tensor(np.random.rand(n, N_samples)).to(dev)
+    else:
+        u = torch.rand((n, N_samples), device=dev)
+    samples, _, _ = ops.sample_pdf(bins.detach().contiguous().float(), weights.detach().contiguous().float(),
+                                   u.contiguous().float())
+    return samples
+
+
+def render(H, W, chunk, rays=None, noisy_focal=None, noisy_extrinsic=None, ndc=True, near=0., far=1.,
+           use_viewdirs=False, mode=None, camera_model=None, image_idx=None, i_map=None, gt_intrinsic=None,
+           gt_extrinsic=None, transform_align=None, **kwargs):
+    """Same ray-source selection, view-direction / NDC handling and return structure as the
+    reference (:18-141)."""
+    assert not mode is None
+    if not rays is None:
+        if camera_model is None:
+            focal = noisy_focal
+        rays_o, rays_d = rays
+    elif not camera_model is None and mode == "train":
+        assert not i_map is None
+        assert image_idx in i_map
+        assert gt_intrinsic is None
+        assert gt_extrinsic is None
+        idx_in_camera_param = np.where(i_map == image_idx)[0][0]
+        rays_o, rays_d = get_rays_full_image_use_camera(
+            H=H, W=W, camera_model=camera_model, extrinsic=noisy_extrinsic[idx_in_camera_param])
+    elif not camera_model is None and mode in ["val", "test"]:
+        assert noisy_focal is None
+        assert noisy_extrinsic is None
+        rays_o, rays_d = get_rays_full_image_use_camera(
+            H=H, W=W, camera_model=camera_model, extrinsic=transform_align)
+    elif camera_model is None and mode == "train":
+        assert not noisy_focal is None
+        assert not noisy_extrinsic is None
+        focal = noisy_focal
+        rays_o, rays_d = get_rays_full_image_no_camera(H=H, W=W, focal=focal, extrinsic=noisy_extrinsic[image_idx])
+    elif camera_model is None and mode in ["val", "test"]:
+        assert not gt_extrinsic is None
+        assert noisy_focal is None
+        assert noisy_extrinsic is None
+        focal = gt_intrinsic[0][0].item()
+        rays_o, rays_d = get_rays_full_image_no_camera(H=H, W=W, focal=focal, extrinsic=gt_extrinsic[image_idx])
+    else:
+        assert False, "This message should not appear."
+
+    if use_viewdirs:
+        viewdirs = rays_d                                   # taken BEFORE the NDC warp (:105-109)
+        viewdirs = viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True)
+        viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+
+    sh = rays_d.shape
+    if ndc and camera_model is None:
+        rays_o, rays_d = ndc_rays(H, W, focal, 1., rays_o, rays_d)
+    elif ndc and not camera_model is None:
+        rays_o, rays_d = ndc_rays_camera(H, W, camera_model, 1., rays_o, rays_d)
+
+    rays_o = torch.reshape(rays_o, [-1, 3]).float()
+    rays_d = torch.reshape(rays_d, [-1, 3]).float()
+    near, far = near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])
+    rays = torch.cat([rays_o, rays_d, near, far], -1)
+    if use_viewdirs:
+        rays = torch.cat([rays, viewdirs], -1)
+
+    all_ret = batchify_rays(rays, chunk, **kwargs)
+    for k in all_ret:
+        k_sh = list(sh[:-1]) + list(all_ret[k].shape[1:])
+        all_ret[k] = torch.reshape(all_ret[k], k_sh)
+    k_extract = ['rgb_map', 'disp_map', 'acc_map']
+    ret_list = [all_ret[k] for k in k_extract]
+    ret_dict = {k: all_ret[k] for k in all_ret if k not in k_extract}
+    return ret_list + [ret_dict]
+
+
+def render_path(render_poses, hwf, chunk, render_kwargs, mode, gt_imgs=None, args=None, savedir=None,
+                camera_model=None, noisy_extrinsic=None, gt_intrinsic=None, gt_extrinsic=None, i_map=None,
+                transform_align=None):
+    """Full-image rendering loop of the reference (:143-183); PNGs are written only when imageio is
+    importable."""
+    H, W, noisy_focal = hwf
+    rgbs, disps = [], []
+    try:
+        import tqdm
+        it = tqdm.tqdm(render_poses)
+    except Exception:
+        it = render_poses
+    for i, extrinsic in enumerate(it):
+        image_idx = i_map[i] if not i_map is None else i
+        with torch.no_grad():
+            rgb, disp, acc, _ = render(
+                H=H, W=W, noisy_focal=noisy_focal, chunk=chunk, noisy_extrinsic=noisy_extrinsic,
+                gt_intrinsic=gt_intrinsic, gt_extrinsic=gt_extrinsic, mode=mode, camera_model=camera_model,
+                image_idx=image_idx, i_map=i_map,
+                transform_align=transform_align[i] if transform_align is not None else None, **render_kwargs)
+        rgbs.append(rgb.reshape((H, W, 3)).cpu().numpy())
+        disps.append(disp.reshape((H, W)).cpu().numpy())
+        if savedir is not None:
+            import imageio
+            imageio.imwrite(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs[-1]))
+    return np.stack(rgbs, 0), np.stack(disps, 0)

@@ -55,11 +55,11 @@ def test_mlp_dgrad_matches_autograd(n_rays, spr):
     d_raw = torch.randn(P, 4, generator=g)
     raw = np.zeros((P, 4), np.float32)
     save = np.full(ML.save_floats(P), np.nan, np.float32)
-    H.call("scnerf_mlp_fwd", pts.numpy(), vd.numpy(), spr, wpk, raw, save, P, None)
+    H.call("scnerf_mlp_fwd", pts.numpy(), vd.numpy(), 3, spr, wpk, raw, save, P, None)
     grads = np.full(ML.GRAD_FLOATS_PER_SAMPLE * P, np.nan, np.float32)
     d_pts = np.full((P, 3), np.nan, np.float32)
     d_views = np.full((P, 3), np.nan, np.float32)
-    H.call("scnerf_mlp_bwd", d_raw.numpy(), pts.numpy(), vd.numpy(), spr, wbk, save, grads, d_pts, d_views, P, None)
+    H.call("scnerf_mlp_bwd", d_raw.numpy(), pts.numpy(), vd.numpy(), 3, spr, wbk, save, grads, d_pts, d_views, P, None)
     ref = oracle_backward(p, pts, vd, spr, d_raw)
     off, _ = ML.section_offsets(ML.GRAD_SECTIONS, P)
 
@@ -77,3 +77,39 @@ def test_mlp_dgrad_matches_autograd(n_rays, spr):
         close(sec("dz%d" % l, 256), ref["dz"][l].numpy(), "dz%d" % l)
     close(d_pts, ref["d_pts"].numpy(), "d_pts")
     close(d_views.reshape(n_rays, spr, 3).sum(1), ref["d_vd"].numpy(), "d_viewdirs")
+
+
+def test_full_network_weight_gradients_match_autograd():
+    """fwd (train) -> dgrad -> scnerf_nerf_wgrad: every parameter gradient of the network."""
+    p = {k: v.clone().requires_grad_(True) for k, v in synth.network_params(seed=4).items()}
+    pd = {k: v.detach() for k, v in p.items()}
+    wpk, wbk = pack_forward(pd), pack_backward(pd)
+    n_rays, spr = 3, 50
+    P = n_rays * spr
+    g = torch.Generator().manual_seed(12)
+    pts = torch.rand(P, 3, generator=g) * 2.4 - 1.2
+    vd = torch.randn(n_rays, 3, generator=g)
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+    d_raw = torch.randn(P, 4, generator=g)
+    raw = np.zeros((P, 4), np.float32)
+    save = np.full(ML.save_floats(P), np.nan, np.float32)
+    H.call("scnerf_mlp_fwd", pts.numpy(), vd.numpy(), 3, spr, wpk, raw, save, P, None)
+    grads = np.full(ML.GRAD_FLOATS_PER_SAMPLE * P, np.nan, np.float32)
+    d_pts = np.zeros((P, 3), np.float32)
+    d_views = np.zeros((P, 3), np.float32)
+    H.call("scnerf_mlp_bwd", d_raw.numpy(), pts.numpy(), vd.numpy(), 3, spr, wbk, save, grads, d_pts, d_views, P, None)
+    chunks = 3
+    ws = np.full(H.lib().scnerf_nerf_wgrad_workspace_floats(chunks), np.nan, np.float32)
+    flat = np.full(ML.N_PARAMS, np.nan, np.float32)
+    assert H.lib().scnerf_nerf_param_count() == ML.N_PARAMS
+    H.call("scnerf_nerf_wgrad", save, grads, d_raw.numpy(), P, chunks, ws, flat, None)
+    out = O.query_network(p, pts.reshape(n_rays, spr, 3), vd).reshape(P, 4)
+    (out * d_raw).sum().backward()
+    assert not np.isnan(flat).any()
+    for name, shape in ML.PARAM_SHAPES:
+        o = ML.PARAM_OFFSETS[name]
+        got = flat[o:o + int(np.prod(shape))].reshape(shape)
+        ref = p[name].grad.numpy()
+        scale = float(np.abs(ref).max()) + 1e-12
+        err = float(np.abs(got - ref).max())
+        assert err <= 3e-5 * scale + 1e-6, "%s: err %g scale %g" % (name, err, scale)

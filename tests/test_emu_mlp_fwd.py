@@ -54,7 +54,7 @@ def test_mlp_forward_matches_oracle(n_rays, spr, save):
     vd = vd / vd.norm(dim=-1, keepdim=True)
     raw = np.full((P, 4), np.nan, np.float32)
     sv = np.full(ML.save_floats(P), np.nan, np.float32) if save else None
-    H.call("scnerf_mlp_fwd", pts.numpy(), vd.numpy(), spr, wpk, raw, sv, P, None)
+    H.call("scnerf_mlp_fwd", pts.numpy(), vd.numpy(), 3, spr, wpk, raw, sv, P, None)
     ref = O.query_network(p, pts.reshape(n_rays, spr, 3), vd).reshape(P, 4)
     np.testing.assert_allclose(raw, ref.numpy(), rtol=2e-5, atol=2e-5)
     if save:
