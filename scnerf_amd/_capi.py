@@ -63,6 +63,9 @@ class ScnerfLibraryError(RuntimeError):
 def load() -> ctypes.CDLL:
     global _lib
     if _lib is None:
+        # torch first: the process must end up with ONE HIP runtime (torch's), so that the streams and
+        # device pointers handed over by PyTorch mean the same thing inside libscnerf_hip.so
+        import torch  # noqa: F401
         if not os.path.isfile(LIB_PATH):
             raise ScnerfLibraryError(
                 "libscnerf_hip.so is not built (%s). Run `python -m scnerf_amd.csrc.build` "
