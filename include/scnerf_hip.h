@@ -61,6 +61,58 @@ int scnerf_fine_sample(const float* rays, int ray_stride, const float* z_c, cons
                        float* z_samples, float* z_std, int64_t* inds, float* cdf, int n, int sc,
                        int sf, void* stream);
 
+/* ------------------------------------------------------------------ camera rays ------ */
+
+/* get_rays_kps_use_camera / get_rays_full_image_use_camera (NeRF/get_rays.py:26-148) fused with the
+ * camera model's parameter algebra (model/camera_model.py:24-46, :166-190; camera_utils.py:78-133,
+ * :191-195).  kps [n,2] float (x, y) or NULL = every pixel of the H x W image in row-major order.
+ * Pose source: explicit `extrinsic` [n_ext,4,4] (n_ext = 1 shared, or n per ray) when non-NULL, else
+ * the learnable cameras, indexed per ray by cam_idx [n] (int64) or by `single_idx` when cam_idx is
+ * NULL.  intr_* [4] = (fx, fy, cx, cy) initial value and residual ("noise"); extr_* [n_cams, 9] =
+ * 6-D rotation + translation; grid_o / grid_d [gh, gw, 3] ray-origin / ray-direction noise grids
+ * (either may be NULL = the model has no such attribute); rays_d is renormalised only when grid_d is
+ * present (get_rays.py:140-146).  Outputs rays_o, rays_d [n,3]. */
+int scnerf_camera_rays_fwd(const float* kps, const long long* cam_idx, int single_idx,
+                           const float* extrinsic, int n_ext, const float* intr_init,
+                           const float* intr_noise, float intr_scale, int multiplicative,
+                           const float* extr_init, const float* extr_noise, float extr_scale,
+                           int n_cams, const float* grid_o, float scale_o, const float* grid_d,
+                           float scale_d, int gh, int gw, int H, int W, float* rays_o, float* rays_d,
+                           int n, void* stream);
+
+/* Gradient of the above w.r.t. the learnable tensors: d_intr_noise [4], d_extr_noise [n_cams,9],
+ * d_grid_o / d_grid_d [gh,gw,3], d_extrinsic [n_ext,4,4] (each may be NULL).  g_o, g_d [n,3] may be
+ * NULL (= zero).  workspace: scnerf_camera_bwd_workspace_floats(n_cams or n_ext) floats. */
+long long scnerf_camera_bwd_workspace_floats(int n_slots);
+int scnerf_camera_rays_bwd(const float* kps, const long long* cam_idx, int single_idx,
+                           const float* extrinsic, int n_ext, const float* intr_init,
+                           const float* intr_noise, float intr_scale, int multiplicative,
+                           const float* extr_init, const float* extr_noise, float extr_scale,
+                           int n_cams, const float* grid_o, float scale_o, const float* grid_d,
+                           float scale_d, int gh, int gw, int H, int W, const float* g_o,
+                           const float* g_d, float* d_intr_noise, float* d_extr_noise, float* d_grid_o,
+                           float* d_grid_d, float* d_extrinsic, float* workspace, int n, void* stream);
+
+/* get_rays_kps_no_camera / get_rays_full_image_no_camera (NeRF/get_rays.py:5-23, :75-90): pinhole
+ * rays at the truncated pixel coordinates kps [n, kps_stride>=2] (or every pixel when NULL) through
+ * the fixed pose c2w [4,4]. */
+int scnerf_pinhole_rays(const float* kps, int kps_stride, const float* c2w, float focal, int H, int W,
+                        float* rays_o, float* rays_d, int n, void* stream);
+
+/* ndc_rays / ndc_rays_camera (NeRF/render.py:357-396); focal_xy = device pointer to (fx, fy). */
+int scnerf_ndc_fwd(int H, int W, const float* focal_xy, float near, const float* rays_o,
+                   const float* rays_d, float* ndc_o, float* ndc_d, int n, void* stream);
+int scnerf_ndc_bwd(int H, int W, const float* focal_xy, float near, const float* rays_o,
+                   const float* rays_d, const float* g_ndc_o, const float* g_ndc_d, float* g_rays_o,
+                   float* g_rays_d, float* g_focal_xy, int n, void* stream);
+
+/* CameraModel.get_ray_o_noise / get_ray_d_noise (model/camera_model.py:24-46): bilinear
+ * (align_corners=False) upsampling of a [gh,gw,3] grid to [H*W,3], times scale; and its gradient. */
+int scnerf_upsample_grid_fwd(const float* grid, float scale, int gh, int gw, int H, int W, float* out,
+                             void* stream);
+int scnerf_upsample_grid_bwd(const float* g_out, float scale, int gh, int gw, int H, int W,
+                             float* d_grid, void* stream);
+
 /* ------------------------------------------------------------------ compositing ------ */
 
 /* raw2outputs, NeRF/render.py:302-355.  raw [n, s, 4]; z [n, s]; rays [n, ray_stride] (columns

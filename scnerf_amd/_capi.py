@@ -8,6 +8,8 @@ import ctypes
 import os
 from ctypes import c_int, c_int64, c_longlong, c_void_p, c_float
 
+F = c_float
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscnerf_hip.so")
 
@@ -22,6 +24,13 @@ PROTOTYPES = {
     "scnerf_sample_pdf": [P, P, P, I, P, P, P, I, I, I, P],
     "scnerf_coarse_sample": [P, I, P, P, P, P, I, I, I, P],
     "scnerf_fine_sample": [P, I, P, P, P, I, P, P, P, P, P, P, I, I, I, P],
+    "scnerf_camera_rays_fwd": [P, P, I, P, I, P, P, F, I, P, P, F, I, P, F, P, F, I, I, I, I, P, P, I, P],
+    "scnerf_camera_rays_bwd": [P, P, I, P, I, P, P, F, I, P, P, F, I, P, F, P, F, I, I, I, I, P, P, P, P, P, P, P, P, I, P],
+    "scnerf_pinhole_rays": [P, I, P, F, I, I, P, P, I, P],
+    "scnerf_ndc_fwd": [I, I, P, F, P, P, P, P, I, P],
+    "scnerf_ndc_bwd": [I, I, P, F, P, P, P, P, P, P, P, I, P],
+    "scnerf_upsample_grid_fwd": [P, F, I, I, I, I, P, P],
+    "scnerf_upsample_grid_bwd": [P, F, I, I, I, I, P, P],
     "scnerf_composite_fwd": [P, P, P, I, P, I, P, P, P, P, P, I, I, P],
     "scnerf_composite_bwd": [P, P, P, I, P, I, P, P, P, P, P, P, P, I, I, P],
     "scnerf_ray_reduce": [P, P, P, P, P, I, I, I, I, P],
@@ -38,7 +47,8 @@ PROTOTYPES = {
 # functions returning long long instead of a status
 SIZE_FUNCS = {"scnerf_mlp_save_floats": [LL], "scnerf_mlp_grad_floats": [LL],
               "scnerf_wgrad_workspace_floats": [I, I, I],
-              "scnerf_nerf_wgrad_workspace_floats": [I]}
+              "scnerf_nerf_wgrad_workspace_floats": [I],
+              "scnerf_camera_bwd_workspace_floats": [I]}
 
 
 def bind(lib: ctypes.CDLL) -> ctypes.CDLL:

@@ -1,0 +1,132 @@
+"""autograd nodes over the camera kernels (scnerf_amd/csrc/camera_rays.hip)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+
+Tensor = torch.Tensor
+
+
+def _cf(t):
+    return None if t is None else t.detach().contiguous().float()
+
+
+class CameraRaysFunction(torch.autograd.Function):
+    """apply(meta, kps, cam_idx, extrinsic, intr_noise, extr_noise, grid_o, grid_d) -> rays_o, rays_d.
+    Differentiable in the four learnable camera tensors and in an explicit `extrinsic` matrix."""
+
+    @staticmethod
+    def forward(ctx, meta, kps, cam_idx, extrinsic, intr_noise, extr_noise, grid_o, grid_d):
+        cam = dict(meta)
+        cam.update(kps=_cf(kps), cam_idx=None if cam_idx is None else cam_idx.detach().contiguous().long(),
+                   extrinsic=_cf(extrinsic), intr_noise=_cf(intr_noise), extr_noise=_cf(extr_noise),
+                   grid_o=_cf(grid_o), grid_d=_cf(grid_d))
+        n = cam["n"]
+        ro, rd = ops.camera_rays_fwd(cam, n)
+        ctx.cam = cam
+        return ro, rd
+
+    @staticmethod
+    def backward(ctx, g_o, g_d):
+        cam = ctx.cam
+        d_in, d_ex, d_go, d_gd, d_E = ops.camera_rays_bwd(cam, cam["n"], _cf(g_o), _cf(g_d))
+        if d_E is not None:
+            d_E = d_E[0] if cam["extrinsic"].dim() == 2 else d_E
+        need = ctx.needs_input_grad
+        return (None, None, None, d_E if need[3] else None, d_in if need[4] else None,
+                d_ex if (need[5] and d_ex is not None) else None, d_go if need[6] else None,
+                d_gd if need[7] else None)
+
+
+def camera_rays(H, W, camera_model, kps_list, idx_in_camera_param=None, extrinsic=None):
+    """Shared implementation of get_rays_kps_use_camera / get_rays_full_image_use_camera."""
+    dev = camera_model.intrinsics_initial.device
+    if not camera_model.intrinsics_initial.is_cuda:
+        raise RuntimeError("the camera model must be on the GPU (scnerf_amd has no CPU path)")
+    n = H * W if kps_list is None else int(kps_list.shape[0])
+    kps = None
+    if kps_list is not None:
+        kps = kps_list[:, :2].to(device=dev, dtype=torch.float32).contiguous()
+    cam_idx, single = None, 0
+    ext = None
+    if extrinsic is not None:
+        ext = extrinsic.to(dev).float()
+        if ext.dim() == 3 and ext.shape[0] != n:
+            raise ValueError("per-ray extrinsics must be [N,4,4]")
+        if ext.shape[-2:] != (4, 4):
+            full = torch.zeros(ext.shape[:-2] + (4, 4), device=dev)
+            full[..., :ext.shape[-2], :ext.shape[-1]] = ext
+            ext = full
+    else:
+        idx = idx_in_camera_param
+        if torch.is_tensor(idx) and idx.dim() >= 1:
+            cam_idx = idx.to(dev).reshape(-1).long()
+            if cam_idx.numel() != n:
+                raise ValueError("one camera index per key point expected")
+        elif isinstance(idx, (list, tuple)) or (hasattr(idx, "__len__") and not torch.is_tensor(idx)):
+            cam_idx = torch.as_tensor(idx, device=dev).reshape(-1).long()
+        else:
+            single = int(idx)
+    has_o, has_d = hasattr(camera_model, "ray_o_noise"), hasattr(camera_model, "ray_d_noise")
+    meta = dict(single_idx=single, intr_init=camera_model.intrinsics_initial.detach().contiguous().float(),
+                intr_scale=float(camera_model.intrinsics_noise_scale),
+                multiplicative=bool(getattr(camera_model, "multiplicative_noise", False)),
+                extr_init=camera_model.extrinsics_initial.detach().contiguous().float(),
+                extr_scale=float(camera_model.extrinsics_noise_scale),
+                scale_o=float(camera_model.ray_o_noise_scale), scale_d=float(camera_model.ray_d_noise_scale),
+                H=int(H), W=int(W), n=n)
+    return CameraRaysFunction.apply(meta, kps, cam_idx, ext, camera_model.intrinsics_noise,
+                                    camera_model.extrinsics_noise,
+                                    camera_model.ray_o_noise if has_o else None,
+                                    camera_model.ray_d_noise if has_d else None)
+
+
+def pinhole_rays(H, W, focal, extrinsic, kps_list):
+    """get_rays_{kps,full_image}_no_camera: fixed pose, no gradients (reference get_rays.py:5-23, :75-90)."""
+    if not extrinsic.is_cuda:
+        raise RuntimeError("extrinsic must be on the GPU")
+    c2w = torch.zeros((4, 4), device=extrinsic.device)
+    c2w[:extrinsic.shape[0], :extrinsic.shape[1]] = extrinsic.detach().float()
+    kps = None if kps_list is None else kps_list.to(device=extrinsic.device, dtype=torch.float32).contiguous()
+    return ops.pinhole_rays(kps, c2w, float(focal), int(H), int(W))
+
+
+class NdcFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, H, W, f2, near, rays_o, rays_d):
+        o, d = _cf(rays_o).reshape(-1, 3), _cf(rays_d).reshape(-1, 3)
+        f2c = _cf(f2)
+        no, nd = ops.ndc_fwd(H, W, f2c, near, o, d)
+        ctx.state = (H, W, f2c, near, o, d, rays_o.shape)
+        return no.view(rays_o.shape), nd.view(rays_d.shape)
+
+    @staticmethod
+    def backward(ctx, g_no, g_nd):
+        H, W, f2, near, o, d, shape = ctx.state
+        g_o, g_d, g_f = ops.ndc_bwd(H, W, f2, near, o, d, _cf(g_no).reshape(-1, 3) if g_no is not None else None,
+                                    _cf(g_nd).reshape(-1, 3) if g_nd is not None else None)
+        return None, None, g_f if ctx.needs_input_grad[2] else None, None, g_o.view(shape), g_d.view(shape)
+
+
+def ndc(H, W, fx, fy, near, rays_o, rays_d):
+    dev = rays_o.device
+    fx = fx if torch.is_tensor(fx) else torch.tensor(float(fx), device=dev)
+    fy = fy if torch.is_tensor(fy) else torch.tensor(float(fy), device=dev)
+    f2 = torch.stack([fx.to(dev).float().reshape(()), fy.to(dev).float().reshape(())])
+    return NdcFunction.apply(int(H), int(W), f2, float(near), rays_o, rays_d)
+
+
+class UpsampleGridFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, grid, scale, H, W):
+        g = _cf(grid)
+        ctx.state = (float(scale), g.shape[0], g.shape[1], H, W)
+        return ops.upsample_grid_fwd(g, scale, H, W)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        scale, gh, gw, H, W = ctx.state
+        return ops.upsample_grid_bwd(_cf(g_out), scale, gh, gw, H, W), None, None, None

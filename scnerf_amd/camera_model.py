@@ -1,0 +1,121 @@
+"""Mirror of the reference's learnable camera models (/root/reference model/camera_model.py):
+same class names, constructor arguments, parameter names / shapes / requires_grad flags and public
+methods, so `run_nerf.py` (hasattr probes, requires_grad_ curriculum toggles, checkpoints) works
+unchanged.  Ray generation itself does not go through these methods: `get_rays_*` hands the raw
+parameter tensors to the fused HIP kernel."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .camera_functional import UpsampleGridFunction
+from .camera_utils import (get_44_rotation_matrix_from_33_rotation_matrix, intrinsic_param_to_K,
+                           ortho2rotation, rotation2orth)
+
+
+class CameraModel(nn.Module):
+    """Base class (reference :12-52)."""
+
+    def __init__(self, intrinsics, extrinsics, args, H, W):
+        nn.Module.__init__(self)
+        self.args = args
+        self.H, self.W = H, W
+        self.model_name = args.camera_model
+        self.ray_o_noise_scale = args.ray_o_noise_scale
+        self.ray_d_noise_scale = args.ray_d_noise_scale
+        self.extrinsics_noise_scale = args.extrinsics_noise_scale
+        self.intrinsics_noise_scale = args.intrinsics_noise_scale
+
+    def get_ray_d_noise(self):
+        """[H*W, 3]: the direction-noise grid upsampled bilinearly to the image, times its scale (:24-34)."""
+        return UpsampleGridFunction.apply(self.ray_d_noise, self.ray_d_noise_scale, self.H, self.W)
+
+    def get_ray_o_noise(self):
+        return UpsampleGridFunction.apply(self.ray_o_noise, self.ray_o_noise_scale, self.H, self.W)
+
+    def get_extrinsic(self):
+        raise Exception("function get_intrinsic not implemented!")
+
+    def get_intrinsic(self):
+        raise Exception("function get_extrinsic not implemented!")
+
+    def log_noises(self, gt_intrinsic, gt_extrinsic):
+        """Scalar summaries of the learnt residuals (reference :54-117 sends them to wandb; here they
+        are returned so any logger can take them)."""
+        out = {"camera/intrinsic_noise_mean": self.get_intrinsic().abs().mean().item()}
+        for name in ("intrinsics_noise", "extrinsics_noise", "ray_o_noise", "ray_d_noise", "distortion_noise"):
+            if hasattr(self, name):
+                t = getattr(self, name)
+                out["camera/%s_abs_mean" % name] = t.abs().mean().item()
+                out["camera/%s_std" % name] = t.std().item()
+        return out
+
+
+class _PinholeRotNoise(CameraModel):
+    def get_intrinsic(self):
+        if self.multiplicative_noise:
+            p = self.intrinsics_initial + self.intrinsics_noise * self.intrinsics_noise_scale * self.intrinsics_initial
+        else:
+            p = self.intrinsics_initial + self.intrinsics_noise * self.intrinsics_noise_scale
+        return intrinsic_param_to_K(p)
+
+    def get_extrinsic(self):
+        e = get_44_rotation_matrix_from_33_rotation_matrix(ortho2rotation(
+            self.extrinsics_initial[:, :6] + self.extrinsics_noise_scale * self.extrinsics_noise[:, :6]))
+        e[..., :3, 3] = self.extrinsics_initial[:, 6:] + self.extrinsics_noise_scale * self.extrinsics_noise[:, 6:]
+        return e
+
+    def forward(self, idx):
+        e = get_44_rotation_matrix_from_33_rotation_matrix(ortho2rotation(
+            self.extrinsics_initial[idx, None, :6] + self.extrinsics_noise_scale * self.extrinsics_noise[idx, None, :6]))
+        e[..., :3, 3] = self.extrinsics_initial[idx, 6:] + self.extrinsics_noise_scale * self.extrinsics_noise[idx, 6:]
+        return self.get_intrinsic(), e.squeeze()
+
+    def _register_common(self, intrinsics, extrinsics):
+        fx, fy, tx, ty = intrinsics[0][0], intrinsics[1][1], intrinsics[0][2], intrinsics[1][2]
+        extrinsics = torch.from_numpy(np.stack([np.asarray(e.cpu() if torch.is_tensor(e) else e) for e in extrinsics])).float()
+        params = rotation2orth(extrinsics[:, :3, :3])
+        translations = extrinsics[:, :3, 3]
+        self.register_parameter("intrinsics_initial", nn.Parameter(
+            torch.Tensor([float(fx), float(fy), float(tx), float(ty)]), requires_grad=False))
+        self.register_parameter("extrinsics_initial", nn.Parameter(
+            torch.cat([params, translations], dim=-1), requires_grad=False))
+
+
+class PinholeModelRotNoiseLearning10kRayoRayd(_PinholeRotNoise):
+    """Reference :120-206."""
+
+    def __init__(self, intrinsics, extrinsics, args, H, W):
+        super().__init__(intrinsics, extrinsics, args, H, W)
+        self._register_common(intrinsics, extrinsics)
+        ray_o_noise = torch.zeros((H // args.grid_size, W // args.grid_size, 3))
+        ray_d_noise = torch.zeros((H // args.grid_size, W // args.grid_size, 3))
+        self.register_parameter("intrinsics_noise", nn.Parameter(torch.zeros(4)))
+        self.register_parameter("extrinsics_noise", nn.Parameter(torch.zeros_like(self.extrinsics_initial)))
+        self.register_parameter("ray_o_noise", nn.Parameter(ray_o_noise))
+        self.register_parameter("ray_d_noise", nn.Parameter(ray_d_noise))
+        self.multiplicative_noise = args.multiplicative_noise
+
+
+class PinholeModelRotNoiseLearning10kRayoRaydDistortion(_PinholeRotNoise):
+    """Reference :209-312.  As there, ray_o_noise and ray_d_noise wrap ONE tensor (:224, :257-262):
+    two Parameters (two autograd leaves) over the same storage until .to()/.cuda() copies them."""
+
+    def __init__(self, intrinsics, extrinsics, args, H, W, k=None):
+        super().__init__(intrinsics, extrinsics, args, H, W)
+        self._register_common(intrinsics, extrinsics)
+        ray_noise = torch.zeros((H // args.grid_size, W // args.grid_size, 3))
+        if k is not None:
+            self.register_parameter("distortion_initial", nn.Parameter(torch.tensor([k[0], k[1]]), requires_grad=False))
+        else:
+            self.register_parameter("distortion_initial", nn.Parameter(torch.zeros(2), requires_grad=False))
+        self.register_parameter("intrinsics_noise", nn.Parameter(torch.zeros(4)))
+        self.register_parameter("extrinsics_noise", nn.Parameter(torch.zeros_like(self.extrinsics_initial)))
+        self.register_parameter("ray_o_noise", nn.Parameter(ray_noise))
+        self.register_parameter("ray_d_noise", nn.Parameter(ray_noise))
+        self.register_parameter("distortion_noise", nn.Parameter(torch.zeros(2)))
+        self.multiplicative_noise = args.multiplicative_noise if hasattr(args, "multiplicative_noise") else False
+
+    def get_distortion(self):
+        return self.distortion_initial + self.distortion_noise * self.args.distortion_noise_scale

@@ -293,3 +293,97 @@ def ray_reduce(d_pts, d_views, z, extra_d, d_rays, accumulate: bool):
                                         d_rays.shape[1], int(bool(accumulate)), n, s, _stream())
     _capi.check(st, "scnerf_ray_reduce")
     return d_rays
+
+
+# ------------------------------------------------------------------------------ camera
+def _cam_common(cam: dict):
+    """(ctypes argument tuple shared by camera fwd / bwd) from a dict of tensors / scalars."""
+    import ctypes
+    F = ctypes.c_float
+    g_o, g_d = cam.get("grid_o"), cam.get("grid_d")
+    grid = g_o if g_o is not None else g_d
+    gh, gw = (int(grid.shape[0]), int(grid.shape[1])) if grid is not None else (0, 0)
+    ext = cam.get("extrinsic")
+    n_ext = 0 if ext is None else (1 if ext.dim() == 2 else int(ext.shape[0]))
+    idx = cam.get("cam_idx")
+    return (_p(cam.get("kps")), _p(idx), int(cam.get("single_idx", 0)), _p(ext), n_ext,
+            _p(cam["intr_init"]), _p(cam["intr_noise"]), F(float(cam["intr_scale"])), int(bool(cam["multiplicative"])),
+            _p(cam["extr_init"]), _p(cam["extr_noise"]), F(float(cam["extr_scale"])), int(cam["extr_init"].shape[0]),
+            _p(g_o), F(float(cam.get("scale_o", 0.0))), _p(g_d), F(float(cam.get("scale_d", 0.0))), gh, gw,
+            int(cam["H"]), int(cam["W"]))
+
+
+def camera_rays_fwd(cam: dict, n: int):
+    dev = cam["intr_init"].device
+    ro = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    rd = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    st = _capi.load().scnerf_camera_rays_fwd(*_cam_common(cam), _p(ro), _p(rd), n, _stream())
+    _capi.check(st, "scnerf_camera_rays_fwd")
+    return ro, rd
+
+
+def camera_rays_bwd(cam: dict, n: int, g_o: Optional[Tensor], g_d: Optional[Tensor]):
+    lib = _capi.load()
+    dev = cam["intr_init"].device
+    C = int(cam["extr_init"].shape[0])
+    ext = cam.get("extrinsic")
+    n_ext = 0 if ext is None else (1 if ext.dim() == 2 else int(ext.shape[0]))
+    d_in = torch.empty(4, dtype=torch.float32, device=dev)
+    d_ex = torch.empty((C, 9), dtype=torch.float32, device=dev) if ext is None else None
+    d_go = torch.empty_like(cam["grid_o"]) if cam.get("grid_o") is not None else None
+    d_gd = torch.empty_like(cam["grid_d"]) if cam.get("grid_d") is not None else None
+    d_E = torch.empty((n_ext, 4, 4), dtype=torch.float32, device=dev) if n_ext else None
+    ws = torch.empty(lib.scnerf_camera_bwd_workspace_floats(max(C, n_ext)), dtype=torch.float32, device=dev)
+    st = lib.scnerf_camera_rays_bwd(*_cam_common(cam), _p(g_o), _p(g_d), _p(d_in), _p(d_ex), _p(d_go), _p(d_gd),
+                                    _p(d_E), _p(ws), n, _stream())
+    _capi.check(st, "scnerf_camera_rays_bwd")
+    return d_in, d_ex, d_go, d_gd, d_E
+
+
+def pinhole_rays(kps: Optional[Tensor], c2w: Tensor, focal: float, H: int, W: int):
+    import ctypes
+    _f(c2w, "c2w")
+    n = H * W if kps is None else kps.shape[0]
+    ro = torch.empty((n, 3), dtype=torch.float32, device=c2w.device)
+    rd = torch.empty((n, 3), dtype=torch.float32, device=c2w.device)
+    st = _capi.load().scnerf_pinhole_rays(_p(kps), 0 if kps is None else int(kps.shape[1]), _p(c2w),
+                                          ctypes.c_float(float(focal)), H, W, _p(ro), _p(rd), n, _stream())
+    _capi.check(st, "scnerf_pinhole_rays")
+    return ro, rd
+
+
+def ndc_fwd(H, W, f2: Tensor, near: float, o: Tensor, d: Tensor):
+    import ctypes
+    no, nd = torch.empty_like(o), torch.empty_like(d)
+    st = _capi.load().scnerf_ndc_fwd(H, W, _p(f2), ctypes.c_float(float(near)), _p(o), _p(d), _p(no), _p(nd),
+                                     o.shape[0], _stream())
+    _capi.check(st, "scnerf_ndc_fwd")
+    return no, nd
+
+
+def ndc_bwd(H, W, f2, near, o, d, g_no, g_nd):
+    import ctypes
+    g_o, g_d = torch.empty_like(o), torch.empty_like(d)
+    g_f = torch.empty(2, dtype=torch.float32, device=o.device)
+    st = _capi.load().scnerf_ndc_bwd(H, W, _p(f2), ctypes.c_float(float(near)), _p(o), _p(d), _p(g_no), _p(g_nd),
+                                     _p(g_o), _p(g_d), _p(g_f), o.shape[0], _stream())
+    _capi.check(st, "scnerf_ndc_bwd")
+    return g_o, g_d, g_f
+
+
+def upsample_grid_fwd(grid: Tensor, scale: float, H: int, W: int):
+    import ctypes
+    _f(grid, "grid")
+    out = torch.empty((H * W, 3), dtype=torch.float32, device=grid.device)
+    st = _capi.load().scnerf_upsample_grid_fwd(_p(grid), ctypes.c_float(float(scale)), grid.shape[0], grid.shape[1],
+                                               H, W, _p(out), _stream())
+    _capi.check(st, "scnerf_upsample_grid_fwd")
+    return out
+
+
+def upsample_grid_bwd(g_out: Tensor, scale: float, gh: int, gw: int, H: int, W: int):
+    import ctypes
+    d = torch.empty((gh, gw, 3), dtype=torch.float32, device=g_out.device)
+    st = _capi.load().scnerf_upsample_grid_bwd(_p(g_out), ctypes.c_float(float(scale)), gh, gw, H, W, _p(d), _stream())
+    _capi.check(st, "scnerf_upsample_grid_bwd")
+    return d

@@ -1,0 +1,180 @@
+"""Camera ray generator kernels (HIP source under the CPU SIMT interpreter) vs golden vectors of
+the reference's get_rays_* / CameraModel / ndc_rays* (values and autograd gradients)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from scnerf_amd import synthetic as synth
+from scnerf_amd.camera_utils import rotation2orth
+from tests.emu import harness as H
+
+pytestmark = pytest.mark.emu
+HH, WW = 378, 504
+
+
+def cam_arrays(spec, aliased):
+    poses = spec["poses"]
+    K = spec["K_init"]
+    a = dict(
+        intr_init=np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]], np.float32),
+        intr_noise=spec["intrinsics_noise"].numpy().astype(np.float32),
+        extr_init=torch.cat([rotation2orth(poses[:, :3, :3]), poses[:, :3, 3]], -1).numpy().astype(np.float32).copy(),
+        extr_noise=spec["extrinsics_noise"].numpy().astype(np.float32),
+        grid_o=spec["ray_o_noise"].numpy().astype(np.float32),
+        grid_d=(spec["ray_o_noise"] if aliased else spec["ray_d_noise"]).numpy().astype(np.float32))
+    return a
+
+
+def close(a, b, tol, what):
+    scale = float(np.abs(b).max()) + 1e-30
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale, "%s: err %g scale %g" % (what, err, scale)
+
+
+def fwd(a, spec, kps, idx, ext, n, single=0):
+    ro = np.zeros((n, 3), np.float32); rd = np.zeros((n, 3), np.float32)
+    gh, gw = a["grid_o"].shape[:2]
+    H.call("scnerf_camera_rays_fwd", kps, idx, single, ext, 0 if ext is None else ext.shape[0] // 1 if ext.ndim == 3 else 1,
+           a["intr_init"], a["intr_noise"], ctypes.c_float(spec["intrinsics_noise_scale"]), int(spec["multiplicative_noise"]),
+           a["extr_init"], a["extr_noise"], ctypes.c_float(spec["extrinsics_noise_scale"]), a["extr_init"].shape[0],
+           a["grid_o"], ctypes.c_float(spec["ray_o_noise_scale"]), a["grid_d"], ctypes.c_float(spec["ray_d_noise_scale"]),
+           gh, gw, HH, WW, ro, rd, n, None)
+    return ro, rd
+
+
+def bwd(a, spec, kps, idx, ext, n, g_o, g_d, single=0):
+    gh, gw = a["grid_o"].shape[:2]
+    C = a["extr_init"].shape[0]
+    n_ext = 0 if ext is None else (ext.shape[0] if ext.ndim == 3 else 1)
+    out = dict(di=np.full(4, np.nan, np.float32), de=np.full((C, 9), np.nan, np.float32),
+               dgo=np.full((gh, gw, 3), np.nan, np.float32), dgd=np.full((gh, gw, 3), np.nan, np.float32),
+               dE=np.full((max(n_ext, 1), 4, 4), np.nan, np.float32))
+    ws = np.zeros(H.lib().scnerf_camera_bwd_workspace_floats(max(C, n_ext)), np.float32)
+    H.call("scnerf_camera_rays_bwd", kps, idx, single, ext, n_ext,
+           a["intr_init"], a["intr_noise"], ctypes.c_float(spec["intrinsics_noise_scale"]), int(spec["multiplicative_noise"]),
+           a["extr_init"], a["extr_noise"], ctypes.c_float(spec["extrinsics_noise_scale"]), C,
+           a["grid_o"], ctypes.c_float(spec["ray_o_noise_scale"]), a["grid_d"], ctypes.c_float(spec["ray_d_noise_scale"]),
+           gh, gw, HH, WW, g_o, g_d, out["di"], out["de"], out["dgo"], out["dgd"], out["dE"] if n_ext else None, ws, n, None)
+    return out
+
+
+@pytest.mark.parametrize("tag,mult,aliased", [("plain_add", False, False), ("plain_mul", True, False),
+                                              ("dist_mul", True, True)])
+def test_camera_rays_per_ray_cameras(golden, tag, mult, aliased):
+    g = golden("camera")
+    k = tag + "/"
+    spec = synth.camera_spec(HH, WW, n_cams=5, seed=4, multiplicative=mult)
+    a = cam_arrays(spec, aliased)
+    kps, idx = g[k + "kps"], g[k + "idx"].astype(np.int64)
+    n = kps.shape[0]
+    ro, rd = fwd(a, spec, kps, idx, None, n)
+    np.testing.assert_allclose(ro, g[k + "rays_o"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rd, g[k + "rays_d"], rtol=1e-5, atol=1e-6)
+    o = bwd(a, spec, kps, idx, None, n, g[k + "g_o"], g[k + "g_d"])
+    close(o["di"], g[k + "g_intrinsics_noise"], 1e-3, "d intrinsics_noise")
+    close(o["de"], g[k + "g_extrinsics_noise"], 1e-3, "d extrinsics_noise")
+    close(o["dgo"], g[k + "g_ray_o_noise"], 1e-4, "d ray_o_noise")
+    close(o["dgd"], g[k + "g_ray_d_noise"], 1e-3, "d ray_d_noise")
+
+
+def test_camera_rays_shared_extrinsic_and_ndc(golden):
+    g = golden("camera")
+    k = "plain_mul/"
+    spec = synth.camera_spec(HH, WW, n_cams=5, seed=4, multiplicative=True)
+    a = cam_arrays(spec, False)
+    kps = g[k + "kps"]
+    n = kps.shape[0]
+    E = np.ascontiguousarray(g[k + "E"][2])                  # the camera model's own pose 2, as a plain matrix
+    ro, rd = fwd(a, spec, kps, None, E, n)
+    np.testing.assert_allclose(ro, g[k + "shared/rays_o"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rd, g[k + "shared/rays_d"], rtol=1e-5, atol=1e-6)
+    # the same through the learnable pose of camera 2 (single index)
+    ro2, rd2 = fwd(a, spec, kps, None, None, n, single=2)
+    np.testing.assert_allclose(ro2, ro, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rd2, rd, rtol=1e-5, atol=1e-6)
+    # NDC through the model's focal lengths + chained gradients
+    K = g[k + "K"]
+    f2 = np.array([K[0, 0], K[1, 1]], np.float32)
+    no = np.zeros((n, 3), np.float32); nd = np.zeros((n, 3), np.float32)
+    H.call("scnerf_ndc_fwd", HH, WW, f2, ctypes.c_float(1.0), ro2, rd2, no, nd, n, None)
+    np.testing.assert_allclose(no, g[k + "shared/ndc_o"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(nd, g[k + "shared/ndc_d"], rtol=2e-5, atol=2e-6)
+    g_ro = np.zeros((n, 3), np.float32); g_rd = np.zeros((n, 3), np.float32); g_f = np.zeros(2, np.float32)
+    H.call("scnerf_ndc_bwd", HH, WW, f2, ctypes.c_float(1.0), ro2, rd2, g[k + "g_o"], g[k + "g_d"], g_ro, g_rd, g_f, n, None)
+    o = bwd(a, spec, kps, None, None, n, g_ro, g_rd, single=2)
+    # intrinsics get gradient through the rays AND through fx, fy of the warp (multiplicative residual)
+    scale = spec["intrinsics_noise_scale"] * a["intr_init"]
+    di = o["di"].copy()
+    di[0] += g_f[0] * scale[0]
+    di[1] += g_f[1] * scale[1]
+    close(di, g[k + "shared/g_intrinsics_noise"], 2e-3, "d intrinsics_noise (rays + ndc)")
+    close(o["dgo"], g[k + "shared/g_ray_o_noise"], 1e-3, "d ray_o_noise")
+    # in the reference this branch received a detached pose tensor?  no: E came from get_extrinsic() -> gradient flows
+    ref_de = g[k + "shared/g_extrinsics_noise"]
+    close(o["de"], ref_de, 2e-3, "d extrinsics_noise")
+
+
+def test_explicit_extrinsic_gradient_is_consistent(golden):
+    """d/dE from the explicit-matrix branch == the accumulators the learnable branch feeds into
+    Gram-Schmidt (finite-difference spot check on one entry)."""
+    g = golden("camera")
+    k = "plain_add/"
+    spec = synth.camera_spec(HH, WW, n_cams=5, seed=4, multiplicative=False)
+    a = cam_arrays(spec, False)
+    kps = g[k + "kps"]
+    n = kps.shape[0]
+    E = np.ascontiguousarray(g[k + "E"][1]).astype(np.float32)
+    go, gd = g[k + "g_o"], g[k + "g_d"]
+    o = bwd(a, spec, kps, None, E, n, go, gd)
+
+    def loss(Em):
+        ro, rd = fwd(a, spec, kps, None, np.ascontiguousarray(Em.astype(np.float32)), n)
+        return float((ro.astype(np.float64) * go).sum() + (rd.astype(np.float64) * gd).sum())
+    for (r, c) in ((0, 1), (2, 3), (1, 2)):
+        Ep, Em = E.astype(np.float64).copy(), E.astype(np.float64).copy()
+        Ep[r, c] += 1e-2
+        Em[r, c] -= 1e-2
+        fd = (loss(Ep) - loss(Em)) / 2e-2
+        assert abs(fd - o["dE"][0, r, c]) <= 2e-2 * max(1.0, abs(fd)), (r, c, fd, o["dE"][0, r, c])
+
+
+def test_pinhole_and_full_image(golden):
+    g = golden("camera")
+    kps = g["pinhole/kps"]
+    n = kps.shape[0]
+    ro = np.zeros((n, 3), np.float32); rd = np.zeros((n, 3), np.float32)
+    H.call("scnerf_pinhole_rays", kps, 2, g["pinhole/c2w"], ctypes.c_float(400.0), HH, WW, ro, rd, n, None)
+    np.testing.assert_allclose(ro, g["pinhole/rays_o"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(rd, g["pinhole/rays_d"], rtol=1e-6, atol=1e-7)
+    f2 = np.array([400.0, 400.0], np.float32)
+    no = np.zeros((n, 3), np.float32); nd = np.zeros((n, 3), np.float32)
+    H.call("scnerf_ndc_fwd", HH, WW, f2, ctypes.c_float(1.0), ro, rd, no, nd, n, None)
+    np.testing.assert_allclose(no, g["pinhole/ndc_o"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(nd, g["pinhole/ndc_d"], rtol=2e-5, atol=2e-6)
+    # full image (kps = NULL) == key points enumerating every pixel
+    h, w = 6, 9
+    ro_f = np.zeros((h * w, 3), np.float32); rd_f = np.zeros((h * w, 3), np.float32)
+    H.call("scnerf_pinhole_rays", None, 0, g["pinhole/c2w"], ctypes.c_float(11.0), h, w, ro_f, rd_f, h * w, None)
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    kk = np.stack([xx.reshape(-1), yy.reshape(-1)], -1).astype(np.float32)
+    ro_k = np.zeros_like(ro_f); rd_k = np.zeros_like(rd_f)
+    H.call("scnerf_pinhole_rays", kk, 2, g["pinhole/c2w"], ctypes.c_float(11.0), h, w, ro_k, rd_k, h * w, None)
+    np.testing.assert_array_equal(rd_f, rd_k)
+
+
+def test_upsample_grid_matches_interpolate():
+    g = torch.Generator().manual_seed(3)
+    grid = torch.randn(37, 50, 3, generator=g)
+    out = np.zeros((HH * WW, 3), np.float32)
+    H.call("scnerf_upsample_grid_fwd", grid.numpy(), ctypes.c_float(1e-3), 37, 50, HH, WW, out, None)
+    gt = grid.clone().requires_grad_(True)
+    ref = torch.nn.functional.interpolate(gt.permute(2, 0, 1)[None], (HH, WW), mode="bilinear",
+                                          align_corners=False).permute(0, 2, 3, 1).reshape(-1, 3) * 1e-3
+    np.testing.assert_allclose(out, ref.detach().numpy(), rtol=1e-5, atol=1e-9)
+    go = torch.randn(HH * WW, 3, generator=g)
+    (ref * go).sum().backward()
+    dg = np.zeros((37, 50, 3), np.float32)
+    H.call("scnerf_upsample_grid_bwd", go.numpy(), ctypes.c_float(1e-3), 37, 50, HH, WW, dg, None)
+    np.testing.assert_allclose(dg, gt.grad.numpy(), rtol=2e-4, atol=1e-6)

@@ -1,0 +1,182 @@
+"""GPU parity of the camera path (pytest -m gpu): scnerf_amd.{get_rays, camera_model, render.render}
+through the C ABI vs the reference's golden vectors and the CPU oracle (BASELINE config 3)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import scnerf_oracle as O
+from scnerf_amd import synthetic as synth
+from conftest import t
+
+pytestmark = pytest.mark.gpu
+HH, WW = 378, 504
+
+
+@pytest.fixture(scope="module")
+def M():
+    assert torch.cuda.is_available()
+    from scnerf_amd import camera_model, get_rays, render, create_nerf, run_nerf_helpers, camera_dict
+    return types.SimpleNamespace(cm=camera_model, gr=get_rays, render=render, cn=create_nerf,
+                                 h=run_nerf_helpers, cd=camera_dict)
+
+
+def make_camera(M, cls_key, mult, n_cams=5, seed=4):
+    spec = synth.camera_spec(HH, WW, n_cams=n_cams, seed=seed, multiplicative=mult)
+    args = types.SimpleNamespace(camera_model=cls_key, grid_size=10, ray_o_noise_scale=spec["ray_o_noise_scale"],
+                                 ray_d_noise_scale=spec["ray_d_noise_scale"],
+                                 extrinsics_noise_scale=spec["extrinsics_noise_scale"],
+                                 intrinsics_noise_scale=spec["intrinsics_noise_scale"], multiplicative_noise=mult,
+                                 distortion_noise_scale=1e-2)
+    cm = M.cd.camera_dict[cls_key](spec["K_init"], list(spec["poses"].numpy()), args, HH, WW)
+    aliased = cm.ray_o_noise.data_ptr() == cm.ray_d_noise.data_ptr()
+    with torch.no_grad():
+        cm.intrinsics_noise.copy_(spec["intrinsics_noise"])
+        cm.extrinsics_noise.copy_(spec["extrinsics_noise"])
+        cm.ray_o_noise.copy_(spec["ray_o_noise"])
+        if not aliased:
+            cm.ray_d_noise.copy_(spec["ray_d_noise"])
+    return cm.cuda(), spec, aliased
+
+
+def close(a, b, tol, what):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
+    scale = float(np.abs(b).max()) + 1e-30
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale, "%s: err %g scale %g" % (what, err, scale)
+
+
+@pytest.mark.parametrize("tag,key,mult", [("plain_add", "pinhole_rot_noise_10k_rayo_rayd", False),
+                                          ("plain_mul", "pinhole_rot_noise_10k_rayo_rayd", True),
+                                          ("dist_mul", "pinhole_rot_noise_10k_rayo_rayd_dist", True)])
+def test_get_rays_kps_use_camera_golden(M, golden, tag, key, mult):
+    g = golden("camera")
+    k = tag + "/"
+    cm, spec, aliased = make_camera(M, key, mult)
+    assert int(g[k + "aliased"]) == int(aliased)          # same construction quirk as the reference
+    assert {n for n, _ in cm.named_parameters()} >= {"intrinsics_initial", "extrinsics_initial", "intrinsics_noise",
+                                                      "extrinsics_noise", "ray_o_noise", "ray_d_noise"}
+    assert not cm.intrinsics_initial.requires_grad and cm.ray_o_noise.requires_grad
+    kps, idx = t(g[k + "kps"]).cuda(), t(g[k + "idx"]).cuda()
+    ro, rd = M.gr.get_rays_kps_use_camera(HH, WW, cm, kps, idx_in_camera_param=idx)
+    np.testing.assert_allclose(ro.detach().cpu().numpy(), g[k + "rays_o"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rd.detach().cpu().numpy(), g[k + "rays_d"], rtol=1e-5, atol=1e-6)
+    ((ro * t(g[k + "g_o"]).cuda()).sum() + (rd * t(g[k + "g_d"]).cuda()).sum()).backward()
+    close(cm.intrinsics_noise.grad, g[k + "g_intrinsics_noise"], 1e-3, "intrinsics_noise")
+    close(cm.extrinsics_noise.grad, g[k + "g_extrinsics_noise"], 1e-3, "extrinsics_noise")
+    close(cm.ray_o_noise.grad, g[k + "g_ray_o_noise"], 1e-4, "ray_o_noise")
+    close(cm.ray_d_noise.grad, g[k + "g_ray_d_noise"], 1e-3, "ray_d_noise")
+    np.testing.assert_allclose(cm.get_intrinsic().detach().cpu().numpy(), g[k + "K"], rtol=1e-6)
+    np.testing.assert_allclose(cm.get_extrinsic().detach().cpu().numpy(), g[k + "E"], rtol=1e-5, atol=1e-6)
+    K1, E1 = cm(1)
+    np.testing.assert_allclose(E1.detach().cpu().numpy(), g[k + "E"][1], rtol=1e-5, atol=1e-6)
+
+
+def test_shared_extrinsic_and_ndc_camera_golden(M, golden):
+    g = golden("camera")
+    k = "plain_mul/"
+    cm, spec, _ = make_camera(M, "pinhole_rot_noise_10k_rayo_rayd", True)
+    kps = t(g[k + "kps"]).cuda()
+    E = cm.get_extrinsic()[2]                              # differentiable pose, like the reference test
+    ro, rd = M.gr.get_rays_kps_use_camera(HH, WW, cm, kps, extrinsic=E)
+    np.testing.assert_allclose(ro.detach().cpu().numpy(), g[k + "shared/rays_o"], rtol=1e-5, atol=1e-6)
+    no, nd = M.render.ndc_rays_camera(HH, WW, cm, 1.0, ro, rd)
+    np.testing.assert_allclose(no.detach().cpu().numpy(), g[k + "shared/ndc_o"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(nd.detach().cpu().numpy(), g[k + "shared/ndc_d"], rtol=2e-5, atol=2e-6)
+    ((no * t(g[k + "g_o"]).cuda()).sum() + (nd * t(g[k + "g_d"]).cuda()).sum()).backward()
+    close(cm.intrinsics_noise.grad, g[k + "shared/g_intrinsics_noise"], 2e-3, "intrinsics_noise")
+    close(cm.extrinsics_noise.grad, g[k + "shared/g_extrinsics_noise"], 2e-3, "extrinsics_noise")
+    close(cm.ray_o_noise.grad, g[k + "shared/g_ray_o_noise"], 1e-3, "ray_o_noise")
+    # single integer index == the same pose
+    ro2, rd2 = M.gr.get_rays_kps_use_camera(HH, WW, cm, kps, idx_in_camera_param=2)
+    np.testing.assert_allclose(ro2.detach().cpu().numpy(), ro.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    with pytest.raises(AssertionError):
+        M.gr.get_rays_kps_use_camera(HH, WW, cm, kps)     # exactly one of idx / extrinsic (reference :107-110)
+
+
+def test_pinhole_ndc_full_image_and_noise_images(M, golden):
+    g = golden("camera")
+    kps3 = torch.cat([t(g["pinhole/kps"]), torch.ones(64, 1)], -1).cuda()
+    c2w = t(g["pinhole/c2w"]).cuda()
+    ro, rd = M.gr.get_rays_kps_no_camera(HH, WW, 400.0, c2w, kps3)
+    np.testing.assert_allclose(ro.cpu().numpy(), g["pinhole/rays_o"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(rd.cpu().numpy(), g["pinhole/rays_d"], rtol=1e-6, atol=1e-7)
+    no, nd = M.render.ndc_rays(HH, WW, 400.0, 1.0, ro, rd)
+    np.testing.assert_allclose(no.cpu().numpy(), g["pinhole/ndc_o"], rtol=2e-5, atol=2e-6)
+    ro_f, rd_f = M.gr.get_rays_full_image_no_camera(HH, WW, 400.0, c2w)
+    assert ro_f.shape == (HH * WW, 3)
+    ro_np, rd_np = M.gr.get_rays_np(HH, WW, 400.0, g["pinhole/c2w"])
+    np.testing.assert_allclose(rd_f.cpu().numpy().reshape(HH, WW, 3), rd_np, rtol=1e-6, atol=1e-6)
+    cm, spec, _ = make_camera(M, "pinhole_rot_noise_10k_rayo_rayd", True)
+    ref = O.upsample_noise_grid(spec["ray_o_noise"], HH, WW, spec["ray_o_noise_scale"])
+    np.testing.assert_allclose(cm.get_ray_o_noise().detach().cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-9)
+    ro_i, rd_i = M.gr.get_rays_full_image_use_camera(HH, WW, cm, idx_in_camera_param=3)
+    cam = _oracle_cam(spec)
+    yy, xx = torch.meshgrid(torch.arange(HH), torch.arange(WW), indexing="ij")
+    kk = torch.stack([xx.reshape(-1), yy.reshape(-1)], -1).float()
+    with torch.no_grad():
+        oo, od = O.camera_rays(cam, HH, WW, kk, torch.full((HH * WW,), 3, dtype=torch.long))
+    np.testing.assert_allclose(ro_i.detach().cpu().numpy(), oo.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rd_i.detach().cpu().numpy(), od.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def _oracle_cam(spec, grad=False):
+    from scnerf_amd.camera_utils import rotation2orth
+    poses = spec["poses"]
+    K = spec["K_init"]
+    mk = (lambda x: x.clone().requires_grad_(True)) if grad else (lambda x: x.clone())
+    return {"intrinsics_initial": torch.stack([K[0, 0], K[1, 1], K[0, 2], K[1, 2]]),
+            "extrinsics_initial": torch.cat([rotation2orth(poses[:, :3, :3]), poses[:, :3, 3]], -1),
+            "intrinsics_noise": mk(spec["intrinsics_noise"]), "extrinsics_noise": mk(spec["extrinsics_noise"]),
+            "ray_o_noise": mk(spec["ray_o_noise"]), "ray_d_noise": mk(spec["ray_d_noise"]),
+            "intrinsics_noise_scale": spec["intrinsics_noise_scale"], "extrinsics_noise_scale": spec["extrinsics_noise_scale"],
+            "ray_o_noise_scale": spec["ray_o_noise_scale"], "ray_d_noise_scale": spec["ray_d_noise_scale"],
+            "multiplicative_noise": spec["multiplicative_noise"]}
+
+
+def test_render_through_camera_model_config3(M):
+    """BASELINE config 3: rays from the learnable camera -> viewdirs -> NDC through the camera's focal
+    lengths -> coarse+fine render, loss.backward() into network AND camera parameters; vs the oracle."""
+    n, sc, sf = 512, 64, 128
+    cm, spec, _ = make_camera(M, "pinhole_rot_noise_10k_rayo_rayd", True, n_cams=17, seed=8)
+    kps, idx = synth.keypoints(HH, WW, n, n_cams=17, seed=9, integer=True)
+    rnd = synth.render_randoms(n, sc, sf, seed=3)
+    target = synth.target_rgb(n, seed=2)
+
+    def net(seed):
+        m = M.h.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+        m.load_state_dict(synth.network_params(seed=seed))
+        return m.cuda()
+    net_c, net_f = net(0), net(1)
+    query = M.cn.FusedNetworkQuery(M.h.get_embedder(10, 0)[0], M.h.get_embedder(4, 0)[0])
+    ro, rd = M.gr.get_rays_kps_use_camera(HH, WW, cm, kps.cuda(), idx_in_camera_param=idx.cuda())
+    rgb, disp, acc, extras = M.render.render(
+        H=HH, W=WW, chunk=8192, rays=torch.stack([ro, rd]), retraw=True, camera_model=cm, mode="train",
+        network_query_fn=query, perturb=1.0, N_importance=sf, network_fine=net_f, N_samples=sc, network_fn=net_c,
+        use_viewdirs=True, white_bkgd=False, raw_noise_std=1.0, near=0., far=1.,
+        _randoms={k: v.cuda() for k, v in rnd.items()})
+    loss = torch.mean((rgb - target.cuda()) ** 2) + torch.mean((extras["rgb0"] - target.cuda()) ** 2)
+    loss.backward()
+
+    cam = _oracle_cam(spec, grad=True)
+    pc = {k: v.clone().requires_grad_(True) for k, v in synth.network_params(seed=0).items()}
+    pf = {k: v.clone().requires_grad_(True) for k, v in synth.network_params(seed=1).items()}
+    oo, od = O.camera_rays(cam, HH, WW, kps, idx)
+    vd = od / torch.norm(od, dim=-1, keepdim=True)
+    fx, fy, _, _ = O.camera_intrinsic_params(cam)
+    no, nd = O.ndc_rays(HH, WW, fx, fy, 1.0, oo, od)
+    batch = torch.cat([no, nd, torch.zeros(n, 1), torch.ones(n, 1), vd], -1)
+    out = O.clamp_rgb_inplace(O.render_rays(batch, pc, pf, sc, sf, rnd["t_rand"], rnd["u"], rnd["noise_c"],
+                                            rnd["noise_f"], rowsum="aten"))
+    ref_loss = torch.mean((out["rgb_map"] - target) ** 2) + torch.mean((out["rgb0"] - target) ** 2)
+    ref_loss.backward()
+    np.testing.assert_allclose(extras["rgb0"].detach().cpu().numpy(), out["rgb0"].detach().numpy(), rtol=0, atol=1e-4)
+    e = np.abs(rgb.detach().cpu().numpy() - out["rgb_map"].detach().numpy()).max(1)
+    assert (e < 1e-4).mean() >= 0.98 and e.max() < 2e-2, ((e < 1e-4).mean(), e.max())
+    np.testing.assert_allclose(float(loss.detach()), float(ref_loss.detach()), rtol=2e-4)
+    # camera gradients: PE-amplified (2^9) and sensitive to the handful of rays whose fine samples moved
+    for name, tol in (("intrinsics_noise", 3e-2), ("extrinsics_noise", 3e-2), ("ray_o_noise", 5e-2), ("ray_d_noise", 5e-2)):
+        got = getattr(cm, name).grad
+        assert got is not None, name
+        close(got, cam[name].grad.numpy(), tol, name)

@@ -1,0 +1,76 @@
+"""World-size-2 test of the flat-gradient all-reduce on CPU (gloo) + ray sharding."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from scnerf_amd.parallel import FlatGradAllReduce, shard_rays
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    a = torch.nn.Linear(5, 3)
+    b = torch.nn.Linear(3, 2)
+    red = FlatGradAllReduce([a, b], world)
+    n_total = 11
+    lo, hi = shard_rays(n_total, rank, world)
+    x = torch.arange(n_total * 5, dtype=torch.float32).reshape(n_total, 5) / 10.0
+    for step in range(2):                       # second step checks zero() + re-pointing
+        red.zero()
+        if step == 1:
+            a.weight.grad = None                # e.g. optimizer.zero_grad(set_to_none=True)
+            red.zero()
+        y = b(torch.relu(a(x[lo:hi])))
+        (y.sum() / (hi - lo)).backward()        # mean over the local shard
+        flat = red.all_reduce().clone()
+    np.save(os.path.join(out_dir, "flat%d.npy" % rank), flat.numpy())
+    np.save(os.path.join(out_dir, "w%d.npy" % rank), a.weight.grad.numpy())
+    dist.destroy_process_group()
+
+
+def test_flat_grad_all_reduce_two_ranks(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    f0, f1 = np.load(tmp_path / "flat0.npy"), np.load(tmp_path / "flat1.npy")
+    np.testing.assert_array_equal(f0, f1)
+    # reference: average of the two shard-mean gradients
+    torch.manual_seed(0)
+    a = torch.nn.Linear(5, 3)
+    b = torch.nn.Linear(3, 2)
+    x = torch.arange(55, dtype=torch.float32).reshape(11, 5) / 10.0
+    tot = None
+    for r in range(world):
+        lo, hi = shard_rays(11, r, world)
+        for m in (a, b):
+            m.zero_grad()
+        (b(torch.relu(a(x[lo:hi]))).sum() / (hi - lo)).backward()
+        g = torch.cat([p.grad.reshape(-1) for m in (a, b) for p in m.parameters()])
+        tot = g if tot is None else tot + g
+    np.testing.assert_allclose(f0, (tot / world).numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(np.load(tmp_path / "w0.npy").reshape(-1), f0[:15], rtol=0, atol=0)
+
+
+def test_shard_rays_partitions_exactly():
+    for n in (0, 1, 7, 4096, 4099):
+        for w in (1, 2, 3, 8):
+            spans = [shard_rays(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
