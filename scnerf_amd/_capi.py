@@ -11,7 +11,7 @@ from ctypes import c_int, c_int64, c_longlong, c_void_p, c_float
 F = c_float
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscnerf_hip.so")
+LIB_PATH = os.environ.get("SCNERF_HIP_LIB") or os.path.join(_HERE, "libscnerf_hip.so")   # override: kernel experiments
 
 P = c_void_p
 I = c_int

@@ -41,6 +41,10 @@ __device__ __forceinline__ int popcount64(unsigned long long m) { return __popcl
 
 __device__ __forceinline__ void block_sync() { __syncthreads(); }
 
+// Compiler-only fence: instructions are not moved across it by the machine scheduler (used to keep
+// prefetches where they were written; no instruction is emitted).
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
 // Dynamic LDS of the launch (16-byte aligned; no static __shared__ anywhere, so the
 // dynamic region starts at offset 0: cdna_hip_programming.md guideline 17).
 template <typename T>

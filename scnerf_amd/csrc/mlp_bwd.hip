@@ -90,12 +90,13 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
     mfma_part<4, 4, 4, 8>(brgb, acc4, ws);
     float dzv[64];
     mask_to_regs<4>(acc4, load_mask(save, P, 8, wave_tile, lane), dzv);
-    store_rows<4>(dzv, grads + (long)kGradDzv * P, pc, 128, h, live);
+    // every gradient tensor the wgrad GEMMs need is the B operand of the next part: it is stored
+    // chunk by chunk while that part runs (mfma_part's save_row)
 
     // ---- views layer^T : [d feature | d encoded dir] = W_v^T dZ_v ------------------------
     f32x16 acc[8];
     zero_acc<8>(acc);
-    mfma_part<64, 8, 16, 4>(dzv, acc, ws);
+    mfma_part<64, 8, 16, 4>(dzv, acc, ws, row_ptr(grads + (long)kGradDzv * P, pc, 128, h, live));
     f32x16 acce1[1];
     zero_acc<1>(acce1);
     mfma_part<64, 1, 64, 8>(dzv, acce1, ws);
@@ -104,7 +105,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
     for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dz[16 * t + r] = acc[t][r];          // d feature (linear layer)
-    store_rows<8>(dz, grads + (long)kGradDfeat * P, pc, 256, h, live);
     {
         float dev[16];
 #pragma unroll
@@ -132,9 +132,8 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
                 acc[t][r] = (h ? w1 : w0) * dsigma;
             }
     }
-    mfma_part<128, 8, 16, 8>(dz, acc, ws);
+    mfma_part<128, 8, 16, 8>(dz, acc, ws, row_ptr(grads + (long)kGradDfeat * P, pc, 256, h, live));
     mask_to_regs<8>(acc, load_mask(save, P, 7, wave_tile, lane), dz);      // dZ of trunk layer 7
-    store_rows<8>(dz, grads + (long)(kGradDz + 7 * 256) * P, pc, 256, h, live);
 
     // ---- trunk layers 7..1 : d h_{l-1} = W_l^T dZ_l, then the ReLU mask of layer l-1 ------
     float de[32];
@@ -143,7 +142,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {
         zero_acc<8>(acc);
-        mfma_part<128, 8, 16, 8>(dz, acc, ws);
+        mfma_part<128, 8, 16, 8>(dz, acc, ws, row_ptr(grads + (long)(kGradDz + l * 256) * P, pc, 256, h, live));
         if (l == 5) {
             // skip connection: layer 5 also consumed the encoded point (columns 0..62)
             f32x16 acce[2];
@@ -155,14 +154,13 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
                 for (int r = 0; r < 16; ++r) de[16 * t + r] = acce[t][r];
         }
         mask_to_regs<8>(acc, load_mask(save, P, l - 1, wave_tile, lane), dz);
-        store_rows<8>(dz, grads + (long)(kGradDz + (l - 1) * 256) * P, pc, 256, h, live);
     }
 
     // ---- layer 0^T : d encoded point, then the encoding's own gradient -> d pts ------------
     {
         f32x16 acce[2];
         zero_acc<2>(acce);
-        mfma_part<128, 2, 64, 0>(dz, acce, ws);
+        mfma_part<128, 2, 64, 0>(dz, acce, ws, row_ptr(grads + (long)kGradDz * P, pc, 256, h, live));
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll

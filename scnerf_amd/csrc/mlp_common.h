@@ -104,8 +104,13 @@ struct WStream {
 template <int N_F4>
 __device__ __forceinline__ void stream_issue(const WStream& ws, f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1]) {
     const int tid = threadIdx.x;
+#ifndef SCN_ABLATE_NO_STREAM       // (timing experiments only)
 #pragma unroll
     for (int i = 0; i < N_F4; ++i) stage[i] = ws.g[i * kThreads + tid];
+#else
+#pragma unroll
+    for (int i = 0; i < N_F4; ++i) stage[i] = f32x4{1.f, 2.f, 3.f, (float)tid};
+#endif
 }
 
 template <int N_F4>
@@ -128,21 +133,78 @@ __device__ __forceinline__ void stream_prime(WStream& ws) {
     block_sync();
 }
 
+// rows [p][32 t + 8 q + 4 h + (0..3)] of a row-major [P][ld] tensor <- registers 16 t + 4 q + (0..3):
+// one 16-byte store per (t, q).  `row` already points at column 4 h of this lane's sample (or is
+// nullptr for a lane without a sample).
+template <int T0, int T1, int N>
+__device__ __forceinline__ void store_tiles(const float (&regs)[N], float* row) {
+    if (row == nullptr) return;
+#pragma unroll
+    for (int t = T0; t < T1; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v = {regs[16 * t + 4 * q + 0], regs[16 * t + 4 * q + 1], regs[16 * t + 4 * q + 2],
+                       regs[16 * t + 4 * q + 3]};
+            *reinterpret_cast<f32x4*>(row + 32 * t + 8 * q) = v;
+        }
+}
+
 // One chunk: CS steps x NT tiles out of LDS buffer `A`, B operands b[B0 .. B0 + CS).
-template <int NSTEP, int NT, int CS, int B0>
-__device__ __forceinline__ void mfma_chunk(const float (&b)[NSTEP], f32x16 (&acc)[NT], const f32x4* A,
-                                           int lane) {
+// The A fragments (one ds_read_b128 = 4 consecutive steps of one tile) go through a 3-deep register
+// ring with prefetch distance 2 -- 512 MFMA cycles ahead of use, so LDS latency never reaches the
+// matrix pipe (the compiler's own schedule kept one read in flight and waited on it: ~20 % idle).
+// At 3/4 of the chunk the staged registers of the NEXT chunk are written to the other LDS buffer,
+// overlapping the ds_write burst with MFMAs instead of serialising it in front of the barrier.
+template <int NSTEP, int NT, int CS, int B0, int N_F4>
+__device__ __forceinline__ void mfma_chunk(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
+                                           const f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1], int lane) {
     constexpr int G = CS / 4;
+    constexpr int NF = G * NT;                 // fragments, order f = g * NT + t
+    const f32x4* A = reinterpret_cast<const f32x4*>(ws.buf[ws.cur]) + lane;
+    if constexpr (NT % 2 == 0) {
+        // Two tiles are interleaved so that consecutive MFMAs never target the same accumulator
+        // (a 4-deep dependent chain on one accumulator issues measurably slower than 64 cycles).
+        constexpr int NP = NF / 2;             // fragment pairs (tiles t, t+1 of the same 4 steps)
+        constexpr int COMMIT_AT = (NP * 3) / 4;
+        f32x4 ring[4];
+        ring[0] = A[((0 % NT) * G + 0 / NT) * 64];
+        ring[1] = A[((1 % NT) * G + 1 / NT) * 64];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
+        for (int p = 0; p < NP; ++p) {
+            if (p + 1 < NP) {
+                const int f = 2 * p + 2;
+                ring[2 * ((p + 1) & 1) + 0] = A[((f % NT) * G + f / NT) * 64];
+                ring[2 * ((p + 1) & 1) + 1] = A[(((f + 1) % NT) * G + (f + 1) / NT) * 64];
+            }
+            if (p == COMMIT_AT) stream_commit<N_F4>(ws, stage);
+            sched_fence();      // keep the reads one pair (512 MFMA cycles) ahead of their use
+            const int f = 2 * p, g = f / NT, t = f % NT;
+            const f32x4 a0 = ring[2 * (p & 1)], a1 = ring[2 * (p & 1) + 1];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const f32x4 a = A[(t * G + g) * 64 + lane];
+            for (int j = 0; j < 4; ++j) {
+                acc[t] = mfma_32x32x2(a0[j], b[B0 + 4 * g + j], acc[t]);
+                acc[t + 1] = mfma_32x32x2(a1[j], b[B0 + 4 * g + j], acc[t + 1]);
+            }
+        }
+        if (COMMIT_AT >= NP) stream_commit<N_F4>(ws, stage);
+    } else {
+        constexpr int COMMIT_AT = (NF * 3) / 4;
+        f32x4 ring[3];
+        ring[0] = A[((0 % NT) * G + 0 / NT) * 64];
+        if (NF > 1) ring[1] = A[((1 % NT) * G + 1 / NT) * 64];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            if (f + 2 < NF) ring[(f + 2) % 3] = A[(((f + 2) % NT) * G + (f + 2) / NT) * 64];
+            if (f == COMMIT_AT) stream_commit<N_F4>(ws, stage);
+            sched_fence();
+            const int g = f / NT, t = f % NT;
+            const f32x4 a = ring[f % 3];
             acc[t] = mfma_32x32x2(a[0], b[B0 + 4 * g + 0], acc[t]);
             acc[t] = mfma_32x32x2(a[1], b[B0 + 4 * g + 1], acc[t]);
             acc[t] = mfma_32x32x2(a[2], b[B0 + 4 * g + 2], acc[t]);
             acc[t] = mfma_32x32x2(a[3], b[B0 + 4 * g + 3], acc[t]);
         }
+        if (COMMIT_AT >= NF) stream_commit<N_F4>(ws, stage);
     }
 }
 
@@ -152,25 +214,33 @@ struct PartLoop {
     static constexpr int CHUNK_F4 = NT * CS * 64 / 4 / kThreads;
     static constexpr int N_F4 = (C + 1 < NC) ? CHUNK_F4 : NEXT_F4;
     static __device__ __forceinline__ void run(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
-                                               int lane) {
+                                               int lane, float* save_row) {
         f32x4 stage[N_F4 > 0 ? N_F4 : 1];
         stream_issue<N_F4>(ws, stage);
-        mfma_chunk<NSTEP, NT, CS, C * CS>(b, acc, reinterpret_cast<const f32x4*>(ws.buf[ws.cur]), lane);
-        stream_commit<N_F4>(ws, stage);
+        sched_fence();      // the loads stay at the head of the chunk: a whole chunk of MFMAs covers them
+        // the B operands of this part are the previous layer's activations (forward) / this layer's
+        // output gradient (backward): the slice this chunk contracts over is stored now, so the
+        // training-mode HBM writes trickle out under the MFMAs instead of bursting at a layer end
+        if constexpr (CS >= 16) store_tiles<(C * CS) / 16, ((C + 1) * CS) / 16, NSTEP>(b, save_row);
+        mfma_chunk<NSTEP, NT, CS, C * CS, N_F4>(b, acc, ws, stage, lane);
+#ifndef SCN_ABLATE_NO_BARRIER      // (timing experiments only: tools/ablate.sh)
         block_sync();
+#endif
         ws.cur ^= 1;
-        if constexpr (C + 1 < NC) PartLoop<NSTEP, NT, CS, NEXT_F4, C + 1>::run(b, acc, ws, lane);
+        if constexpr (C + 1 < NC) PartLoop<NSTEP, NT, CS, NEXT_F4, C + 1>::run(b, acc, ws, lane, save_row);
     }
 };
 
 // One "part" = NSTEP MFMA steps over NT output tiles with B operands taken from registers
 // b[0..NSTEP).  CS steps per LDS chunk; NEXT_F4 = 16-byte loads per thread of the chunk that
-// follows this part in the stream (0 at the end of the stream).
+// follows this part in the stream (0 at the end of the stream).  save_row: where this lane's
+// B-operand row goes in HBM (column 4 h of its sample's row), or nullptr.
 template <int NSTEP, int NT, int CS, int NEXT_F4>
-__device__ __forceinline__ void mfma_part(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws) {
+__device__ __forceinline__ void mfma_part(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
+                                          float* save_row = nullptr) {
     static_assert(NSTEP % CS == 0 && CS % 4 == 0, "chunking");
     static_assert((NT * CS * 64) % (4 * kThreads) == 0, "chunk must be whole 16-byte loads per thread");
-    PartLoop<NSTEP, NT, CS, NEXT_F4, 0>::run(b, acc, ws, lane_id());
+    PartLoop<NSTEP, NT, CS, NEXT_F4, 0>::run(b, acc, ws, lane_id(), save_row);
 }
 
 // acc[t][r] = bias of feature feat_of(t, r, h); bias_hp is the half-pair table
@@ -195,20 +265,9 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NT]) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 }
 
-// rows [p][col0 + feat_of(t, 4q .. 4q+3, h)] <- 4 consecutive features per 16-byte store
-template <int NT>
-__device__ __forceinline__ void store_rows(const float* regs, float* __restrict__ base, long p,
-                                           int ld, int h, bool live) {
-    if (!live) return;
-    float* row = base + p * ld + 4 * h;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 v = {regs[16 * t + 4 * q + 0], regs[16 * t + 4 * q + 1], regs[16 * t + 4 * q + 2],
-                       regs[16 * t + 4 * q + 3]};
-            *reinterpret_cast<f32x4*>(row + 32 * t + 8 * q) = v;
-        }
+// this lane's row pointer inside a row-major [P][ld] section (nullptr when the lane has no sample)
+__device__ __forceinline__ float* row_ptr(float* base, long p, int ld, int h, bool live) {
+    return live ? base + p * ld + 4 * h : nullptr;
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));

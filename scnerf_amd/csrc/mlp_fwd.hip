@@ -65,25 +65,47 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     stream_prime<8>(ws);   // first chunk of E0 (8 tiles x 16 steps)
 
     const float px = pts[pc * 3 + 0], py = pts[pc * 3 + 1], pz = pts[pc * 3 + 2];
-    float e[32];
-    pe_slots<10, 32>(px, py, pz, h, e);
-    if (save) store_pe<10, 32>(e, save + (long)kSaveEpts * P, pc, 64, h, live);
 
     float hreg[256 / 2];           // this lane's 128 of the 256 trunk features
     f32x16 acc[8];
     float sigma_part = 0.f;
 
-    // trunk layers 0..7 and the (linear) feature layer as l == 8
-#pragma unroll 1
-    for (int l = 0; l <= 8; ++l) {
-        init_bias<8>(acc, wpk + (l < 8 ? kFwdBias + 256 * l : kFwdBiasF), h);
-        if (l == 0 || l == 5) mfma_part<32, 8, 16, 8>(e, acc, ws);
-        if (l != 0) mfma_part<128, 8, 16, 8>(hreg, acc, ws);   // every chunk that can follow is 8 x 16 B / thread
-        relu_to_regs<128>(acc, hreg, l < 8);
-        if (save) {
-            store_rows<8>(hreg, save + (long)(l < 8 ? kSaveAct + 256 * l : kSaveFeat) * P, pc, 256, h, live);
-            if (l < 8) *reinterpret_cast<u32x4*>(mask_ptr(save, P, l, wave_tile, lane)) = relu_bits<128>(hreg);
+    // layer 0 (peeled: nothing else is live while the 30 sincos of the encoding run).  The encoded
+    // point is parked in LDS for the skip layer instead of staying live through layers 1..4.
+    f32x4* park = reinterpret_cast<f32x4*>(ws.buf[0] + 2 * kMaxChunkFwd) + threadIdx.x;
+    {
+        float e[32];
+        pe_slots<10, 32>(px, py, pz, h, e);
+        if (save) store_pe<10, 32>(e, save + (long)kSaveEpts * P, pc, 64, h, live);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            f32x4 v = {e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3]};
+            park[g * kThreads] = v;
         }
+        init_bias<8>(acc, wpk + kFwdBias, h);
+        mfma_part<32, 8, 16, 8>(e, acc, ws);
+        relu_to_regs<128>(acc, hreg, true);
+        if (save) *reinterpret_cast<u32x4*>(mask_ptr(save, P, 0, wave_tile, lane)) = relu_bits<128>(hreg);
+    }
+
+    // trunk layers 1..7 and the (linear) feature layer as l == 8.  In training mode the output of
+    // layer l-1 (the B operand of layer l's main part) is written to HBM chunk by chunk during layer l.
+#pragma unroll 1
+    for (int l = 1; l <= 8; ++l) {
+        init_bias<8>(acc, wpk + (l < 8 ? kFwdBias + 256 * l : kFwdBiasF), h);
+        if (l == 5) {
+            float e[32];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 v = park[g * kThreads];
+                e[4 * g] = v[0]; e[4 * g + 1] = v[1]; e[4 * g + 2] = v[2]; e[4 * g + 3] = v[3];
+            }
+            mfma_part<32, 8, 16, 8>(e, acc, ws);
+        }
+        mfma_part<128, 8, 16, 8>(hreg, acc, ws,       // every chunk that can follow is 8 x 16 B / thread
+                                 save ? row_ptr(save + (long)(kSaveAct + 256 * (l - 1)) * P, pc, 256, h, live) : nullptr);
+        relu_to_regs<128>(acc, hreg, l < 8);
+        if (save && l < 8) *reinterpret_cast<u32x4*>(mask_ptr(save, P, l, wave_tile, lane)) = relu_bits<128>(hreg);
         if (l == 7) {
             // density head on the VALU: sigma = w_alpha . h8 + b  (half of the features per lane)
             const float* wa = wpk + kFwdAlphaW;
@@ -102,18 +124,16 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     if (save) store_pe<4, 16>(ev, save + (long)kSaveEviews * P, pc, 32, h, live);
     f32x16 accv[4];
     init_bias<4>(accv, wpk + kFwdBiasV, h);
-    mfma_part<128, 4, 32, 4>(hreg, accv, ws);   // then VE: 4 tiles x 16 steps = 4 f4
-    mfma_part<16, 4, 16, 4>(ev, accv, ws);      // then RGB: 1 tile x 64 steps = 4 f4
+    mfma_part<128, 4, 32, 4>(hreg, accv, ws,             // then VE: 4 tiles x 16 steps = 4 f4
+                             save ? row_ptr(save + (long)kSaveFeat * P, pc, 256, h, live) : nullptr);
+    mfma_part<16, 4, 16, 4>(ev, accv, ws);               // then RGB: 1 tile x 64 steps = 4 f4
     float hv[64];
     relu_to_regs<64>(accv, hv, true);
-    if (save) {
-        store_rows<4>(hv, save + (long)kSaveHv * P, pc, 128, h, live);
-        *reinterpret_cast<u32x4*>(mask_ptr(save, P, 8, wave_tile, lane)) = relu_bits<64>(hv);
-    }
+    if (save) *reinterpret_cast<u32x4*>(mask_ptr(save, P, 8, wave_tile, lane)) = relu_bits<64>(hv);
 
     f32x16 accc[1];
     init_bias<1>(accc, wpk + kFwdBiasRGB, h);
-    mfma_part<64, 1, 64, 0>(hv, accc, ws);
+    mfma_part<64, 1, 64, 0>(hv, accc, ws, save ? row_ptr(save + (long)kSaveHv * P, pc, 128, h, live) : nullptr);
 
     const float sigma = sigma_part + shfl_xor(sigma_part, 32) + wpk[kFwdAlphaB];
     if (live && h == 0) {
@@ -164,7 +184,13 @@ extern "C" int scnerf_mlp_fwd(const float* pts, const float* viewdirs, int vd_st
                               void* stream) {
     SCN_RETURN_IF(!pts || !viewdirs || !wpacked || !raw || samples_per_ray < 1 || vd_stride < 3 || n_samples < 0, SCN_EINVAL);
     if (n_samples == 0) return 0;
-    const size_t lds = (size_t)2 * kMaxChunkFwd * sizeof(float);
+    const size_t lds = (size_t)(2 * kMaxChunkFwd + 32 * kThreads) * sizeof(float);   // weights + parked encodings
+    static bool lds_opt_in = false;          // 96 KB of dynamic LDS needs the per-kernel opt-in (> 64 KB)
+    if (!lds_opt_in) {
+        SCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_opt_in = true;
+    }
     hipLaunchKernelGGL(mlp_fwd_kernel, dim3(scn_ceil_div(n_samples, kSamplesPerBlock)), dim3(kThreads), lds,
                        (hipStream_t)stream, pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save,
                        (long)n_samples);

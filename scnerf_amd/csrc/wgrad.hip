@@ -36,7 +36,7 @@ struct WgradArgs {
     float* part_v;                            // [G][BK + 1]  (last = sum v)
 };
 
-template <int WN, int WK>
+template <int WN, int WK, bool HAS_VEC>
 __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
     constexpr int BN = 2 * WN * 32, BK = 2 * WK * 32;
     constexpr int STAGE = kMS * (BN + BK) + kMS;           // floats per LDS stage (+ vec)
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
             if (p < p_end && col < a.k_load) v = *reinterpret_cast<const f32x4*>(a.B + p * a.ldb + col);
             sb[q] = v;
         }
-        if (a.vec && tid < kMS) {
+        if (HAS_VEC && tid < kMS) {
             const long p = p0 + tid;
             sv = p < p_end ? a.vec[p * a.vec_stride] : 0.f;
         }
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
         for (int q = 0; q < A_F4; ++q) *reinterpret_cast<f32x4*>(s + (q * kThreads + tid) * 4) = sa[q];
 #pragma unroll
         for (int q = 0; q < B_F4; ++q) *reinterpret_cast<f32x4*>(s + kMS * BN + (q * kThreads + tid) * 4) = sb[q];
-        if (a.vec && tid < kMS) s[kMS * (BN + BK) + tid] = sv;
+        if (HAS_VEC && tid < kMS) s[kMS * (BN + BK) + tid] = sv;
     };
 
     if (n_stage > 0) {
@@ -106,34 +106,43 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
     block_sync();
     for (int st = 0; st < n_stage; ++st) {
         const int buf = st & 1;
-        if (st + 1 < n_stage) issue(st + 1);
+        const bool more = st + 1 < n_stage;
+        if (more) issue(st + 1);
+        sched_fence();          // the global loads stay at the head of the stage
         const float* As = lds + buf * STAGE;
         const float* Bs = As + kMS * BN;
         const float* Vs = Bs + kMS * BK;
+        // operands of step s+1 are read while the 16 (WN x WK) MFMAs of step s run
+        float av[2][WN], bv[2][WK], vv[2] = {0.f, 0.f};
+        auto read_step = [&](int s2, int slot) {
+            const int row = 2 * s2 + mh;
+#pragma unroll
+            for (int i = 0; i < WN; ++i) av[slot][i] = As[row * BN + (wn * WN + i) * 32 + li];
+#pragma unroll
+            for (int j = 0; j < WK; ++j) bv[slot][j] = Bs[row * BK + (wk * WK + j) * 32 + li];
+            if (HAS_VEC) vv[slot] = Vs[row];
+        };
+        read_step(0, 0);
 #pragma unroll
         for (int s = 0; s < kMS / 2; ++s) {
-            const int row = 2 * s + mh;
-            float av[WN], bv[WK];
-#pragma unroll
-            for (int i = 0; i < WN; ++i) av[i] = As[row * BN + (wn * WN + i) * 32 + li];
-#pragma unroll
-            for (int j = 0; j < WK; ++j) bv[j] = Bs[row * BK + (wk * WK + j) * 32 + li];
+            const int cur = s & 1;
+            if (s + 1 < kMS / 2) read_step(s + 1, cur ^ 1);
+            if (s == (kMS / 2) * 3 / 4 && more) commit(buf ^ 1);
+            sched_fence();
 #pragma unroll
             for (int i = 0; i < WN; ++i)
 #pragma unroll
-                for (int j = 0; j < WK; ++j) acc[i][j] = mfma_32x32x2(av[i], bv[j], acc[i][j]);
+                for (int j = 0; j < WK; ++j) acc[i][j] = mfma_32x32x2(av[cur][i], bv[cur][j], acc[i][j]);
             if (wk == 0) {
 #pragma unroll
-                for (int i = 0; i < WN; ++i) bsum[i] += av[i];
+                for (int i = 0; i < WN; ++i) bsum[i] += av[cur][i];
             }
-            if (a.vec && wn == 0) {
-                const float vv = Vs[row];
+            if (HAS_VEC && wn == 0) {
 #pragma unroll
-                for (int j = 0; j < WK; ++j) vsum[j] = fmaf(vv, bv[j], vsum[j]);
-                if (wk == 0 && li == 0) vtot += vv;
+                for (int j = 0; j < WK; ++j) vsum[j] = fmaf(vv[cur], bv[cur][j], vsum[j]);
+                if (wk == 0 && li == 0) vtot += vv[cur];
             }
         }
-        if (st + 1 < n_stage) commit(buf ^ 1);
         block_sync();
     }
 
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
             if (mh == 0) a.part_b[(long)blockIdx.x * BN + (wn * WN + i) * 32 + li] = tot;
         }
     }
-    if (a.vec && wn == 0) {
+    if (HAS_VEC && wn == 0) {
 #pragma unroll
         for (int j = 0; j < WK; ++j) {
             const float tot = vsum[j] + shfl_xor(vsum[j], 32);
@@ -169,43 +178,47 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
     }
 }
 
+// fixed-order sum over the G partials with four independent accumulators (four loads in flight per
+// thread: the single-accumulator loop was latency-bound at ~1 TB/s)
+__device__ __forceinline__ float sum_partials(const float* __restrict__ p, long stride, int G) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int g = 0;
+    for (; g + 3 < G; g += 4) {
+        const float a = p[(long)g * stride], b = p[(long)(g + 1) * stride];
+        const float c = p[(long)(g + 2) * stride], d = p[(long)(g + 3) * stride];
+        s0 += a; s1 += b; s2 += c; s3 += d;
+    }
+    for (; g < G; ++g) s0 += p[(long)g * stride];
+    return (s0 + s1) + (s2 + s3);
+}
+
 // out[n * ldo + col0 + k] = sum_g part[g][n][k]   (n < n_out, k < k_out), fixed order over g
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part_w, const float* __restrict__ part_b,
-                                    const float* __restrict__ part_v, int G, int BN, int BK, int n_out,
-                                    int k_out, float* __restrict__ dW, int ldo, int col0,
-                                    float* __restrict__ db, float* __restrict__ dv, float* __restrict__ dvsum) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(
+    const float* __restrict__ part_w, const float* __restrict__ part_b, const float* __restrict__ part_v, int G,
+    int BN, int BK, int n_out, int k_out, float* __restrict__ dW, int ldo, int col0, float* __restrict__ db,
+    float* __restrict__ dv, float* __restrict__ dvsum) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long nw = (long)n_out * k_out;
     if (idx < nw) {
         const int n = (int)(idx / k_out), k = (int)(idx % k_out);
-        float s = 0.f;
-        for (int g = 0; g < G; ++g) s += part_w[((long)g * BN + n) * BK + k];
-        dW[(long)n * ldo + col0 + k] = s;
+        dW[(long)n * ldo + col0 + k] = sum_partials(part_w + (long)n * BK + k, (long)BN * BK, G);
         return;
     }
     long j = idx - nw;
     if (db) {
         if (j < n_out) {
-            float s = 0.f;
-            for (int g = 0; g < G; ++g) s += part_b[(long)g * BN + j];
-            db[j] = s;
+            db[j] = sum_partials(part_b + j, BN, G);
             return;
         }
         j -= n_out;
     }
     if (dv) {
         if (j < k_out) {
-            float s = 0.f;
-            for (int g = 0; g < G; ++g) s += part_v[(long)g * (BK + 1) + j];
-            dv[j] = s;
+            dv[j] = sum_partials(part_v + j, BK + 1, G);
             return;
         }
         j -= k_out;
-        if (j == 0 && dvsum) {
-            float s = 0.f;
-            for (int g = 0; g < G; ++g) s += part_v[(long)g * (BK + 1) + BK];
-            *dvsum = s;
-        }
+        if (j == 0 && dvsum) *dvsum = sum_partials(part_v + BK, BK + 1, G);
     }
 }
 
@@ -213,7 +226,8 @@ template <int WN, int WK>
 int launch_wgrad(const WgradArgs& a, int G, hipStream_t stream) {
     constexpr int BN = 2 * WN * 32, BK = 2 * WK * 32;
     const size_t lds = (size_t)2 * (kMS * (BN + BK) + kMS) * sizeof(float);
-    hipLaunchKernelGGL((wgrad_kernel<WN, WK>), dim3(G), dim3(kThreads), lds, stream, a);
+    if (a.vec) hipLaunchKernelGGL((wgrad_kernel<WN, WK, true>), dim3(G), dim3(kThreads), lds, stream, a);
+    else hipLaunchKernelGGL((wgrad_kernel<WN, WK, false>), dim3(G), dim3(kThreads), lds, stream, a);
     return scn_launch_status();
 }
 

@@ -73,6 +73,7 @@ inline unsigned long long ballot(bool p) {
 inline int popcount64(unsigned long long m) { return __builtin_popcountll(m); }
 
 inline void block_sync() { simt::block_barrier(); }
+inline void sched_fence() {}
 
 template <typename T>
 inline T* dynamic_lds() { return reinterpret_cast<T*>(simt::block_lds()); }

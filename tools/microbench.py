@@ -1,9 +1,9 @@
 """Kernel micro-timings on the GPU box (HIP events on torch's current stream).
-    python tools/microbench.py [--samples 1048576]"""
+    python tools/microbench.py [--samples 786432]"""
 import argparse
 import json
-import sys
 import os
+import sys
 
 import torch
 
@@ -26,33 +26,28 @@ def timeit(fn, iters=10, warmup=2):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--samples", type=int, default=4096 * 256)
+    ap.add_argument("--samples", type=int, default=4096 * 192)
     a = ap.parse_args()
     ops.check_layout()
     p = synth.network_params(seed=0)
     flat = torch.cat([p[n].reshape(-1) for n, _ in ML.PARAM_SHAPES]).cuda()
     res = {}
-    res["pack_fwd_ms"] = timeit(lambda: ops.pack_weights(flat, "fwd"))
-    wpk = ops.pack_weights(flat, "fwd")
+    wf, wb = ops.pack_weights(flat, "fwd"), ops.pack_weights(flat, "bwd")
     P = a.samples
     pts = (torch.rand(P, 3, device="cuda") * 2 - 1)
-    vd = torch.nn.functional.normalize(torch.randn(P // 64, 3, device="cuda"), dim=-1)
-    save = torch.empty(ML.save_floats(P), device="cuda")
+    vd = torch.nn.functional.normalize(torch.randn(P // 192, 3, device="cuda"), dim=-1)
+    save = ops.save_workspace(P, "cuda")
+    d_raw = torch.randn(P, 4, device="cuda")
     flop = 2 * 593408 * P
     for name, sv in (("mlp_fwd_infer", None), ("mlp_fwd_train", save)):
-        ms = timeit(lambda: ops.mlp_fwd(pts, vd, 64, wpk, sv), iters=5)
-        res[name + "_ms"] = ms
-        res[name + "_tflops"] = flop / ms / 1e9
-    n = 4096
-    rays = synth.ray_batch(n).cuda()
-    t_vals = torch.linspace(0, 1, 64).cuda()
-    t_rand = torch.rand(n, 64, device="cuda")
-    res["coarse_sample_ms"] = timeit(lambda: ops.coarse_sample(rays, t_vals, t_rand, False))
-    z_c, _ = ops.coarse_sample(rays, t_vals, t_rand, False)
-    w_c = torch.rand(n, 64, device="cuda")
-    u = torch.rand(n, 128, device="cuda")
-    res["fine_sample_ms"] = timeit(lambda: ops.fine_sample(rays, z_c, w_c, u))
-    print(json.dumps(res, indent=1))
+        ms = timeit(lambda: ops.mlp_fwd(pts, vd, 192, wf, sv), iters=5)
+        res[name] = {"ms": ms, "tflops": flop / ms / 1e9}
+    ms = timeit(lambda: ops.mlp_bwd(d_raw, pts, vd, 192, wb, save), iters=5)
+    res["mlp_bwd"] = {"ms": ms, "tflops": flop / ms / 1e9}
+    grads, _, _ = ops.mlp_bwd(d_raw, pts, vd, 192, wb, save)
+    ms = timeit(lambda: ops.nerf_wgrad(save, grads, d_raw, P), iters=5)
+    res["wgrad_all"] = {"ms": ms, "tflops": flop / ms / 1e9}
+    print(json.dumps(res))
 
 
 if __name__ == "__main__":
