@@ -182,18 +182,24 @@ int scnerf_mlp_bwd(const float* d_raw, const float* pts, const float* viewdirs, 
 
 /* Weight / bias gradient of one nn.Linear as a GEMM reduced over the samples (what autograd
  * derives for the layers of NeRF/run_nerf_helpers.py:88-128):
- *   dW[n * ldo + col0 + k] = sum_p dz[p * lda + n] * x[p * ldb + k]     n < n_out, k < k_out
- *   db[n] = sum_p dz[p * lda + n]                                         (db may be NULL)
- *   dv[k] = sum_p vec[p * vec_stride] * x[p * ldb + k], *dvsum = sum_p vec[...]   (vec may be NULL)
- * Columns < n_load / k_load (multiples of 4, <= 256) are read with 16-byte loads, so dz and x
- * must be 16-byte aligned with lda, ldb multiples of 4.  The samples are split into n_chunks
- * workgroups whose partial results are summed in a fixed order; `workspace` holds
- * scnerf_wgrad_workspace_floats(n_load, k_load, n_chunks) floats. */
+ *   dW[n * ldo + col0 + k] = sum_p dz[p][n] * x[p][k]     n < n_out, k < k_out
+ *   db[n] = sum_p dz[p][n]                                  (db may be NULL)
+ * Each operand is either row-major [n_samples][ld] (*_tiled = 0; columns < n_load / k_load, multiples
+ * of 4 and <= 256, are read with 16-byte loads, so the pointer must be 16-byte aligned and ld a multiple
+ * of 4) or a TILE-NATIVE section of width ld as written by scnerf_mlp_fwd / scnerf_mlp_bwd (*_tiled = 1:
+ * per 32 samples a block [ld/32][4][64 lanes][4]; ld must equal n_load / k_load and be 64, 128 or 256).
+ * The samples are split into n_chunks workgroups whose partial results are summed in a fixed order;
+ * `workspace` holds scnerf_wgrad_workspace_floats(n_load, k_load, n_chunks) floats. */
 long long scnerf_wgrad_workspace_floats(int n_load, int k_load, int n_chunks);
-int scnerf_wgrad(const float* dz, int lda, int n_load, int n_out, const float* x, int ldb,
-                 int k_load, int k_out, const float* vec, int vec_stride, long long n_samples,
-                 int n_chunks, float* workspace, float* dW, int ldo, int col0, float* db,
-                 float* dv, float* dvsum, void* stream);
+int scnerf_wgrad(const float* dz, int lda, int n_load, int n_out, int dz_tiled, const float* x,
+                 int ldb, int k_load, int k_out, int x_tiled, long long n_samples, int n_chunks,
+                 float* workspace, float* dW, int ldo, int col0, float* db, void* stream);
+
+/* Gradient of a one-row linear layer (alpha_linear, NeRF/run_nerf_helpers.py:100,115):
+ * dv[k] = sum_p vec[p * vec_stride] * x[p][k] (k < 256) for a tile-native x of width 256, and
+ * *dvsum = sum_p vec[p * vec_stride] (may be NULL).  workspace: >= 257 * n_chunks floats. */
+int scnerf_vecmat(const float* x_tiled256, const float* vec, int vec_stride, long long n_samples,
+                  int n_chunks, float* workspace, float* dv, float* dvsum, void* stream);
 
 /* All weight and bias gradients of one standard NeRF, written into a flat gradient buffer in
  * the reference's parameter order (scnerf_nerf_param_count() floats; NeRF/run_nerf_helpers.py:

@@ -40,7 +40,8 @@ PROTOTYPES = {
     "scnerf_mlp_bwd": [P, P, P, I, I, P, P, P, P, P, LL, P],
     "scnerf_nerf_param_count": [],
     "scnerf_nerf_wgrad": [P, P, P, LL, I, P, P, P],
-    "scnerf_wgrad": [P, I, I, I, P, I, I, I, P, I, LL, I, P, P, I, I, P, P, P, P],
+    "scnerf_wgrad": [P, I, I, I, I, P, I, I, I, I, LL, I, P, P, I, I, P, P],
+    "scnerf_vecmat": [P, P, I, LL, I, P, P, P, P],
 }
 
 

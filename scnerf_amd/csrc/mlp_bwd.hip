@@ -35,7 +35,7 @@ __device__ __forceinline__ void mask_to_regs(const f32x16 (&acc)[NT], u32x4 bits
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = 16 * t + r;
-            dst[i] = ((bits[i >> 5] >> (i & 31)) & 1u) ? acc[t][r] : 0.f;
+            dst[i] = mask_select(acc[t][r], bits, i);
         }
 }
 
@@ -71,6 +71,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
     const long p = wave_tile * kSamplesPerWave + m;
     const bool live = p < P;
     const long pc = live ? p : P - 1;
+    const long Ppad = padded_samples(P);
 
     WStream ws;
     ws.g = reinterpret_cast<const f32x4*>(wbk);
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
     // ---- views layer^T : [d feature | d encoded dir] = W_v^T dZ_v ------------------------
     f32x16 acc[8];
     zero_acc<8>(acc);
-    mfma_part<64, 8, 16, 4>(dzv, acc, ws, row_ptr(grads + (long)kGradDzv * P, pc, 128, h, live));
+    mfma_part<64, 8, 16, 4>(dzv, acc, ws, tile_ptr(grads + (long)kGradDzv * Ppad, wave_tile, 128, lane));
     f32x16 acce1[1];
     zero_acc<1>(acce1);
     mfma_part<64, 1, 64, 8>(dzv, acce1, ws);
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
                 acc[t][r] = (h ? w1 : w0) * dsigma;
             }
     }
-    mfma_part<128, 8, 16, 8>(dz, acc, ws, row_ptr(grads + (long)kGradDfeat * P, pc, 256, h, live));
+    mfma_part<128, 8, 16, 8>(dz, acc, ws, tile_ptr(grads + (long)kGradDfeat * Ppad, wave_tile, 256, lane));
     mask_to_regs<8>(acc, load_mask(save, P, 7, wave_tile, lane), dz);      // dZ of trunk layer 7
 
     // ---- trunk layers 7..1 : d h_{l-1} = W_l^T dZ_l, then the ReLU mask of layer l-1 ------
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {
         zero_acc<8>(acc);
-        mfma_part<128, 8, 16, 8>(dz, acc, ws, row_ptr(grads + (long)(kGradDz + l * 256) * P, pc, 256, h, live));
+        mfma_part<128, 8, 16, 8>(dz, acc, ws, tile_ptr(grads + (long)(kGradDz + l * 256) * Ppad, wave_tile, 256, lane));
         if (l == 5) {
             // skip connection: layer 5 also consumed the encoded point (columns 0..62)
             f32x16 acce[2];
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
     {
         f32x16 acce[2];
         zero_acc<2>(acce);
-        mfma_part<128, 2, 64, 0>(dz, acce, ws, row_ptr(grads + (long)kGradDz * P, pc, 256, h, live));
+        mfma_part<128, 2, 64, 0>(dz, acce, ws, tile_ptr(grads + (long)kGradDz * Ppad, wave_tile, 256, lane));
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll

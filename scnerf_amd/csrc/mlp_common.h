@@ -36,9 +36,14 @@ constexpr int kBwdTotal = kBwdAlphaW + 256;
 constexpr int kMaxChunkFwd = 8192;      // floats: 32 KB, x2 buffers = 64 KB LDS
 constexpr int kMaxChunkBwd = 8192;      // floats: 32 KB, x2 buffers = 64 KB LDS
 
-// activation / gradient workspace section widths (row-major [P][width])
-constexpr int kSaveAct = 0;             // 8 x [P][256]
-constexpr int kSaveFeat = 8 * 256;      // offsets in floats-per-sample units (multiply by P)
+// Activation / gradient workspaces.  Offsets are in floats per (padded) sample: a section starts at
+// offset * padded_samples(P).  The wide sections (act*, feat, hv, dz*, dfeat, dzv) are TILE-NATIVE:
+// per wave tile of 32 samples a block [t][q][lane][4] (t = 32-feature tile, q = 0..3, lane = (m, h)),
+// holding feature 32 t + 8 q + 4 h + j of sample m at element j -- exactly the registers a lane owns,
+// so every store instruction of the MLP kernels writes 1 KB contiguous.  The wgrad GEMM stages whole
+// tiles linearly into LDS and reads this layout there.  epts / eviews are row-major [P][64] / [P][32].
+constexpr int kSaveAct = 0;             // 8 sections of width 256
+constexpr int kSaveFeat = 8 * 256;
 constexpr int kSaveHv = kSaveFeat + 256;
 constexpr int kSaveEpts = kSaveHv + 128;
 constexpr int kSaveEviews = kSaveEpts + 64;
@@ -133,19 +138,22 @@ __device__ __forceinline__ void stream_prime(WStream& ws) {
     block_sync();
 }
 
-// rows [p][32 t + 8 q + 4 h + (0..3)] of a row-major [P][ld] tensor <- registers 16 t + 4 q + (0..3):
-// one 16-byte store per (t, q).  `row` already points at column 4 h of this lane's sample (or is
-// nullptr for a lane without a sample).
+// tile-native block <- registers 16 t + 4 q + (0..3): one 16-byte store per (t, q), lane-contiguous.
+// `tile` points at this lane's 16 bytes inside (t, q) = (0, 0) of its wave tile's block (or is nullptr
+// when nothing is saved).  Lanes without a sample store too (their slot exists; values are finite).
 template <int T0, int T1, int N>
-__device__ __forceinline__ void store_tiles(const float (&regs)[N], float* row) {
-    if (row == nullptr) return;
+__device__ __forceinline__ void store_tiles(const float (&regs)[N], float* tile) {
+#ifdef SCN_ABLATE_NO_ROWSTORE      // (timing experiments only)
+    return;
+#endif
+    if (tile == nullptr) return;
 #pragma unroll
     for (int t = T0; t < T1; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 v = {regs[16 * t + 4 * q + 0], regs[16 * t + 4 * q + 1], regs[16 * t + 4 * q + 2],
                        regs[16 * t + 4 * q + 3]};
-            *reinterpret_cast<f32x4*>(row + 32 * t + 8 * q) = v;
+            *reinterpret_cast<f32x4*>(tile + (t * 4 + q) * 256) = v;     // 64 lanes x 16 B contiguous
         }
 }
 
@@ -214,33 +222,33 @@ struct PartLoop {
     static constexpr int CHUNK_F4 = NT * CS * 64 / 4 / kThreads;
     static constexpr int N_F4 = (C + 1 < NC) ? CHUNK_F4 : NEXT_F4;
     static __device__ __forceinline__ void run(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
-                                               int lane, float* save_row) {
+                                               int lane, float* save_tile) {
         f32x4 stage[N_F4 > 0 ? N_F4 : 1];
         stream_issue<N_F4>(ws, stage);
         sched_fence();      // the loads stay at the head of the chunk: a whole chunk of MFMAs covers them
         // the B operands of this part are the previous layer's activations (forward) / this layer's
         // output gradient (backward): the slice this chunk contracts over is stored now, so the
         // training-mode HBM writes trickle out under the MFMAs instead of bursting at a layer end
-        if constexpr (CS >= 16) store_tiles<(C * CS) / 16, ((C + 1) * CS) / 16, NSTEP>(b, save_row);
+        if constexpr (CS >= 16) store_tiles<(C * CS) / 16, ((C + 1) * CS) / 16, NSTEP>(b, save_tile);
         mfma_chunk<NSTEP, NT, CS, C * CS, N_F4>(b, acc, ws, stage, lane);
 #ifndef SCN_ABLATE_NO_BARRIER      // (timing experiments only: tools/ablate.sh)
         block_sync();
 #endif
         ws.cur ^= 1;
-        if constexpr (C + 1 < NC) PartLoop<NSTEP, NT, CS, NEXT_F4, C + 1>::run(b, acc, ws, lane, save_row);
+        if constexpr (C + 1 < NC) PartLoop<NSTEP, NT, CS, NEXT_F4, C + 1>::run(b, acc, ws, lane, save_tile);
     }
 };
 
 // One "part" = NSTEP MFMA steps over NT output tiles with B operands taken from registers
 // b[0..NSTEP).  CS steps per LDS chunk; NEXT_F4 = 16-byte loads per thread of the chunk that
-// follows this part in the stream (0 at the end of the stream).  save_row: where this lane's
-// B-operand row goes in HBM (column 4 h of its sample's row), or nullptr.
+// follows this part in the stream (0 at the end of the stream).  save_tile: this lane's slot in the
+// tile-native HBM section its B operands are saved to (tile_ptr), or nullptr.
 template <int NSTEP, int NT, int CS, int NEXT_F4>
 __device__ __forceinline__ void mfma_part(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
-                                          float* save_row = nullptr) {
+                                          float* save_tile = nullptr) {
     static_assert(NSTEP % CS == 0 && CS % 4 == 0, "chunking");
     static_assert((NT * CS * 64) % (4 * kThreads) == 0, "chunk must be whole 16-byte loads per thread");
-    PartLoop<NSTEP, NT, CS, NEXT_F4, 0>::run(b, acc, ws, lane_id(), save_row);
+    PartLoop<NSTEP, NT, CS, NEXT_F4, 0>::run(b, acc, ws, lane_id(), save_tile);
 }
 
 // acc[t][r] = bias of feature feat_of(t, r, h); bias_hp is the half-pair table
@@ -265,9 +273,9 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NT]) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 }
 
-// this lane's row pointer inside a row-major [P][ld] section (nullptr when the lane has no sample)
-__device__ __forceinline__ float* row_ptr(float* base, long p, int ld, int h, bool live) {
-    return live ? base + p * ld + 4 * h : nullptr;
+// this lane's slot in the tile-native section of `width` features that starts at `section`
+__device__ __forceinline__ float* tile_ptr(float* section, long wave_tile, int width, int lane) {
+    return section + wave_tile * (32L * width) + lane * 4;
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -276,17 +284,26 @@ __host__ __device__ inline long padded_samples(long P) {
     return (P + kSamplesPerBlock - 1) / kSamplesPerBlock * kSamplesPerBlock;
 }
 
-// bit i of the lane's mask = (v[i] > 0); N <= 128 registers -> 4 words
+// ReLU mask of N <= 128 registers in 4 words: element i sits in word i >> 5 at bit 31 - (i & 31)
+// (built by shifting in from the right: bits = 2 * bits + (v > 0) is one v_cmp + one v_addc_co).
 template <int N>
 __device__ __forceinline__ u32x4 relu_bits(const float (&v)[N]) {
     u32x4 bits = {0u, 0u, 0u, 0u};
+#ifndef SCN_ABLATE_NO_MASK         // (timing experiments only)
 #pragma unroll
-    for (int i = 0; i < N; ++i) bits[i >> 5] |= (v[i] > 0.f ? 1u : 0u) << (i & 31);
+    for (int i = 0; i < N; ++i) bits[i >> 5] = bits[i >> 5] + bits[i >> 5] + (v[i] > 0.f ? 1u : 0u);
+#endif
     return bits;
 }
 
+// v if the mask bit of element i is set, else +0 (bitwise AND with 0 / ~0: v_bfe_i32 + v_and_b32)
+__device__ __forceinline__ float mask_select(float v, u32x4 bits, int i) {
+    const int m = -(int)((bits[i >> 5] >> (31 - (i & 31))) & 1u);
+    return __int_as_float(__float_as_int(v) & m);
+}
+
 __device__ __forceinline__ unsigned int* mask_ptr(float* save, long P, int section, long wave_tile, int lane) {
-    unsigned int* base = reinterpret_cast<unsigned int*>(save + (long)kSavePerSample * P);
+    unsigned int* base = reinterpret_cast<unsigned int*>(save + (long)kSavePerSample * padded_samples(P));
     return base + ((long)section * (padded_samples(P) / 32) + wave_tile) * 256 + lane * 4;
 }
 

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     const long p = wave_tile * kSamplesPerWave + m;
     const bool live = p < P;
     const long pc = live ? p : P - 1;
+    const long Ppad = padded_samples(P);
 
     WStream ws;
     ws.g = reinterpret_cast<const f32x4*>(wpk);
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     {
         float e[32];
         pe_slots<10, 32>(px, py, pz, h, e);
-        if (save) store_pe<10, 32>(e, save + (long)kSaveEpts * P, pc, 64, h, live);
+        if (save) store_pe<10, 32>(e, save + (long)kSaveEpts * Ppad, pc, 64, h, live);
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             f32x4 v = {e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3]};
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
             mfma_part<32, 8, 16, 8>(e, acc, ws);
         }
         mfma_part<128, 8, 16, 8>(hreg, acc, ws,       // every chunk that can follow is 8 x 16 B / thread
-                                 save ? row_ptr(save + (long)(kSaveAct + 256 * (l - 1)) * P, pc, 256, h, live) : nullptr);
+                                 save ? tile_ptr(save + (long)(kSaveAct + 256 * (l - 1)) * Ppad, wave_tile, 256, lane) : nullptr);
         relu_to_regs<128>(acc, hreg, l < 8);
         if (save && l < 8) *reinterpret_cast<u32x4*>(mask_ptr(save, P, l, wave_tile, lane)) = relu_bits<128>(hreg);
         if (l == 7) {
@@ -121,11 +122,11 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     const long ray = pc / samples_per_ray;
     float ev[16];
     pe_slots<4, 16>(viewdirs[ray * vd_stride + 0], viewdirs[ray * vd_stride + 1], viewdirs[ray * vd_stride + 2], h, ev);
-    if (save) store_pe<4, 16>(ev, save + (long)kSaveEviews * P, pc, 32, h, live);
+    if (save) store_pe<4, 16>(ev, save + (long)kSaveEviews * Ppad, pc, 32, h, live);
     f32x16 accv[4];
     init_bias<4>(accv, wpk + kFwdBiasV, h);
     mfma_part<128, 4, 32, 4>(hreg, accv, ws,             // then VE: 4 tiles x 16 steps = 4 f4
-                             save ? row_ptr(save + (long)kSaveFeat * P, pc, 256, h, live) : nullptr);
+                             save ? tile_ptr(save + (long)kSaveFeat * Ppad, wave_tile, 256, lane) : nullptr);
     mfma_part<16, 4, 16, 4>(ev, accv, ws);               // then RGB: 1 tile x 64 steps = 4 f4
     float hv[64];
     relu_to_regs<64>(accv, hv, true);
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
 
     f32x16 accc[1];
     init_bias<1>(accc, wpk + kFwdBiasRGB, h);
-    mfma_part<64, 1, 64, 0>(hv, accc, ws, save ? row_ptr(save + (long)kSaveHv * P, pc, 128, h, live) : nullptr);
+    mfma_part<64, 1, 64, 0>(hv, accc, ws, save ? tile_ptr(save + (long)kSaveHv * Ppad, wave_tile, 128, lane) : nullptr);
 
     const float sigma = sigma_part + shfl_xor(sigma_part, 32) + wpk[kFwdAlphaB];
     if (live && h == 0) {
@@ -172,11 +173,11 @@ extern "C" int scnerf_mlp_layout_info(int* out, int n) {
 }
 
 extern "C" long long scnerf_mlp_save_floats(long long n_samples) {
-    return (long long)kSavePerSample * n_samples + (long long)kMaskWordsPerSample * padded_samples(n_samples);
+    return (long long)(kSavePerSample + kMaskWordsPerSample) * padded_samples(n_samples);
 }
 
 extern "C" long long scnerf_mlp_grad_floats(long long n_samples) {
-    return (long long)kGradPerSample * n_samples;
+    return (long long)kGradPerSample * padded_samples(n_samples);
 }
 
 extern "C" int scnerf_mlp_fwd(const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,

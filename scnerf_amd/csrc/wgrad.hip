@@ -23,23 +23,42 @@ namespace {
 using namespace scn;
 
 constexpr int kThreads = 256;
-constexpr int kMS = 16;   // samples per LDS stage
+constexpr int kMS = 32;   // samples per LDS stage = one wave tile of the MLP kernels
 
 struct WgradArgs {
-    const float* A; int lda; int n_load;      // dZ  [P][lda], columns < n_load are read
-    const float* B; int ldb; int k_load;      // X   [P][ldb], columns < k_load are read
-    const float* vec; int vec_stride;         // optional v[p] = vec[p * vec_stride]
-    long P;
-    long chunk;                               // samples per workgroup (multiple of kMS)
-    float* part_w;                            // [G][BN][BK]
-    float* part_b;                            // [G][BN]
-    float* part_v;                            // [G][BK + 1]  (last = sum v)
+    const float* A; int lda; int n_load; int a_tiled;   // dZ: tile-native section of width lda, or row-major [P][lda]
+    const float* B; int ldb; int k_load; int b_tiled;   // X : likewise
+    long P;                                             // valid samples (row-major operands are masked beyond)
+    long Ppad;                                          // samples the tile-native sections cover
+    long chunk;                                         // samples per workgroup (multiple of kMS)
+    float* part_w;                                      // [G][BN][BK]
+    float* part_b;                                      // [G][BN]
 };
 
-template <int WN, int WK, bool HAS_VEC>
+// LDS image of one staged operand: row-major [kMS samples][width + 4] (the 4-float pad makes the
+// 16-byte writes of 8 consecutive samples and the 4-byte reads of 32 consecutive columns both
+// conflict-free).  A 16-byte piece of either HBM layout holds 4 consecutive columns of one sample:
+//   row-major source : piece e -> sample e / width, column e % width
+//   tile-native source: piece index e/4 = (t*4 + q)*64 + lane, lane = m + 32 h -> sample m,
+//                       column 32 t + 8 q + 4 h
+__device__ __forceinline__ int lds_piece_offset(int e, int width, int tiled) {
+    int m, c;
+    if (tiled) {
+        const int piece = e >> 2, ln = piece & 63, tq = piece >> 6;
+        m = ln & 31;
+        c = (tq >> 2) * 32 + (tq & 3) * 8 + (ln >> 5) * 4;
+    } else {
+        m = e / width;
+        c = e % width;
+    }
+    return m * (width + 4) + c;
+}
+
+template <int WN, int WK>
 __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
     constexpr int BN = 2 * WN * 32, BK = 2 * WK * 32;
-    constexpr int STAGE = kMS * (BN + BK) + kMS;           // floats per LDS stage (+ vec)
+    constexpr int LDA = BN + 4, LDB = BK + 4;              // padded LDS row strides
+    constexpr int STAGE = kMS * (LDA + LDB);               // floats per LDS stage
     constexpr int A_F4 = kMS * BN / 4 / kThreads, B_F4 = kMS * BK / 4 / kThreads;
     static_assert(kMS * BN % (4 * kThreads) == 0 && kMS * BK % (4 * kThreads) == 0, "stage shape");
     float* lds = dynamic_lds<float>();
@@ -47,7 +66,8 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
     const int wn = wave >> 1, wk = wave & 1;
     const int li = lane & 31, mh = lane >> 5;
     const long p_begin = (long)blockIdx.x * a.chunk;
-    const long p_end = min(a.P, p_begin + a.chunk);
+    const long p_lim = a.Ppad;                              // tiles exist up to here
+    const long p_end = min(p_lim, p_begin + a.chunk);
     const int n_stage = p_begin < p_end ? (int)((p_end - p_begin + kMS - 1) / kMS) : 0;
 
     f32x16 acc[WN][WK];
@@ -57,46 +77,59 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
         for (int j = 0; j < WK; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float bsum[WN], vsum[WK], vtot = 0.f;
+    float bsum[WN];
 #pragma unroll
     for (int i = 0; i < WN; ++i) bsum[i] = 0.f;
-#pragma unroll
-    for (int j = 0; j < WK; ++j) vsum[j] = 0.f;
 
+    int a_dst[A_F4], b_dst[B_F4];      // where this thread's staged pieces go in the LDS image
+#pragma unroll
+    for (int q = 0; q < A_F4; ++q) a_dst[q] = lds_piece_offset((q * kThreads + tid) * 4, BN, a.a_tiled);
+#pragma unroll
+    for (int q = 0; q < B_F4; ++q) b_dst[q] = lds_piece_offset((q * kThreads + tid) * 4, BK, a.b_tiled);
+
+    // per-thread source offsets of the staged 16-byte pieces, relative to the stage's first sample
+    // (computed once: the address arithmetic must not sit in front of every stage's MFMAs)
+    int a_src[A_F4], b_src[B_F4], a_row[A_F4], b_row[B_F4];
+#pragma unroll
+    for (int q = 0; q < A_F4; ++q) {
+        const int e = (q * kThreads + tid) * 4;
+        if (a.a_tiled) { a_src[q] = e; a_row[q] = 0; }
+        else { a_src[q] = (e / BN) * a.lda + e % BN; a_row[q] = (e % BN) < a.n_load ? e / BN : kMS; }
+    }
+#pragma unroll
+    for (int q = 0; q < B_F4; ++q) {
+        const int e = (q * kThreads + tid) * 4;
+        if (a.b_tiled) { b_src[q] = e; b_row[q] = 0; }
+        else { b_src[q] = (e / BK) * a.ldb + e % BK; b_row[q] = (e % BK) < a.k_load ? e / BK : kMS; }
+    }
     f32x4 sa[A_F4], sb[B_F4];
-    float sv = 0.f;
     auto issue = [&](int st) {
         const long p0 = p_begin + (long)st * kMS;
+        // tile-native: the 32-sample block starts at p0 * ld; row-major: row p0.  Rows >= P of a
+        // row-major operand are zero (tile-native sections hold zeros / finite values there).
+        const float* As0 = a.A + p0 * a.lda;
+        const float* Bs0 = a.B + p0 * a.ldb;
+        const int rows = (int)min((long)kMS, a.P - p0);       // valid rows of a row-major operand
+        const int rows_a = a.a_tiled ? kMS : rows, rows_b = a.b_tiled ? kMS : rows;
 #pragma unroll
         for (int q = 0; q < A_F4; ++q) {
-            const int e = (q * kThreads + tid) * 4;      // element index inside [kMS][BN]
-            const int row = e / BN, col = e % BN;
-            const long p = p0 + row;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (p < p_end && col < a.n_load) v = *reinterpret_cast<const f32x4*>(a.A + p * a.lda + col);
+            if (a_row[q] < rows_a) v = *reinterpret_cast<const f32x4*>(As0 + a_src[q]);
             sa[q] = v;
         }
 #pragma unroll
         for (int q = 0; q < B_F4; ++q) {
-            const int e = (q * kThreads + tid) * 4;
-            const int row = e / BK, col = e % BK;
-            const long p = p0 + row;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (p < p_end && col < a.k_load) v = *reinterpret_cast<const f32x4*>(a.B + p * a.ldb + col);
+            if (b_row[q] < rows_b) v = *reinterpret_cast<const f32x4*>(Bs0 + b_src[q]);
             sb[q] = v;
-        }
-        if (HAS_VEC && tid < kMS) {
-            const long p = p0 + tid;
-            sv = p < p_end ? a.vec[p * a.vec_stride] : 0.f;
         }
     };
     auto commit = [&](int buf) {
         float* s = lds + buf * STAGE;
 #pragma unroll
-        for (int q = 0; q < A_F4; ++q) *reinterpret_cast<f32x4*>(s + (q * kThreads + tid) * 4) = sa[q];
+        for (int q = 0; q < A_F4; ++q) *reinterpret_cast<f32x4*>(s + a_dst[q]) = sa[q];
 #pragma unroll
-        for (int q = 0; q < B_F4; ++q) *reinterpret_cast<f32x4*>(s + kMS * BN + (q * kThreads + tid) * 4) = sb[q];
-        if (HAS_VEC && tid < kMS) s[kMS * (BN + BK) + tid] = sv;
+        for (int q = 0; q < B_F4; ++q) *reinterpret_cast<f32x4*>(s + kMS * LDA + b_dst[q]) = sb[q];
     };
 
     if (n_stage > 0) {
@@ -110,17 +143,15 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
         if (more) issue(st + 1);
         sched_fence();          // the global loads stay at the head of the stage
         const float* As = lds + buf * STAGE;
-        const float* Bs = As + kMS * BN;
-        const float* Vs = Bs + kMS * BK;
-        // operands of step s+1 are read while the 16 (WN x WK) MFMAs of step s run
-        float av[2][WN], bv[2][WK], vv[2] = {0.f, 0.f};
+        const float* Bs = As + kMS * LDA;
+        // operands of step s+1 are read while the WN x WK MFMAs of step s run
+        float av[2][WN], bv[2][WK];
         auto read_step = [&](int s2, int slot) {
-            const int row = 2 * s2 + mh;
+            const int m = 2 * s2 + mh;
 #pragma unroll
-            for (int i = 0; i < WN; ++i) av[slot][i] = As[row * BN + (wn * WN + i) * 32 + li];
+            for (int i = 0; i < WN; ++i) av[slot][i] = As[m * LDA + (wn * WN + i) * 32 + li];
 #pragma unroll
-            for (int j = 0; j < WK; ++j) bv[slot][j] = Bs[row * BK + (wk * WK + j) * 32 + li];
-            if (HAS_VEC) vv[slot] = Vs[row];
+            for (int j = 0; j < WK; ++j) bv[slot][j] = Bs[m * LDB + (wk * WK + j) * 32 + li];
         };
         read_step(0, 0);
 #pragma unroll
@@ -136,11 +167,6 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
             if (wk == 0) {
 #pragma unroll
                 for (int i = 0; i < WN; ++i) bsum[i] += av[cur][i];
-            }
-            if (HAS_VEC && wn == 0) {
-#pragma unroll
-                for (int j = 0; j < WK; ++j) vsum[j] = fmaf(vv[cur], bv[cur][j], vsum[j]);
-                if (wk == 0 && li == 0) vtot += vv[cur];
             }
         }
         block_sync();
@@ -165,16 +191,59 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
             if (mh == 0) a.part_b[(long)blockIdx.x * BN + (wn * WN + i) * 32 + li] = tot;
         }
     }
-    if (HAS_VEC && wn == 0) {
+}
+
+// dv[k] = sum_p v[p] * X[p][k] for a tile-native X of width 256 (alpha_linear's weight gradient:
+// v = d sigma, X = the last trunk activation), and sum_p v[p] (its bias gradient).  HBM-bound: X is
+// read once.  Thread `tid` owns the 16-byte pieces tid + 256 i (i < 8) of every tile it visits, i.e.
+// always the same 4 features of the same in-tile sample, so it accumulates them privately; the 32
+// samples of a tile are then folded with shuffles and the workgroups' partials are summed in a fixed
+// order by wgrad_reduce_kernel.
+__global__ __launch_bounds__(kThreads) void vecmat_kernel(const float* __restrict__ X, const float* __restrict__ vec,
+                                                          int vec_stride, long P, long n_tiles,
+                                                          float* __restrict__ part /* [G][257] */) {
+    const int tid = threadIdx.x, lane = lane_id();
+    const int m = lane & 31;
+    f32x4 acc[8];
 #pragma unroll
-        for (int j = 0; j < WK; ++j) {
-            const float tot = vsum[j] + shfl_xor(vsum[j], 32);
-            if (mh == 0) a.part_v[(long)blockIdx.x * (BK + 1) + (wk * WK + j) * 32 + li] = tot;
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float vs = 0.f;
+    for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long p = tile * 32 + m;
+        const float v = p < P ? vec[p * vec_stride] : 0.f;
+        if (tid < 32) vs += v;
+        const f32x4* blk = reinterpret_cast<const f32x4*>(X + tile * (32L * 256));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 x = blk[tid + kThreads * i];
+            acc[i][0] = fmaf(v, x[0], acc[i][0]); acc[i][1] = fmaf(v, x[1], acc[i][1]);
+            acc[i][2] = fmaf(v, x[2], acc[i][2]); acc[i][3] = fmaf(v, x[3], acc[i][3]);
         }
-        if (wk == 0) {
-            const float tot = vtot + shfl_xor(vtot, 32);
-            if (lane == 0) a.part_v[(long)blockIdx.x * (BK + 1) + BK] = tot;
+    }
+    // fold the 32 samples (lanes with equal lane >> 5); piece tid + 256 i = (t*4+q)*64 + lane
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x = acc[i][j];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) x += shfl_xor(x, o);
+            acc[i][j] = x;
         }
+    float vt = vs;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) vt += shfl_xor(vt, o);
+    float* out = part + (long)blockIdx.x * 257;
+    if (m == 0) {
+        const int h = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int tq = ((tid + kThreads * i) >> 6);        // t*4 + q
+            const int c = (tq >> 2) * 32 + (tq & 3) * 8 + 4 * h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[c + j] = acc[i][j];
+        }
+        if (tid == 0) out[256] = vt;
     }
 }
 
@@ -194,9 +263,8 @@ __device__ __forceinline__ float sum_partials(const float* __restrict__ p, long 
 
 // out[n * ldo + col0 + k] = sum_g part[g][n][k]   (n < n_out, k < k_out), fixed order over g
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(
-    const float* __restrict__ part_w, const float* __restrict__ part_b, const float* __restrict__ part_v, int G,
-    int BN, int BK, int n_out, int k_out, float* __restrict__ dW, int ldo, int col0, float* __restrict__ db,
-    float* __restrict__ dv, float* __restrict__ dvsum) {
+    const float* __restrict__ part_w, const float* __restrict__ part_b, int G, int BN, int BK, int n_out,
+    int k_out, float* __restrict__ dW, int ldo, int col0, float* __restrict__ db) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long nw = (long)n_out * k_out;
     if (idx < nw) {
@@ -204,32 +272,33 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(
         dW[(long)n * ldo + col0 + k] = sum_partials(part_w + (long)n * BK + k, (long)BN * BK, G);
         return;
     }
-    long j = idx - nw;
-    if (db) {
-        if (j < n_out) {
-            db[j] = sum_partials(part_b + j, BN, G);
-            return;
-        }
-        j -= n_out;
-    }
-    if (dv) {
-        if (j < k_out) {
-            dv[j] = sum_partials(part_v + j, BK + 1, G);
-            return;
-        }
-        j -= k_out;
-        if (j == 0 && dvsum) *dvsum = sum_partials(part_v + BK, BK + 1, G);
-    }
+    const long j = idx - nw;
+    if (db && j < n_out) db[j] = sum_partials(part_b + j, BN, G);
+}
+
+// dv[k] = sum_g part[g][k] (k < 256), *dvsum = sum_g part[g][256]
+__global__ __launch_bounds__(256) void vecmat_reduce_kernel(const float* __restrict__ part, int G,
+                                                            float* __restrict__ dv, float* __restrict__ dvsum) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < 256) dv[k] = sum_partials(part + k, 257, G);
+    else if (k == 256 && dvsum) *dvsum = sum_partials(part + 256, 257, G);
 }
 
 template <int WN, int WK>
 int launch_wgrad(const WgradArgs& a, int G, hipStream_t stream) {
     constexpr int BN = 2 * WN * 32, BK = 2 * WK * 32;
-    const size_t lds = (size_t)2 * (kMS * (BN + BK) + kMS) * sizeof(float);
-    if (a.vec) hipLaunchKernelGGL((wgrad_kernel<WN, WK, true>), dim3(G), dim3(kThreads), lds, stream, a);
-    else hipLaunchKernelGGL((wgrad_kernel<WN, WK, false>), dim3(G), dim3(kThreads), lds, stream, a);
+    const size_t lds = (size_t)2 * kMS * (BN + 4 + BK + 4) * sizeof(float);
+    static bool opted_in = false;           // > 64 KB of dynamic LDS needs the per-kernel opt-in
+    if (!opted_in && lds > 64 * 1024) {
+        SCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<WN, WK>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        opted_in = true;
+    }
+    hipLaunchKernelGGL((wgrad_kernel<WN, WK>), dim3(G), dim3(kThreads), lds, stream, a);
     return scn_launch_status();
 }
+
+
 
 struct Shape { int BN, BK; };
 
@@ -247,31 +316,31 @@ bool pick_shape(int n_load, int k_load, Shape* s) {
 extern "C" long long scnerf_wgrad_workspace_floats(int n_load, int k_load, int n_chunks) {
     Shape s;
     if (!pick_shape(n_load, k_load, &s) || n_chunks < 1) return -1;
-    return (long long)n_chunks * ((long long)s.BN * s.BK + s.BN + s.BK + 1);
+    return (long long)n_chunks * ((long long)s.BN * s.BK + s.BN);
 }
 
-extern "C" int scnerf_wgrad(const float* dz, int lda, int n_load, int n_out, const float* x, int ldb,
-                            int k_load, int k_out, const float* vec, int vec_stride, long long n_samples,
-                            int n_chunks, float* workspace, float* dW, int ldo, int col0, float* db,
-                            float* dv, float* dvsum, void* stream) {
+extern "C" int scnerf_wgrad(const float* dz, int lda, int n_load, int n_out, int dz_tiled, const float* x,
+                            int ldb, int k_load, int k_out, int x_tiled, long long n_samples, int n_chunks,
+                            float* workspace, float* dW, int ldo, int col0, float* db, void* stream) {
     SCN_RETURN_IF(!dz || !x || !workspace || !dW || n_samples < 0 || n_chunks < 1, SCN_EINVAL);
     SCN_RETURN_IF(lda % 4 || ldb % 4 || n_load % 4 || k_load % 4 || n_out > n_load || k_out > k_load, SCN_EINVAL);
     SCN_RETURN_IF(((uintptr_t)dz | (uintptr_t)x) & 15, SCN_EINVAL);
     Shape s;
     SCN_RETURN_IF(!pick_shape(n_load, k_load, &s), SCN_ENOSUP);
+    // a tile-native operand must fill the block tile exactly (its HBM block is the LDS image)
+    SCN_RETURN_IF((dz_tiled && (lda != s.BN || n_load != lda)) || (x_tiled && (ldb != s.BK || k_load != ldb)), SCN_EINVAL);
     WgradArgs a;
-    a.A = dz; a.lda = lda; a.n_load = n_load;
-    a.B = x; a.ldb = ldb; a.k_load = k_load;
-    a.vec = vec; a.vec_stride = vec_stride;
+    a.A = dz; a.lda = lda; a.n_load = n_load; a.a_tiled = dz_tiled;
+    a.B = x; a.ldb = ldb; a.k_load = k_load; a.b_tiled = x_tiled;
     a.P = (long)n_samples;
-    long chunk = (a.P + n_chunks - 1) / n_chunks;
+    a.Ppad = scn::mlp::padded_samples(a.P);
+    long chunk = (a.Ppad + n_chunks - 1) / n_chunks;
     chunk = (chunk + kMS - 1) / kMS * kMS;
     if (chunk == 0) chunk = kMS;
     a.chunk = chunk;
     const int G = n_chunks;
     a.part_w = workspace;
     a.part_b = a.part_w + (long)G * s.BN * s.BK;
-    a.part_v = a.part_b + (long)G * s.BN;
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (s.BN == 256 && s.BK == 256) rc = launch_wgrad<4, 4>(a, G, st);
@@ -280,10 +349,20 @@ extern "C" int scnerf_wgrad(const float* dz, int lda, int n_load, int n_out, con
     else if (s.BN == 128 && s.BK == 64) rc = launch_wgrad<2, 1>(a, G, st);
     else rc = launch_wgrad<1, 2>(a, G, st);
     SCN_RETURN_IF(rc != 0, rc);
-    const long total = (long)n_out * k_out + (db ? n_out : 0) + (dv ? k_out + 1 : 0);
+    const long total = (long)n_out * k_out + (db ? n_out : 0);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(scn_ceil_div(total, 256)), dim3(256), 0, st, a.part_w,
-                       a.part_b, a.part_v, G, s.BN, s.BK, n_out, k_out, dW, ldo, col0, db,
-                       vec ? dv : nullptr, vec ? dvsum : nullptr);
+                       a.part_b, G, s.BN, s.BK, n_out, k_out, dW, ldo, col0, db);
+    return scn_launch_status();
+}
+
+extern "C" int scnerf_vecmat(const float* x_tiled256, const float* vec, int vec_stride, long long n_samples,
+                             int n_chunks, float* workspace, float* dv, float* dvsum, void* stream) {
+    SCN_RETURN_IF(!x_tiled256 || !vec || !workspace || !dv || n_samples < 0 || n_chunks < 1 || vec_stride < 1, SCN_EINVAL);
+    const long n_tiles = scn::mlp::padded_samples((long)n_samples) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(vecmat_kernel, dim3(n_chunks), dim3(kThreads), 0, st, x_tiled256, vec, vec_stride,
+                       (long)n_samples, n_tiles, workspace);
+    hipLaunchKernelGGL(vecmat_reduce_kernel, dim3(2), dim3(256), 0, st, workspace, n_chunks, dv, dvsum);
     return scn_launch_status();
 }
 
@@ -310,8 +389,9 @@ extern "C" int scnerf_nerf_wgrad(const float* save, const float* grads, const fl
     using namespace scn::mlp;
     SCN_RETURN_IF(!save || !grads || !d_raw || !workspace || !flat_grad || n_samples < 1 || n_chunks < 1, SCN_EINVAL);
     const long long P = n_samples;
-    auto S = [&](int sec) { return save + (long long)sec * P; };
-    auto G = [&](int sec) { return grads + (long long)sec * P; };
+    const long long Ppad = scn::mlp::padded_samples(P);
+    auto S = [&](int sec) { return save + (long long)sec * Ppad; };
+    auto G = [&](int sec) { return grads + (long long)sec * Ppad; };
     auto act = [&](int l) { return S(kSaveAct + 256 * l); };
     auto dz = [&](int l) { return G(kGradDz + 256 * l); };
     float* g = flat_grad;
@@ -319,23 +399,26 @@ extern "C" int scnerf_nerf_wgrad(const float* save, const float* grads, const fl
 #define SCN_WG(...)                          \
     rc = scnerf_wgrad(__VA_ARGS__, stream);  \
     if (rc != 0) return rc;
-    // layer 0: X = encoded points (63 valid of 64 columns)
-    SCN_WG(dz(0), 256, 256, 256, S(kSaveEpts), 64, 64, 63, nullptr, 0, P, n_chunks, workspace, g + kW0, 63, 0, g + kB0, nullptr, nullptr)
+    // (dz, lda, n_load, n_out, tiled,  x, ldb, k_load, k_out, tiled,  P, chunks, ws, dW, ldo, col0, db)
+    // layer 0: X = encoded points (row-major, 63 valid of 64 columns)
+    SCN_WG(dz(0), 256, 256, 256, 1, S(kSaveEpts), 64, 64, 63, 0, P, n_chunks, workspace, g + kW0, 63, 0, g + kB0)
     for (int l = 1; l <= 7; ++l) {
         if (l == 5) {
-            SCN_WG(dz(5), 256, 256, 256, S(kSaveEpts), 64, 64, 63, nullptr, 0, P, n_chunks, workspace, g + trunk_w(5), 319, 0, nullptr, nullptr, nullptr)
-            SCN_WG(dz(5), 256, 256, 256, act(4), 256, 256, 256, nullptr, 0, P, n_chunks, workspace, g + trunk_w(5), 319, 63, g + trunk_b(5), nullptr, nullptr)
+            SCN_WG(dz(5), 256, 256, 256, 1, S(kSaveEpts), 64, 64, 63, 0, P, n_chunks, workspace, g + trunk_w(5), 319, 0, nullptr)
+            SCN_WG(dz(5), 256, 256, 256, 1, act(4), 256, 256, 256, 1, P, n_chunks, workspace, g + trunk_w(5), 319, 63, g + trunk_b(5))
         } else {
-            SCN_WG(dz(l), 256, 256, 256, act(l - 1), 256, 256, 256, nullptr, 0, P, n_chunks, workspace, g + trunk_w(l), 256, 0, g + trunk_b(l), nullptr, nullptr)
+            SCN_WG(dz(l), 256, 256, 256, 1, act(l - 1), 256, 256, 256, 1, P, n_chunks, workspace, g + trunk_w(l), 256, 0, g + trunk_b(l))
         }
     }
-    // feature_linear (+ alpha_linear as the rank-1 side product with v = d sigma = d_raw[:, 3])
-    SCN_WG(G(kGradDfeat), 256, 256, 256, act(7), 256, 256, 256, d_raw + 3, 4, P, n_chunks, workspace, g + kWF, 256, 0, g + kBF, g + kWA, g + kBA)
+    // feature_linear; alpha_linear (one output row) = d sigma^T . act7 with d sigma = d_raw[:, 3]
+    SCN_WG(G(kGradDfeat), 256, 256, 256, 1, act(7), 256, 256, 256, 1, P, n_chunks, workspace, g + kWF, 256, 0, g + kBF)
+    rc = scnerf_vecmat(act(7), d_raw + 3, 4, P, n_chunks, workspace, g + kWA, g + kBA, stream);
+    if (rc != 0) return rc;
     // views layer: [feature | encoded direction]
-    SCN_WG(G(kGradDzv), 128, 128, 128, S(kSaveFeat), 256, 256, 256, nullptr, 0, P, n_chunks, workspace, g + kWV, 283, 0, g + kBV, nullptr, nullptr)
-    SCN_WG(G(kGradDzv), 128, 128, 128, S(kSaveEviews), 32, 32, 27, nullptr, 0, P, n_chunks, workspace, g + kWV, 283, 256, nullptr, nullptr, nullptr)
-    // rgb_linear: dZ = d_raw[:, 0:3]
-    SCN_WG(d_raw, 4, 4, 3, S(kSaveHv), 128, 128, 128, nullptr, 0, P, n_chunks, workspace, g + kWRGB, 128, 0, g + kBRGB, nullptr, nullptr)
+    SCN_WG(G(kGradDzv), 128, 128, 128, 1, S(kSaveFeat), 256, 256, 256, 1, P, n_chunks, workspace, g + kWV, 283, 0, g + kBV)
+    SCN_WG(G(kGradDzv), 128, 128, 128, 1, S(kSaveEviews), 32, 32, 27, 0, P, n_chunks, workspace, g + kWV, 283, 256, nullptr)
+    // rgb_linear: dZ = d_raw[:, 0:3] (row-major), X = hidden of the views layer
+    SCN_WG(d_raw, 4, 4, 3, 0, S(kSaveHv), 128, 128, 128, 1, P, n_chunks, workspace, g + kWRGB, 128, 0, g + kBRGB)
 #undef SCN_WG
     return 0;
 }

@@ -282,7 +282,23 @@ def padded_samples(P: int) -> int:
 
 
 def save_floats(P: int) -> int:
-    return SAVE_FLOATS_PER_SAMPLE * P + MASK_WORDS_PER_SAMPLE * padded_samples(P)
+    return (SAVE_FLOATS_PER_SAMPLE + MASK_WORDS_PER_SAMPLE) * padded_samples(P)
+
+
+def grad_floats(P: int) -> int:
+    return GRAD_FLOATS_PER_SAMPLE * padded_samples(P)
+
+
+TILED_SECTIONS = {"feat", "hv", "dfeat", "dzv"} | {"act%d" % l for l in range(D)} | {"dz%d" % l for l in range(D)}
+
+
+def untile(block, width: int, P: int):
+    """tile-native section (flat array of width * padded P floats) -> row-major [P, width]:
+    per 32 samples a block [t][q][lane = m + 32 h][j] holding feature 32 t + 8 q + 4 h + j."""
+    Pp = block.shape[0] // width
+    a = block.reshape(Pp // 32, width // 32, 4, 2, 32, 4)          # tile, t, q, h, m, j
+    a = a.transpose(0, 4, 1, 2, 3, 5).reshape(Pp, width)           # tile, m, t, q, h, j
+    return a[:P]
 
 
 GRAD_SECTIONS = [("dz%d" % l, W) for l in range(D)] + [("dfeat", W), ("dzv", W // 2)]
@@ -290,8 +306,10 @@ GRAD_FLOATS_PER_SAMPLE = sum(w for _, w in GRAD_SECTIONS)      # 2432
 
 
 def section_offsets(sections, P):
+    """offsets (floats) of the workspace sections: every section spans width * padded_samples(P)."""
+    Pp = padded_samples(P)
     off, out = 0, {}
     for name, w in sections:
         out[name] = off
-        off += w * P
+        off += w * Pp
     return out, off

@@ -158,6 +158,10 @@ def check_layout():
     exp = [ML.FWD_STREAM, ML.FWD_BIAS, ML.FWD_BIAS_F, ML.FWD_BIAS_V, ML.FWD_BIAS_RGB, ML.FWD_ALPHA_W,
            ML.FWD_ALPHA_B, ML.FWD_TOTAL, ML.BWD_STREAM, ML.BWD_ALPHA_W, ML.BWD_TOTAL,
            ML.SAVE_FLOATS_PER_SAMPLE, ML.GRAD_FLOATS_PER_SAMPLE]
+    lib = _capi.load()
+    for P in (1, 128, 4097):
+        if lib.scnerf_mlp_save_floats(P) != ML.save_floats(P) or lib.scnerf_mlp_grad_floats(P) != ML.grad_floats(P):
+            raise RuntimeError("workspace size formulas disagree between the kernels and mlp_layout.py")
     if out[:len(exp)].tolist() != exp:
         raise RuntimeError("kernel / mlp_layout.py constants disagree: %s vs %s" % (out[:len(exp)].tolist(), exp))
 
@@ -217,7 +221,7 @@ def mlp_bwd(d_raw: Tensor, pts: Tensor, viewdirs: Tensor, samples_per_ray: int, 
     if wpacked_bwd.numel() != ML.BWD_TOTAL:
         raise ValueError("wpacked_bwd has the wrong size")
     dev = pts.device
-    grads = torch.empty(ML.GRAD_FLOATS_PER_SAMPLE * P, dtype=torch.float32, device=dev)
+    grads = torch.empty(ML.grad_floats(P), dtype=torch.float32, device=dev)
     d_pts = torch.empty((P, 3), dtype=torch.float32, device=dev)
     d_views = torch.empty((P, 3), dtype=torch.float32, device=dev)
     with PROFILE.region("mlp_bwd_kernel/P=%d" % P, 2 * 593408 * P):

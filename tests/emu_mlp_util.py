@@ -30,12 +30,22 @@ def pack_backward(p):
 
 
 def save_views(save, P):
+    """row-major [P, width] views of every section of the activation workspace (+ the bit masks)."""
     off, total = ML.section_offsets(ML.SAVE_SECTIONS, P)
     assert save.shape[0] == ML.save_floats(P)
-    out = {"mask": save[total:].view(np.uint32).reshape(9, ML.padded_samples(P) // 32, 64, 4)}
+    Pp = ML.padded_samples(P)
+    out = {"mask": save[total:].view(np.uint32).reshape(9, Pp // 32, 64, 4)}
     for name, w in ML.SAVE_SECTIONS:
-        out[name] = save[off[name]: off[name] + w * P].reshape(P, w)
+        blk = save[off[name]: off[name] + w * Pp]
+        out[name] = ML.untile(blk, w, P) if name in ML.TILED_SECTIONS else blk.reshape(Pp, w)[:P]
     return out
+
+
+def grad_views(grads, P):
+    off, total = ML.section_offsets(ML.GRAD_SECTIONS, P)
+    assert grads.shape[0] == ML.grad_floats(P)
+    Pp = ML.padded_samples(P)
+    return {name: ML.untile(grads[off[name]: off[name] + w * Pp], w, P) for name, w in ML.GRAD_SECTIONS}
 
 
 def oracle_activations(p, pts, viewdirs_per_sample):

@@ -9,7 +9,7 @@ from oracle import scnerf_oracle as O
 from scnerf_amd import mlp_layout as ML
 from scnerf_amd import synthetic as synth
 from tests.emu import harness as H
-from tests.emu_mlp_util import pack_forward, pack_backward
+from tests.emu_mlp_util import pack_forward, pack_backward, grad_views
 
 pytestmark = pytest.mark.emu
 
@@ -56,15 +56,15 @@ def test_mlp_dgrad_matches_autograd(n_rays, spr):
     raw = np.zeros((P, 4), np.float32)
     save = np.full(ML.save_floats(P), np.nan, np.float32)
     H.call("scnerf_mlp_fwd", pts.numpy(), vd.numpy(), 3, spr, wpk, raw, save, P, None)
-    grads = np.full(ML.GRAD_FLOATS_PER_SAMPLE * P, np.nan, np.float32)
+    grads = np.full(ML.grad_floats(P), np.nan, np.float32)
     d_pts = np.full((P, 3), np.nan, np.float32)
     d_views = np.full((P, 3), np.nan, np.float32)
     H.call("scnerf_mlp_bwd", d_raw.numpy(), pts.numpy(), vd.numpy(), 3, spr, wbk, save, grads, d_pts, d_views, P, None)
     ref = oracle_backward(p, pts, vd, spr, d_raw)
-    off, _ = ML.section_offsets(ML.GRAD_SECTIONS, P)
+    gv = grad_views(grads, P)
 
     def sec(name, w):
-        return grads[off[name]: off[name] + w * P].reshape(P, w)
+        return gv[name]
 
     def close(a, b, what):
         scale = float(np.abs(b).max()) + 1e-12
@@ -94,7 +94,7 @@ def test_full_network_weight_gradients_match_autograd():
     raw = np.zeros((P, 4), np.float32)
     save = np.full(ML.save_floats(P), np.nan, np.float32)
     H.call("scnerf_mlp_fwd", pts.numpy(), vd.numpy(), 3, spr, wpk, raw, save, P, None)
-    grads = np.full(ML.GRAD_FLOATS_PER_SAMPLE * P, np.nan, np.float32)
+    grads = np.full(ML.grad_floats(P), np.nan, np.float32)
     d_pts = np.zeros((P, 3), np.float32)
     d_views = np.zeros((P, 3), np.float32)
     H.call("scnerf_mlp_bwd", d_raw.numpy(), pts.numpy(), vd.numpy(), 3, spr, wbk, save, grads, d_pts, d_views, P, None)

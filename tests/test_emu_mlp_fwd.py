@@ -19,9 +19,10 @@ def test_layout_constants_match_kernel():
            ML.FWD_ALPHA_B, ML.FWD_TOTAL, ML.BWD_STREAM, ML.BWD_ALPHA_W, ML.BWD_TOTAL,
            ML.SAVE_FLOATS_PER_SAMPLE, ML.GRAD_FLOATS_PER_SAMPLE]
     assert out[:len(exp)].tolist() == exp
-    so, _ = ML.section_offsets(ML.SAVE_SECTIONS, 1)
-    go, _ = ML.section_offsets(ML.GRAD_SECTIONS, 1)
-    assert out[13:19].tolist() == [so["feat"], so["hv"], so["epts"], so["eviews"], go["dfeat"], go["dzv"]]
+    so, _ = ML.section_offsets(ML.SAVE_SECTIONS, 128)       # offsets per padded sample
+    go, _ = ML.section_offsets(ML.GRAD_SECTIONS, 128)
+    assert out[13:19].tolist() == [so[k] // 128 for k in ("feat", "hv", "epts", "eviews")] + [go[k] // 128 for k in ("dfeat", "dzv")]
+    assert int(out[19]) == ML.MASK_WORDS_PER_SAMPLE
     assert ML.N_PARAMS == 595844
 
 
@@ -69,7 +70,8 @@ def test_mlp_forward_matches_oracle(n_rays, spr, save):
             np.testing.assert_allclose(s["act%d" % l], oa["acts"][l].numpy(), rtol=2e-5, atol=2e-5)
         np.testing.assert_allclose(s["feat"], oa["feat"].numpy(), rtol=2e-5, atol=2e-5)
         np.testing.assert_allclose(s["hv"], oa["hv"].numpy(), rtol=2e-5, atol=2e-5)
-        # lane-native ReLU bit masks: bit (16 t + r) of lane (m, h) <-> feature feat_of(t, r, h)
+        # lane-native ReLU bit masks: element i = 16 t + r of lane (m, h) <-> feature feat_of(t, r, h),
+        # stored in word i >> 5 at bit 31 - (i & 31)
         for sec, ref, ntile in [(l, s["act%d" % l], 8) for l in range(8)] + [(8, s["hv"], 4)]:
             for p_ in (0, 31, 77, P - 1):
                 wt, m = divmod(p_, 32)
@@ -78,5 +80,5 @@ def test_mlp_forward_matches_oracle(n_rays, spr, save):
                     for t_ in range(ntile):
                         for r in range(16):
                             i = 16 * t_ + r
-                            bit = (int(words[i >> 5]) >> (i & 31)) & 1
+                            bit = (int(words[i >> 5]) >> (31 - (i & 31))) & 1
                             assert bit == int(ref[p_, ML.feat_of(t_, r, hh)] > 0)
