@@ -212,6 +212,17 @@ int scnerf_nerf_wgrad(const float* save, const float* grads, const float* d_raw,
                       long long n_samples, int n_chunks, float* workspace, float* flat_grad,
                       void* stream);
 
+/* ------------------------------------------------------------------ optimizer -------- */
+
+/* One Adam step over a flat fp32 segment (f_custom_adam / torch.optim.Adam without amsgrad,
+ * NeRF/create_nerf.py:199-254): param, exp_avg, exp_avg_sq updated in place from grad; `step` is the
+ * 1-based step count of the segment (bias corrections), weight_decay != 0 adds weight_decay * param
+ * to the gradient first (the reference applies it to the trailing ray-noise / distortion tensors
+ * only, :219-226, :238-239).  All pointers 16-byte aligned. */
+int scnerf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                     long long n, double lr, double beta1, double beta2, double eps,
+                     double weight_decay, long long step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

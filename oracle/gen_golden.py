@@ -338,7 +338,40 @@ def gen_rowsum(ns):
                         capability=np.array(torch.backends.cpu.get_cpu_capability()))
 
 
-ALL = dict(init=gen_init_check, embedder=gen_embedder, mlp=gen_mlp, sample_pdf=gen_sample_pdf,
+def gen_optimizer(ns):
+    """K steps of the reference's CustomAdamOptimizer (weight decay on the trailing ray-noise tensors
+    only, learning rate following run_nerf.py's schedule) and of torch.optim.Adam."""
+    out = {}
+    g = torch.Generator().manual_seed(51)
+    shapes = [(37, 5), (64,), (3, 4, 3), (3, 4, 3)]          # two "network" tensors + ray_o / ray_d grids
+    p0 = [torch.randn(s, generator=g) for s in shapes]
+    grads = [[torch.randn(s, generator=g) * (0.1 + k) for s in shapes] for k in range(4)]
+    args = types.SimpleNamespace(camera_model="pinhole_rot_noise_10k_rayo_rayd")
+    for tag, wd in (("custom_wd", 0.1), ("custom_nowd", 0.0), ("adam", None)):
+        ps = [torch.nn.Parameter(x.clone()) for x in p0]
+        if wd is None:
+            opt = torch.optim.Adam(ps, lr=5e-4, betas=(0.9, 0.999))
+        else:
+            opt = ns.create_nerf.CustomAdamOptimizer(params=ps, lr=5e-4, betas=(0.9, 0.999), weight_decay=wd,
+                                                     H=12, W=16, args=args)
+        for k in range(4):
+            for pp, gg in zip(ps, grads[k]):
+                pp.grad = gg.clone()
+            opt.step()
+            new_lr = 5e-4 * (0.1 ** ((k + 1) / (250 * 1000)))
+            for grp in opt.param_groups:
+                grp["lr"] = new_lr
+            for i, pp in enumerate(ps):
+                out["%s/step%d/p%d" % (tag, k, i)] = np32(pp).copy()      # (np32 aliases the live parameter)
+    for i, x in enumerate(p0):
+        out["p0/%d" % i] = np32(x)
+    for k in range(4):
+        for i, x in enumerate(grads[k]):
+            out["grad%d/%d" % (k, i)] = np32(x)
+    np.savez_compressed(os.path.join(GOLDEN, "optimizer.npz"), **out)
+
+
+ALL = dict(optimizer=gen_optimizer, init=gen_init_check, embedder=gen_embedder, mlp=gen_mlp, sample_pdf=gen_sample_pdf,
            composite=gen_composite, render_rays=gen_render_rays, camera=gen_camera,
            rowsum=gen_rowsum)
 

@@ -354,3 +354,30 @@ def pinhole_rays(H, W, focal, c2w: Tensor, kps: Tensor):
     rays_d = torch.sum(dirs[:, None, :] * c2w[:3, :3], dim=-1)
     rays_o = c2w[:3, -1].expand(rays_d.shape)
     return rays_o, rays_d
+
+
+# --------------------------------------------------------------------- optimizer
+def adam_step(params, grads, exp_avgs, exp_avg_sqs, steps, lr, beta1=0.9, beta2=0.999, eps=1e-8,
+              weight_decay=0.0, decay_idx_from=None):
+    """One step of the reference's f_custom_adam (NeRF/create_nerf.py:199-254), amsgrad off: lists of
+    tensors updated in place; `steps[i]` is the (already incremented) step count of tensor i; weight
+    decay is added to the gradient of tensors with index >= decay_idx_from only (:219-226, :238-239).
+    With decay_idx_from = len(params) this is torch.optim.Adam."""
+    import math
+    if decay_idx_from is None:
+        decay_idx_from = len(params)
+    for i, p in enumerate(params):
+        g = grads[i]
+        bc1 = 1 - beta1 ** steps[i]
+        bc2 = 1 - beta2 ** steps[i]
+        if weight_decay != 0 and i >= decay_idx_from:
+            g = g.add(p, alpha=weight_decay)
+        exp_avgs[i].mul_(beta1).add_(g, alpha=1 - beta1)
+        exp_avg_sqs[i].mul_(beta2).addcmul_(g, g, value=1 - beta2)
+        denom = (exp_avg_sqs[i].sqrt() / math.sqrt(bc2)).add_(eps)
+        p.addcdiv_(exp_avgs[i], denom, value=-(lr / bc1))
+
+
+def lr_schedule(lrate, lrate_decay, global_step):
+    """run_nerf.py:617-621: lrate * 0.1 ** (global_step / (lrate_decay * 1000))."""
+    return lrate * (0.1 ** (global_step / (lrate_decay * 1000)))

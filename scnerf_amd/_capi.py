@@ -6,7 +6,9 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_int, c_int64, c_longlong, c_void_p, c_float
+from ctypes import c_int, c_int64, c_longlong, c_void_p, c_float, c_double
+
+D = c_double
 
 F = c_float
 
@@ -31,6 +33,7 @@ PROTOTYPES = {
     "scnerf_ndc_bwd": [I, I, P, F, P, P, P, P, P, P, P, I, P],
     "scnerf_upsample_grid_fwd": [P, F, I, I, I, I, P, P],
     "scnerf_upsample_grid_bwd": [P, F, I, I, I, I, P, P],
+    "scnerf_adam_step": [P, P, P, P, LL, D, D, D, D, D, LL, P],
     "scnerf_composite_fwd": [P, P, P, I, P, I, P, P, P, P, P, I, I, P],
     "scnerf_composite_bwd": [P, P, P, I, P, I, P, P, P, P, P, P, P, I, I, P],
     "scnerf_ray_reduce": [P, P, P, P, P, I, I, I, I, P],

@@ -144,6 +144,16 @@ def create_nerf(args, noisy_focal, noisy_poses, H, W, mode="train", device="cuda
                 intrinsics=intrinsic_init, extrinsics=noisy_poses, args=args, H=H, W=W).to(device)
         grad_vars += list(camera_model.parameters())
 
-    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    # one contiguous buffer per network *before* the optimizer looks at the tensors, so that each
+    # network becomes a single fused-Adam segment
+    _unwrap(model).flat_parameters()
+    if model_fine is not None:
+        _unwrap(model_fine).flat_parameters()
+    from .optim import CustomAdamOptimizer, FusedAdam
+    if getattr(args, "use_custom_optim", False):
+        optimizer = CustomAdamOptimizer(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999),
+                                        weight_decay=args.non_linear_weight_decay, H=H, W=W, args=args)
+    else:
+        optimizer = FusedAdam(grad_vars, lr=args.lrate, betas=(0.9, 0.999))
     start = 0
     return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer, camera_model
