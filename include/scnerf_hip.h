@@ -212,6 +212,29 @@ int scnerf_nerf_wgrad(const float* save, const float* grads, const float* d_raw,
                       long long n_samples, int n_chunks, float* workspace, float* flat_grad,
                       void* stream);
 
+/* ------------------------------------------------------------------ PRD loss --------- */
+
+/* Projected-ray-distance loss, proj_ray_dist_loss_single (model/ray_dist_loss.py:22-246) after its
+ * argument plumbing: kps0/kps1 [m,2] matched key points, rays*_o / rays*_d [m,3] their rays, K [4,4]
+ * the intrinsic matrix (negate_fx != 0 flips K[0][0] as the reference does for method "NeRF",
+ * :102-105), E2 [2,4,4] the two camera-to-world poses.  Train mode (eval_mode = 0): 0.5 * (mean of the
+ * valid image-0 errors + mean of the valid image-1 errors), valid = chirality (t0, t1 > 0) and error
+ * < threshold and finite (:213-229); *n_match = matches valid both ways.  Eval mode: invalid errors
+ * are replaced by the threshold and averaged over the chirality-valid matches (:231-246).
+ * sums6: 6-float scratch kept for the backward.  loss / n_match: device scalars. */
+int scnerf_prd_loss_fwd(const float* kps0, const float* kps1, const float* rays0_o, const float* rays0_d,
+                        const float* rays1_o, const float* rays1_d, const float* K, const float* E2,
+                        float eps, float threshold, int negate_fx, int eval_mode, int m, float* sums6,
+                        float* loss, float* n_match, void* stream);
+
+/* Gradient of the train-mode loss w.r.t. the four ray tensors, K (w.r.t. the matrix as passed) and
+ * E2; g_loss is a device scalar; workspace36: 36 floats. */
+int scnerf_prd_loss_bwd(const float* kps0, const float* kps1, const float* rays0_o, const float* rays0_d,
+                        const float* rays1_o, const float* rays1_d, const float* K, const float* E2,
+                        float eps, float threshold, int negate_fx, int m, const float* sums6,
+                        const float* g_loss, float* g_rays0_o, float* g_rays0_d, float* g_rays1_o,
+                        float* g_rays1_d, float* g_K, float* g_E2, float* workspace36, void* stream);
+
 /* ------------------------------------------------------------------ optimizer -------- */
 
 /* One Adam step over a flat fp32 segment (f_custom_adam / torch.optim.Adam without amsgrad,

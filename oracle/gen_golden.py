@@ -329,6 +329,82 @@ def gen_camera(ns):
     np.savez_compressed(os.path.join(GOLDEN, "camera.npz"), **out)
 
 
+def _ref_camera(ns, H, W, n_cams=5, mult=True):
+    spec = synth.camera_spec(H, W, n_cams=n_cams, seed=4, multiplicative=mult)
+    args = types.SimpleNamespace(
+        camera_model="pinhole_rot_noise_10k_rayo_rayd", grid_size=10,
+        ray_o_noise_scale=spec["ray_o_noise_scale"], ray_d_noise_scale=spec["ray_d_noise_scale"],
+        extrinsics_noise_scale=spec["extrinsics_noise_scale"],
+        intrinsics_noise_scale=spec["intrinsics_noise_scale"], multiplicative_noise=mult,
+        distortion_noise_scale=1e-2)
+    cm = ns.camera_model.PinholeModelRotNoiseLearning10kRayoRayd(
+        spec["K_init"], list(spec["poses"].numpy()), args, H, W)
+    with torch.no_grad():
+        cm.intrinsics_noise.copy_(spec["intrinsics_noise"])
+        cm.extrinsics_noise.copy_(spec["extrinsics_noise"])
+        cm.ray_o_noise.copy_(spec["ray_o_noise"])
+        cm.ray_d_noise.copy_(spec["ray_d_noise"])
+    return cm
+
+
+def gen_prd(ns):
+    """proj_ray_dist_loss_single (model/ray_dist_loss.py:22) on synthetic matches of two cameras of the
+    synthetic rig: (leaf) every float input a leaf tensor -> loss, n_match and all input gradients;
+    (camera) the run_nerf.py:536-587 call chain through the camera model -> parameter gradients;
+    (eval) mode "val"."""
+    out = {}
+    H, W = 378, 504
+    cm = _ref_camera(ns, H, W)
+    prd = ns.ray_dist_loss.proj_ray_dist_loss_single
+    i0, i1 = 1, 3
+    with torch.no_grad():
+        K = cm.get_intrinsic().clone()
+        E = cm.get_extrinsic().clone()
+    k0, k1 = synth.matched_keypoints(H, W, K, E[i0], E[i1], 300, seed=8)
+    args = types.SimpleNamespace(proj_ray_dist_threshold=5.0)
+    for tag, thr in (("leaf", 5.0), ("leaf_tight", 1.0)):
+        args.proj_ray_dist_threshold = thr
+        with torch.no_grad():
+            r0 = ns.get_rays.get_rays_kps_use_camera(H, W, cm, k0, idx_in_camera_param=i0)
+            r1 = ns.get_rays.get_rays_kps_use_camera(H, W, cm, k1, idx_in_camera_param=i1)
+        leaves = [t.clone().requires_grad_(True) for t in (r0[0], r0[1], r1[0], r1[1], K, E)]
+        loss, nm = prd(k0, k1, i0, i1, (leaves[0], leaves[1]), (leaves[2], leaves[3]), "train", "cpu", H, W, args,
+                       intrinsic=leaves[4], extrinsic=leaves[5], method="NeRF")
+        loss.backward()
+        k = tag + "/"
+        out.update({k + "kps0": np32(k0), k + "kps1": np32(k1), k + "idx": np.array([i0, i1]),
+                    k + "threshold": np.array(thr, np.float32), k + "loss": np32(loss), k + "n_match": np.array(nm),
+                    k + "rays0_o": np32(leaves[0]), k + "rays0_d": np32(leaves[1]), k + "rays1_o": np32(leaves[2]),
+                    k + "rays1_d": np32(leaves[3]), k + "K": np32(leaves[4]), k + "E": np32(leaves[5]),
+                    k + "g_rays0_o": np32(leaves[0].grad), k + "g_rays0_d": np32(leaves[1].grad),
+                    k + "g_rays1_o": np32(leaves[2].grad), k + "g_rays1_d": np32(leaves[3].grad),
+                    k + "g_K": np32(leaves[4].grad), k + "g_E": np32(leaves[5].grad)})
+    # through the camera model, as the training loop calls it (i_map = i_train maps image id -> camera slot)
+    args.proj_ray_dist_threshold = 5.0
+    i_map = np.array([10, 11, 12, 13, 14])
+    r0 = ns.get_rays.get_rays_kps_use_camera(H, W, cm, k0, idx_in_camera_param=i0)
+    r1 = ns.get_rays.get_rays_kps_use_camera(H, W, cm, k1, idx_in_camera_param=i1)
+    loss, nm = prd(k0, k1, int(i_map[i0]), int(i_map[i1]), r0, r1, "train", "cpu", H, W, args,
+                   camera_model=cm, method="NeRF", i_map=i_map)
+    loss.backward()
+    out.update({"camera/loss": np32(loss), "camera/n_match": np.array(nm), "camera/i_map": i_map,
+                "camera/g_intrinsics_noise": np32(cm.intrinsics_noise.grad),
+                "camera/g_extrinsics_noise": np32(cm.extrinsics_noise.grad),
+                "camera/g_ray_o_noise": np32(cm.ray_o_noise.grad),
+                "camera/g_ray_d_noise": np32(cm.ray_d_noise.grad)})
+    # eval mode (no gradient): the reference indexes extrinsic[[[i0, i1]]] (:86,94)
+    try:
+        with torch.no_grad():
+            r0 = ns.get_rays.get_rays_kps_use_camera(H, W, cm, k0, idx_in_camera_param=i0)
+            r1 = ns.get_rays.get_rays_kps_use_camera(H, W, cm, k1, idx_in_camera_param=i1)
+            loss_e, _ = prd(k0, k1, i0, i1, r0, r1, "val", "cpu", H, W, args, intrinsic=K, extrinsic=E, method="NeRF")
+        out["eval/loss"] = np32(loss_e)
+    except Exception as exc:                     # recorded so the tests know the pin is absent
+        print("  eval mode of the reference failed here:", type(exc).__name__, exc)
+        out["eval/unavailable"] = np.array(1)
+    np.savez_compressed(os.path.join(GOLDEN, "prd.npz"), **out)
+
+
 def gen_rowsum(ns):
     """Pins the explicit ATen-AVX512 row-sum restatement against torch.sum here."""
     g = torch.Generator().manual_seed(41)
@@ -373,7 +449,7 @@ def gen_optimizer(ns):
 
 ALL = dict(optimizer=gen_optimizer, init=gen_init_check, embedder=gen_embedder, mlp=gen_mlp, sample_pdf=gen_sample_pdf,
            composite=gen_composite, render_rays=gen_render_rays, camera=gen_camera,
-           rowsum=gen_rowsum)
+           rowsum=gen_rowsum, prd=gen_prd)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -28,7 +28,8 @@ _cache = {}
 
 def load_reference():
     """Returns a namespace with the reference modules:
-    .render, .helpers, .create_nerf, .get_rays, .camera_model, .camera_utils"""
+    .render, .helpers, .create_nerf, .get_rays, .camera_model, .camera_utils,
+    .ray_dist_loss"""
     if "ns" in _cache:
         return _cache["ns"]
     if not reference_available():
@@ -58,11 +59,12 @@ def load_reference():
         import camera_model as camera_model_mod  # model/camera_model.py
         import create_nerf as create_nerf_mod    # NeRF/create_nerf.py
         from model import camera_utils as camera_utils_mod
+        from model import ray_dist_loss as ray_dist_loss_mod   # model/ray_dist_loss.py
     finally:
         sys.path[:] = saved_path
     ns = types.SimpleNamespace(
         render=render_mod, helpers=helpers, create_nerf=create_nerf_mod,
         get_rays=get_rays_mod, camera_model=camera_model_mod,
-        camera_utils=camera_utils_mod)
+        camera_utils=camera_utils_mod, ray_dist_loss=ray_dist_loss_mod)
     _cache["ns"] = ns
     return ns

@@ -381,3 +381,51 @@ def adam_step(params, grads, exp_avgs, exp_avg_sqs, steps, lr, beta1=0.9, beta2=
 def lr_schedule(lrate, lrate_decay, global_step):
     """run_nerf.py:617-621: lrate * 0.1 ** (global_step / (lrate_decay * 1000))."""
     return lrate * (0.1 ** (global_step / (lrate_decay * 1000)))
+
+
+# ----------------------------------------------------------------------------- PRD loss
+
+def prd_loss(kps0, kps1, rays0_o, rays0_d, rays1_o, rays1_d, K, E2, threshold, eps=1e-10, negate_fx=True,
+             eval_mode=False):
+    """Projected-ray-distance loss of one image pair (model/ray_dist_loss.py:97-246), written per
+    match instead of with batched einsums: the mutually closest points p0 / p1 of the two rays
+    (:127-158), each re-projected into the other camera through E^-1 = [R^T | -R^T t] (:107-111,168-169)
+    and K with K[0][0] negated for NeRF's axes (:102-105,170-176), squared pixel error against the
+    matched key point (:203-208).  Train (:211-229): mean over {chirality t0,t1>0 and error < threshold
+    and finite}, separately per direction, halved sum; also returns the count valid in both.
+    Eval (:231-246): errors above the threshold / non-finite are set to it, mean over the
+    chirality-valid.  Differentiable in every float argument (torch autograd)."""
+    def unit(v):
+        return v / (v.norm(p=2, dim=-1, keepdim=True) + eps)
+    d0, d1 = unit(rays0_d), unit(rays1_d)
+    w = rays0_o - rays1_o
+    r = (d0 * d1).sum(-1)
+    den = r ** 2 - 1 + eps
+    t0 = ((d0 * w).sum(-1) - r * (d1 * w).sum(-1)) / den
+    t1 = ((d1 * -w).sum(-1) - r * (d0 * -w).sum(-1)) / den
+    p0 = t0[:, None] * d0 + rays0_o
+    p1 = t1[:, None] * d1 + rays1_o
+    Kk = K.clone()
+    if negate_fx:
+        Kk[0, 0] = -Kk[0, 0]
+
+    def reproject(p, E):
+        R, t = E[:3, :3], E[:3, 3]
+        Rt = R.transpose(0, 1)
+        q = p @ Rt.transpose(0, 1) + (-(Rt @ t))[None]         # R^T p - R^T t
+        q4 = torch.cat([q, torch.ones_like(q[:, :1])], -1)
+        n = q4 @ Kk.transpose(0, 1)
+        return n[:, :2] / (n[:, 2:3] + eps)
+    u01 = reproject(p0, E2[1])
+    u10 = reproject(p1, E2[0])
+    chir = (t0 > 0) & (t1 > 0)
+    l0 = ((u10 - kps0) ** 2).sum(-1)[chir]
+    l1 = ((u01 - kps1) ** 2).sum(-1)[chir]
+    if not eval_mode:
+        ok0 = (l0 < threshold) & torch.isfinite(l0)
+        ok1 = (l1 < threshold) & torch.isfinite(l1)
+        return 0.5 * (l0[ok0].mean() + l1[ok1].mean()), float((ok0 & ok1).sum())
+    thr = torch.full_like(l0, threshold)
+    l0 = torch.where((l0 > threshold) | ~torch.isfinite(l0), thr, l0)
+    l1 = torch.where((l1 > threshold) | ~torch.isfinite(l1), thr, l1)
+    return 0.5 * (l0.mean() + l1.mean()), None

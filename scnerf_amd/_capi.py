@@ -33,6 +33,8 @@ PROTOTYPES = {
     "scnerf_ndc_bwd": [I, I, P, F, P, P, P, P, P, P, P, I, P],
     "scnerf_upsample_grid_fwd": [P, F, I, I, I, I, P, P],
     "scnerf_upsample_grid_bwd": [P, F, I, I, I, I, P, P],
+    "scnerf_prd_loss_fwd": [P, P, P, P, P, P, P, P, F, F, I, I, I, P, P, P, P],
+    "scnerf_prd_loss_bwd": [P, P, P, P, P, P, P, P, F, F, I, I, P, P, P, P, P, P, P, P, P, P],
     "scnerf_adam_step": [P, P, P, P, LL, D, D, D, D, D, LL, P],
     "scnerf_composite_fwd": [P, P, P, I, P, I, P, P, P, P, P, I, I, P],
     "scnerf_composite_bwd": [P, P, P, I, P, I, P, P, P, P, P, P, P, I, I, P],

@@ -1,7 +1,8 @@
 """Makes the reference's own module names resolve to this package, so that an unmodified
 `NeRF/run_nerf.py` (`from render import render, render_path`, `from get_rays import ...`,
 `from run_nerf_helpers import ...`, `from create_nerf import create_nerf`,
-`from model.camera_model import *`: /root/reference NeRF/run_nerf.py:13-58) runs on the HIP path.
+`from model.camera_model import *`, `from model.ray_dist_loss import ...`:
+/root/reference NeRF/run_nerf.py:13-62) runs on the HIP path.
 
     import scnerf_amd.dropin; scnerf_amd.dropin.install()     # before run_nerf.py's imports
 """
@@ -18,6 +19,7 @@ _MAP = {
     "camera_model": "scnerf_amd.camera_model",
     "model.camera_model": "scnerf_amd.camera_model",
     "model.camera_utils": "scnerf_amd.camera_utils",
+    "model.ray_dist_loss": "scnerf_amd.ray_dist_loss",
 }
 
 
@@ -30,4 +32,5 @@ def install():
         sys.modules["model"] = pkg
     sys.modules["model"].camera_model = sys.modules["model.camera_model"]
     sys.modules["model"].camera_utils = sys.modules["model.camera_utils"]
+    sys.modules["model"].ray_dist_loss = sys.modules["model.ray_dist_loss"]
     return sorted(_MAP)

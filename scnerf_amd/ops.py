@@ -391,3 +391,38 @@ def upsample_grid_bwd(g_out: Tensor, scale: float, gh: int, gw: int, H: int, W: 
     st = _capi.load().scnerf_upsample_grid_bwd(_p(g_out), ctypes.c_float(float(scale)), gh, gw, H, W, _p(d), _stream())
     _capi.check(st, "scnerf_upsample_grid_bwd")
     return d
+
+
+def prd_loss_fwd(kps0, kps1, r0o, r0d, r1o, r1d, K, E2, eps: float, threshold: float, negate_fx: bool,
+                 eval_mode: bool):
+    """-> (loss [] , n_match [], sums [6]) device tensors; no host sync."""
+    import ctypes
+    for name, t in (("kps0", kps0), ("kps1", kps1), ("rays0_o", r0o), ("rays0_d", r0d), ("rays1_o", r1o),
+                    ("rays1_d", r1d), ("K", K), ("E2", E2)):
+        _f(t, name)
+    m = kps0.shape[0]
+    out = torch.empty(8, dtype=torch.float32, device=kps0.device)
+    st = _capi.load().scnerf_prd_loss_fwd(_p(kps0), _p(kps1), _p(r0o), _p(r0d), _p(r1o), _p(r1d), _p(K), _p(E2),
+                                          ctypes.c_float(eps), ctypes.c_float(threshold), int(negate_fx),
+                                          int(eval_mode), m, _p(out), out[6:].data_ptr(), out[7:].data_ptr(),
+                                          _stream())
+    _capi.check(st, "scnerf_prd_loss_fwd")
+    return out[6], out[7], out[:6]
+
+
+def prd_loss_bwd(kps0, kps1, r0o, r0d, r1o, r1d, K, E2, eps: float, threshold: float, negate_fx: bool, sums,
+                 g_loss: Tensor):
+    """-> (g_rays0_o, g_rays0_d, g_rays1_o, g_rays1_d, g_K [4,4], g_E2 [2,4,4])"""
+    import ctypes
+    m = kps0.shape[0]
+    dev = kps0.device
+    g = torch.empty((4, m, 3), dtype=torch.float32, device=dev)
+    small = torch.empty(16 + 32 + 36, dtype=torch.float32, device=dev)
+    g_loss = _f(g_loss.reshape(1).contiguous(), "g_loss")
+    st = _capi.load().scnerf_prd_loss_bwd(_p(kps0), _p(kps1), _p(r0o), _p(r0d), _p(r1o), _p(r1d), _p(K), _p(E2),
+                                          ctypes.c_float(eps), ctypes.c_float(threshold), int(negate_fx), m,
+                                          _p(sums), _p(g_loss), g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(),
+                                          g[3].data_ptr(), small.data_ptr(), small[16:].data_ptr(),
+                                          small[48:].data_ptr(), _stream())
+    _capi.check(st, "scnerf_prd_loss_bwd")
+    return g[0], g[1], g[2], g[3], small[:16].view(4, 4), small[16:48].view(2, 4, 4)

@@ -131,3 +131,34 @@ def keypoints(H: int, W: int, n: int, n_cams: int, seed=6, integer=False):
         kps = kps.floor()
     idx = torch.randint(0, n_cams, (n,), generator=g)
     return kps, idx
+
+
+def matched_keypoints(H: int, W: int, K, E0, E1, n: int, seed=8, noise_px=0.7, outlier_frac=0.25):
+    """n matched key-point pairs for the cameras E0 / E1 (camera-to-world, NeRF axes: x right, y up,
+    camera looks down -z; pixel = (fx X/-Z + cx, -fy Y/-Z + cy) as get_rays_kps_* implies): 3-D points
+    in front of both cameras projected into each view + Gaussian pixel noise; `outlier_frac` of the
+    pairs get an unrelated second key point (large error / negative depth cases)."""
+    g = torch.Generator().manual_seed(seed)
+    fx, fy, cx, cy = float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])
+
+    def project(E, X):
+        Xc = (X - E[:3, 3]) @ E[:3, :3]
+        return torch.stack([fx * Xc[:, 0] / -Xc[:, 2] + cx, -fy * Xc[:, 1] / -Xc[:, 2] + cy], -1), -Xc[:, 2]
+    pts, k0, k1 = [], [], []
+    kept = 0
+    while kept < n:
+        X = torch.cat([torch.randn(4 * n, 2, generator=g) * 1.2, -3.0 - 2.0 * torch.rand(4 * n, 1, generator=g)], -1)
+        a, za = project(E0, X)
+        b, zb = project(E1, X)
+        ok = (za > 0.5) & (zb > 0.5) & (a[:, 0] > 0) & (a[:, 0] < W - 1) & (a[:, 1] > 0) & (a[:, 1] < H - 1) \
+            & (b[:, 0] > 0) & (b[:, 0] < W - 1) & (b[:, 1] > 0) & (b[:, 1] < H - 1)
+        k0.append(a[ok]); k1.append(b[ok])
+        kept += int(ok.sum())
+    k0 = torch.cat(k0)[:n] + torch.randn(n, 2, generator=g) * noise_px
+    k1 = torch.cat(k1)[:n] + torch.randn(n, 2, generator=g) * noise_px
+    n_out = int(n * outlier_frac)
+    k1[:n_out, 0] = torch.rand(n_out, generator=g) * (W - 1)
+    k1[:n_out, 1] = torch.rand(n_out, generator=g) * (H - 1)
+    k0[:, 0].clamp_(0, W - 1); k1[:, 0].clamp_(0, W - 1)
+    k0[:, 1].clamp_(0, H - 1); k1[:, 1].clamp_(0, H - 1)
+    return k0.contiguous(), k1.contiguous()
