@@ -64,3 +64,49 @@ def shard_rays(n_total: int, rank: int, world_size: int):
     base, rem = divmod(n_total, world_size)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def render_path_sharded(render_poses, hwf, chunk, render_kwargs, mode, rank: int, world_size: int,
+                        process_group=None, render_fn=None, device=None, **path_kwargs):
+    """Multi-GPU `render_path` (reference NeRF/render.py:143-183): every rank renders a contiguous band
+    of each image's rays ([lo, hi) of the H*W row-major pixels, `shard_rays`), the bands are exchanged
+    with ONE all-gather per image (RCCL; rgb+disp packed as 4 floats per pixel, equal-size padded
+    shards), and every rank returns the full (rgbs [n,H,W,3], disps [n,H,W]) numpy arrays -- identical
+    to the single-GPU result, since rays are independent and evaluation draws no random numbers.
+    `path_kwargs`: camera_model, noisy_extrinsic, gt_intrinsic, gt_extrinsic, i_map, transform_align.
+    `render_fn` defaults to scnerf_amd.render.render (injectable for the CPU gloo test)."""
+    import numpy as np
+    import torch.distributed as dist
+    if render_fn is None:
+        from .render import render as render_fn
+    from .render import _image_kwargs
+    H, W, _ = hwf
+    n_pix = H * W
+    lo, hi = shard_rays(n_pix, rank, world_size)
+    width = -(-n_pix // world_size)                      # padded shard length
+    rgbs, disps = [], []
+    for i, _pose in enumerate(render_poses):
+        kw = _image_kwargs(i, hwf, chunk, render_kwargs, mode, path_kwargs.get("camera_model"),
+                           path_kwargs.get("noisy_extrinsic"), path_kwargs.get("gt_intrinsic"),
+                           path_kwargs.get("gt_extrinsic"), path_kwargs.get("i_map"),
+                           path_kwargs.get("transform_align"))
+        with torch.no_grad():
+            rgb, disp, _acc, _ = render_fn(_ray_range=(lo, hi), **kw)
+        dev = rgb.device if device is None else device
+        mine = torch.zeros((width, 4), dtype=torch.float32, device=dev)
+        mine[:hi - lo, :3] = rgb.reshape(-1, 3)
+        mine[:hi - lo, 3] = disp.reshape(-1)
+        if world_size > 1:
+            full = torch.empty((world_size, width, 4), dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(full.view(-1), mine.view(-1), group=process_group)
+            parts = []
+            for r in range(world_size):
+                a, b = shard_rays(n_pix, r, world_size)
+                parts.append(full[r, :b - a])
+            img = torch.cat(parts, 0)
+        else:
+            img = mine[:n_pix]
+        img = img.cpu().numpy()
+        rgbs.append(img[:, :3].reshape(H, W, 3).copy())
+        disps.append(img[:, 3].reshape(H, W).copy())
+    return np.stack(rgbs, 0), np.stack(disps, 0)

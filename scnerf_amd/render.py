@@ -154,9 +154,10 @@ def sample_pdf(bins, weights, N_samples, det=False, pytest=False, _u=None):
 
 def render(H, W, chunk, rays=None, noisy_focal=None, noisy_extrinsic=None, ndc=True, near=0., far=1.,
            use_viewdirs=False, mode=None, camera_model=None, image_idx=None, i_map=None, gt_intrinsic=None,
-           gt_extrinsic=None, transform_align=None, **kwargs):
+           gt_extrinsic=None, transform_align=None, _ray_range=None, **kwargs):
     """Same ray-source selection, view-direction / NDC handling and return structure as the
-    reference (:18-141)."""
+    reference (:18-141).  `_ray_range=(lo, hi)` (not in the reference; used by the multi-GPU image
+    renderer) renders only the flattened rays [lo, hi): outputs come back as [hi-lo, ...]."""
     assert not mode is None
     if not rays is None:
         if camera_model is None:
@@ -207,6 +208,9 @@ def render(H, W, chunk, rays=None, noisy_focal=None, noisy_extrinsic=None, ndc=T
     if use_viewdirs:
         rays = torch.cat([rays, viewdirs], -1)
 
+    if _ray_range is not None:
+        rays = rays[_ray_range[0]:_ray_range[1]]
+        sh = (rays.shape[0], 3)
     all_ret = batchify_rays(rays, chunk, **kwargs)
     for k in all_ret:
         k_sh = list(sh[:-1]) + list(all_ret[k].shape[1:])
@@ -217,29 +221,79 @@ def render(H, W, chunk, rays=None, noisy_focal=None, noisy_extrinsic=None, ndc=T
     return ret_list + [ret_dict]
 
 
+class _HostRing:
+    """Pinned host staging for finished images: the device->host copy of image i runs on a side
+    stream while image i+1 renders; nothing blocks the host until the pixels are needed."""
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.pending = []
+
+    def push(self, *tensors):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.stream.wait_event(ev)
+        hosts = []
+        with torch.cuda.stream(self.stream):
+            for t in tensors:
+                h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                h.copy_(t, non_blocking=True)
+                t.record_stream(self.stream)
+                hosts.append(h)
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        self.pending.append((done, hosts))
+        return len(self.pending) - 1
+
+    def get(self, i):
+        done, hosts = self.pending[i]
+        done.synchronize()
+        return [h.numpy() for h in hosts]
+
+
+def _image_kwargs(i, hwf, chunk, render_kwargs, mode, camera_model, noisy_extrinsic, gt_intrinsic, gt_extrinsic,
+                  i_map, transform_align):
+    H, W, noisy_focal = hwf
+    return dict(H=H, W=W, noisy_focal=noisy_focal, chunk=chunk, noisy_extrinsic=noisy_extrinsic,
+                gt_intrinsic=gt_intrinsic, gt_extrinsic=gt_extrinsic, mode=mode, camera_model=camera_model,
+                image_idx=i_map[i] if not i_map is None else i, i_map=i_map,
+                transform_align=transform_align[i] if transform_align is not None else None, **render_kwargs)
+
+
 def render_path(render_poses, hwf, chunk, render_kwargs, mode, gt_imgs=None, args=None, savedir=None,
                 camera_model=None, noisy_extrinsic=None, gt_intrinsic=None, gt_extrinsic=None, i_map=None,
                 transform_align=None):
-    """Full-image rendering loop of the reference (:143-183); PNGs are written only when imageio is
-    importable."""
-    H, W, noisy_focal = hwf
+    """Full-image rendering loop of the reference (:143-183): one image per entry of `render_poses`,
+    returns (rgbs [n,H,W,3], disps [n,H,W]) as numpy; PNGs are written when `savedir` is given.
+    Forward only (no activation workspaces); finished images leave the GPU through pinned buffers on a
+    copy stream, so rendering image i+1 overlaps the transfer (and PNG encoding) of image i."""
+    H, W, _ = hwf
+    ring = None
     rgbs, disps = [], []
     try:
         import tqdm
         it = tqdm.tqdm(render_poses)
     except Exception:
         it = render_poses
-    for i, extrinsic in enumerate(it):
-        image_idx = i_map[i] if not i_map is None else i
-        with torch.no_grad():
-            rgb, disp, acc, _ = render(
-                H=H, W=W, noisy_focal=noisy_focal, chunk=chunk, noisy_extrinsic=noisy_extrinsic,
-                gt_intrinsic=gt_intrinsic, gt_extrinsic=gt_extrinsic, mode=mode, camera_model=camera_model,
-                image_idx=image_idx, i_map=i_map,
-                transform_align=transform_align[i] if transform_align is not None else None, **render_kwargs)
-        rgbs.append(rgb.reshape((H, W, 3)).cpu().numpy())
-        disps.append(disp.reshape((H, W)).cpu().numpy())
+
+    def collect(j):
+        rgb, disp = ring.get(j)
+        rgbs.append(rgb)
+        disps.append(disp)
         if savedir is not None:
             import imageio
-            imageio.imwrite(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs[-1]))
+            imageio.imwrite(os.path.join(savedir, '{:03d}.png'.format(j)), to8b(rgb))
+
+    for i, _extrinsic in enumerate(it):
+        with torch.no_grad():
+            rgb, disp, _acc, _ = render(**_image_kwargs(i, hwf, chunk, render_kwargs, mode, camera_model,
+                                                        noisy_extrinsic, gt_intrinsic, gt_extrinsic, i_map,
+                                                        transform_align))
+        if ring is None:
+            ring = _HostRing(rgb.device)
+        ring.push(rgb.reshape((H, W, 3)), disp.reshape((H, W)))
+        if i > 0:
+            collect(i - 1)                       # image i is rendering / copying meanwhile
+    if ring is not None:
+        collect(len(ring.pending) - 1)
     return np.stack(rgbs, 0), np.stack(disps, 0)

@@ -74,3 +74,36 @@ def test_shard_rays_partitions_exactly():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _fake_render(H, W, chunk, _ray_range=None, image_idx=None, **_kw):
+    """Stands in for scnerf_amd.render.render on CPU: a deterministic per-pixel 'image'."""
+    lo, hi = _ray_range
+    pix = torch.arange(lo, hi, dtype=torch.float32)
+    rgb = torch.stack([pix, pix * 0.5 + image_idx, -pix], -1)
+    return [rgb, pix + 100.0 * image_idx, torch.ones_like(pix), {}]
+
+
+def _render_worker(rank, world, port, out_dir):
+    from scnerf_amd.parallel import render_path_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rgbs, disps = render_path_sharded([None] * 3, (5, 7, None), 16, {}, "test", rank, world, render_fn=_fake_render,
+                                      gt_extrinsic=torch.zeros(3, 4, 4))
+    np.save(os.path.join(out_dir, "rgb%d.npy" % rank), rgbs)
+    np.save(os.path.join(out_dir, "disp%d.npy" % rank), disps)
+    dist.destroy_process_group()
+
+
+def test_render_path_sharded_two_ranks(tmp_path):
+    """Uneven bands (35 pixels over 2 ranks), one all-gather per image, every rank gets the full images."""
+    world = 2
+    mp.spawn(_render_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    pix = np.arange(35, dtype=np.float32)
+    for r in range(world):
+        rgbs, disps = np.load(tmp_path / ("rgb%d.npy" % r)), np.load(tmp_path / ("disp%d.npy" % r))
+        assert rgbs.shape == (3, 5, 7, 3) and disps.shape == (3, 5, 7)
+        for i in range(3):
+            np.testing.assert_array_equal(rgbs[i].reshape(-1, 3), np.stack([pix, pix * 0.5 + i, -pix], -1))
+            np.testing.assert_array_equal(disps[i].reshape(-1), pix + 100.0 * i)
