@@ -447,9 +447,59 @@ def gen_optimizer(ns):
     np.savez_compressed(os.path.join(GOLDEN, "optimizer.npz"), **out)
 
 
+def gen_checkpoint(ns):
+    """A checkpoint written exactly as run_nerf.py:626-641 writes it (DataParallel-wrapped networks ->
+    'module.' keys, the optimizer's state_dict, the camera model's state_dict) after two optimizer
+    steps of the reference, + the parameters after a third step with recorded gradients: what a
+    restored run must reproduce.  Tiny networks (D=3, W=16) keep the fixture small."""
+    H, W = 20, 30
+    spec = synth.camera_spec(H, W, n_cams=4, seed=14, multiplicative=True)
+    args = types.SimpleNamespace(
+        camera_model="pinhole_rot_noise_10k_rayo_rayd", grid_size=10,
+        ray_o_noise_scale=spec["ray_o_noise_scale"], ray_d_noise_scale=spec["ray_d_noise_scale"],
+        extrinsics_noise_scale=spec["extrinsics_noise_scale"],
+        intrinsics_noise_scale=spec["intrinsics_noise_scale"], multiplicative_noise=True)
+    torch.manual_seed(5)
+
+    def net():
+        return torch.nn.DataParallel(ns.helpers.NeRF(D=3, W=16, input_ch=63, output_ch=5, skips=[4],
+                                                     input_ch_views=27, use_viewdirs=True))
+    model, model_fine = net(), net()
+    cm = ns.camera_model.PinholeModelRotNoiseLearning10kRayoRayd(spec["K_init"], list(spec["poses"].numpy()), args, H, W)
+    grad_vars = list(model.parameters()) + list(model_fine.parameters()) + list(cm.parameters())
+    opt = ns.create_nerf.CustomAdamOptimizer(params=grad_vars, lr=5e-4, betas=(0.9, 0.999), weight_decay=0.1,
+                                             H=H, W=W, args=args)
+    g = torch.Generator().manual_seed(77)
+
+    def step(k):
+        gs = []
+        for p in grad_vars:
+            if p.requires_grad:
+                p.grad = torch.randn(p.shape, generator=g) * (0.05 * (k + 1))
+                gs.append(p.grad.clone())
+        opt.step()
+        for grp in opt.param_groups:
+            grp["lr"] = 5e-4 * (0.1 ** ((k + 1) / (250 * 1000)))
+        return gs
+    step(0)
+    step(1)
+    save_dict = {"global_step": 2, "network_fn_state_dict": model.state_dict(),
+                 "network_fine_state_dict": model_fine.state_dict(), "optimizer_state_dict": opt.state_dict(),
+                 "camera_model": cm.state_dict()}
+    torch.save(save_dict, os.path.join(GOLDEN, "ref_ckpt.tar"))
+    gs = step(2)
+    out = {"lr_after_reload": np.array(opt.param_groups[0]["lr"])}
+    trainable = [p for p in grad_vars if p.requires_grad]
+    for i, (p, gg) in enumerate(zip(trainable, gs)):
+        out["grad/%d" % i] = np32(gg)
+        out["after/%d" % i] = np32(p).copy()
+    out["n_trainable"] = np.array(len(trainable))
+    np.savez_compressed(os.path.join(GOLDEN, "ref_ckpt_after.npz"), **out)
+
+
 ALL = dict(optimizer=gen_optimizer, init=gen_init_check, embedder=gen_embedder, mlp=gen_mlp, sample_pdf=gen_sample_pdf,
            composite=gen_composite, render_rays=gen_render_rays, camera=gen_camera,
-           rowsum=gen_rowsum, prd=gen_prd)
+           rowsum=gen_rowsum, prd=gen_prd, checkpoint=gen_checkpoint)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

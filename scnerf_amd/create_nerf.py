@@ -7,6 +7,8 @@ that the fused kernels (multires 10 / 4 compiled in) match what the caller asked
 still be *called* like the reference's closure: query(pts, viewdirs, network_fn) -> raw."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -98,7 +100,10 @@ def create_nerf(args, noisy_focal, noisy_poses, H, W, mode="train", device="cuda
     """Instantiate the coarse / fine networks, the query object, the render kwargs, the camera model
     and the optimizer with the reference's structure and return order (:34-184):
     (render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer, camera_model).
-    Checkpoint reloading (:142-172) is left to the caller's driver."""
+    Checkpoints are found and restored as the reference does (:142-172): `args.ft_path`, else the last
+    `*tar*` file in `basedir/expname`, unless `args.no_reload`; the optimizer's per-parameter state is
+    merged into the fresh optimizer's, the networks load their `module.`-prefixed keys, the camera
+    model its own state."""
     camera_model = None
     embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
     input_ch_views = 0
@@ -156,4 +161,27 @@ def create_nerf(args, noisy_focal, noisy_poses, H, W, mode="train", device="cuda
     else:
         optimizer = FusedAdam(grad_vars, lr=args.lrate, betas=(0.9, 0.999))
     start = 0
+    ft_path = getattr(args, "ft_path", None)
+    basedir, expname = getattr(args, "basedir", None), getattr(args, "expname", None)
+    if ft_path is not None and ft_path != 'None':
+        ckpts = [ft_path]
+    elif basedir is not None and expname is not None and os.path.isdir(os.path.join(basedir, expname)):
+        ckpts = [os.path.join(basedir, expname, f) for f in sorted(os.listdir(os.path.join(basedir, expname)))
+                 if 'tar' in f]
+    else:
+        ckpts = []
+    print('Found ckpts', ckpts)
+    if len(ckpts) > 0 and not getattr(args, "no_reload", False):
+        ckpt_path = ckpts[-1]
+        print('Reloading from', ckpt_path)
+        ckpt = torch.load(ckpt_path, map_location=device)
+        start = ckpt['global_step']
+        optim_dict = optimizer.state_dict()
+        optim_dict["state"].update(ckpt['optimizer_state_dict']["state"])
+        optimizer.load_state_dict(optim_dict)
+        model.load_state_dict(ckpt['network_fn_state_dict'])
+        if model_fine is not None:
+            model_fine.load_state_dict(ckpt['network_fine_state_dict'])
+        if camera_model is not None and "camera_model" in ckpt.keys():
+            camera_model.load_state_dict(ckpt["camera_model"])
     return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer, camera_model

@@ -66,6 +66,7 @@ class RenderRaysFunction(torch.autograd.Function):
         train = any(ctx.needs_input_grad)
         viewdirs = rays[:, 8:11]
 
+        net_c.require_standard()
         flat_c = net_c.flat_parameters()
         wf_c = ops.pack_weights(flat_c, "fwd")
         z_c, pts_c = ops.coarse_sample(rays, host_linspace(sc, dev), _c(t_rand), cfg.lindisp)
@@ -89,6 +90,7 @@ class RenderRaysFunction(torch.autograd.Function):
         u_dev = _c(u) if u is not None else host_linspace(sf, dev)
         z_f, pts_f, z_s, z_std, _, _ = ops.fine_sample(rays, z_c, w_c, u_dev)
         tot = sc + sf
+        fine_net.require_standard()
         flat_f = fine_net.flat_parameters()
         wf_f = wf_c if fine_net is net_c else ops.pack_weights(flat_f, "fwd")
         save_f = ops.save_workspace(n * tot, dev) if train else None

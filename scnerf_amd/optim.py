@@ -87,6 +87,8 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._decay_from = (0 if weight_decay != 0 else len(params)) if decay_from is None else decay_from
         self._segments = None
+        self._loaded_steps = {}          # parameter index -> step count restored from a checkpoint
+        self._step_as_tensor = True      # torch.optim.Adam keeps `step` as a tensor, the reference's class an int
 
     # -- segments ---------------------------------------------------------------------------------
     def _build_segments(self):
@@ -102,12 +104,14 @@ class FusedAdam(torch.optim.Optimizer):
                 raise RuntimeError("FusedAdam needs GPU parameters (scnerf_amd has no CPU path)")
             decay = i >= self._decay_from
             contiguous = bool(cur) and p.data_ptr() == cur[-1].data_ptr() + 4 * cur[-1].numel()
-            if cur and contiguous and cur_key == (p.device, decay):
+            # tensors restored with different step counts (bias corrections differ) cannot share a launch
+            key = (p.device, decay, self._loaded_steps.get(i, 0))
+            if cur and contiguous and cur_key == key:
                 cur.append(p)
             else:
                 if cur:
                     segs.append(_Segment(cur, cur_key[1]))
-                cur, cur_key = [p], (p.device, decay)
+                cur, cur_key = [p], key
         if cur:
             segs.append(_Segment(cur, cur_key[1]))
         for s in segs:
@@ -127,6 +131,48 @@ class FusedAdam(torch.optim.Optimizer):
                 if o is not None and o.n == s.n:
                     s.exp_avg, s.exp_avg_sq, s.step = o.exp_avg, o.exp_avg_sq, o.step
         return self._segments
+
+    # -- checkpoints: torch.optim's per-parameter format, so files written by the reference load here ----
+    def state_dict(self):
+        """Same layout as torch.optim.Adam / the reference's CustomAdamOptimizer (`state[i] = {step,
+        exp_avg, exp_avg_sq}` per parameter index that has been stepped, `param_groups`): checkpoints
+        are interchangeable with the reference's (run_nerf.py:626-641, create_nerf.py:142-172)."""
+        self.state.clear()
+        for s in (self._segments or []):
+            if s.step == 0:
+                continue
+            o = 0
+            for p in s.params:
+                n = p.numel()
+                self.state[p] = {
+                    "step": torch.tensor(float(s.step)) if self._step_as_tensor else int(s.step),
+                    "exp_avg": s.exp_avg[o:o + n].view(p.shape).clone(),
+                    "exp_avg_sq": s.exp_avg_sq[o:o + n].view(p.shape).clone()}
+                o += n
+        sd = super().state_dict()
+        self.state.clear()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)          # validates the groups, casts tensors to the parameters' device
+        plist = self.param_groups[0]["params"]
+        index = {id(p): i for i, p in enumerate(plist)}
+        loaded = {index[id(p)]: st for p, st in self.state.items() if id(p) in index and len(st)}
+        self._loaded_steps = {i: int(float(st["step"])) for i, st in loaded.items()}
+        self._segments = None
+        for s in self.segments():
+            o = 0
+            for p in s.params:
+                st = loaded.get(index[id(p)])
+                n = p.numel()
+                if st is not None:
+                    if "max_exp_avg_sq" in st:
+                        raise NotImplementedError("amsgrad state is not supported")
+                    s.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                    s.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    s.step = int(float(st["step"]))
+                o += n
+        self.state.clear()
 
     def zero_grad(self, set_to_none: bool = False):
         """Zeroes the flat gradient buffers in place (the .grad views stay attached)."""
@@ -174,3 +220,4 @@ class CustomAdamOptimizer(FusedAdam):
             decay_from -= "dist" in args.camera_model
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decay_from=decay_from)
         self.args, self.H, self.W = args, H, W
+        self._step_as_tensor = False

@@ -108,23 +108,27 @@ class NeRF(nn.Module):
     def flat_parameters(self) -> torch.Tensor:
         """One contiguous fp32 buffer holding all parameters in registration order; the
         nn.Parameters are re-pointed at views of it (in-place optimizers keep it current).
-        Re-flattens transparently after .to()/.cuda() moved the tensors."""
-        self.require_standard()
-        params = self.ordered_parameters()
+        Re-flattens transparently after .to()/.cuda() moved the tensors.  Works for any network
+        shape (one optimizer segment, one all-reduce range); only the standard shape has packing
+        tables for the fused kernels (mlp_layout.PARAM_OFFSETS == these offsets)."""
+        params = [p for _, p in self.named_parameters()]
+        offsets, o = [], 0
+        for p in params:
+            offsets.append(o)
+            o += p.numel()
+        if self.is_standard():
+            assert [n for n, _ in self.named_parameters()] == [n for n, _ in ML.PARAM_SHAPES]
+            assert offsets == [ML.PARAM_OFFSETS[n] for n, _ in ML.PARAM_SHAPES]
         flat = self._flat
-        ok = flat is not None and flat.device == params[0].device
+        ok = flat is not None and flat.device == params[0].device and flat.numel() == o
         if ok:
             base = flat.data_ptr()
-            for p, (name, _) in zip(params, ML.PARAM_SHAPES):
-                if p.data_ptr() != base + 4 * ML.PARAM_OFFSETS[name]:
-                    ok = False
-                    break
+            ok = all(p.data_ptr() == base + 4 * off for p, off in zip(params, offsets))
         if not ok:
             with torch.no_grad():
                 flat = torch.cat([p.detach().reshape(-1).float() for p in params]).contiguous()
-                for p, (name, shape) in zip(params, ML.PARAM_SHAPES):
-                    o = ML.PARAM_OFFSETS[name]
-                    p.data = flat[o:o + p.numel()].view(shape)
+                for p, off in zip(params, offsets):
+                    p.data = flat[off:off + p.numel()].view(p.shape)
             self._flat = flat
         return flat
 
