@@ -497,9 +497,202 @@ def gen_checkpoint(ns):
     np.savez_compressed(os.path.join(GOLDEN, "ref_ckpt_after.npz"), **out)
 
 
+@contextlib.contextmanager
+def injected_uniforms(queue):
+    """torch.rand(*shape) and torch.rand_like(x) pop pre-drawn tensors (NeRF++'s perturb_samples /
+    sample_pdf draw this way, ddp_train_nerf.py:77,108)."""
+    real_rand, real_like = torch.rand, torch.rand_like
+
+    def fake_rand(*a, **k):
+        t = queue.pop(0)
+        shape = tuple(a[0]) if len(a) == 1 and not isinstance(a[0], int) else tuple(a)
+        assert tuple(t.shape) == shape, (t.shape, shape)
+        return t.clone()
+
+    def fake_like(x, **k):
+        t = queue.pop(0)
+        assert t.shape == x.shape, (t.shape, x.shape)
+        return t.clone()
+    torch.rand, torch.rand_like = fake_rand, fake_like
+    try:
+        yield
+    finally:
+        torch.rand, torch.rand_like = real_rand, real_like
+
+
+def _projections(named_grads, seed=99):
+    """Per tensor: L2 norm and the dot product with a seeded Gaussian vector -- a gradient fingerprint
+    that pins every entry's contribution without storing the (multi-MB) gradient itself."""
+    from oracle.nerfpp_oracle import grad_fingerprint
+    return {name: np.array(grad_fingerprint(name, g, seed)) for name, g in named_grads}
+
+
+def gen_nerfpp(ns_unused):
+    """NeRF++, from the reference's own nerfplusplus/ code: init pin,
+    KATs of intersect_sphere / perturb_samples / sample_pdf / depth2pts_outside, NerfNet.forward with
+    gradients, a two-level cascade training step with injected uniforms, and the pixel-centre ray
+    generator with and without radial distortion."""
+    from oracle.ref_import import load_nerfpp
+    npp = load_nerfpp()
+    out = {}
+    args = types.SimpleNamespace(max_freq_log2=10, max_freq_log2_viewdirs=4, netdepth=8, netwidth=256,
+                                 use_viewdirs=True)
+
+    def make_net(seed):
+        torch.manual_seed(seed)
+        return npp.ddp_model.NerfNet(args)
+    # --- init pin: synthetic.nerfpp_params(seed) == reference construction
+    net = make_net(777)
+    mine = synth.nerfpp_params(777)
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, mine[k]), k
+    out["init/abs_sums"] = np.array([float(v.double().abs().sum()) for v in net.state_dict().values()])
+    out["init/first8_fg0"] = np32(net.state_dict()["fg_net.base_layers.0.0.weight"].reshape(-1)[:8])
+    out["init/first8_bg5"] = np32(net.state_dict()["bg_net.base_layers.5.0.weight"].reshape(-1)[:8])
+
+    # --- function KATs
+    n = 48
+    o, d, near = synth.nerfpp_rays(n, seed=21)
+    out["kat/ray_o"], out["kat/ray_d"] = np32(o), np32(d)
+    far = npp.train.intersect_sphere(o, d)
+    out["kat/far"] = np32(far)
+    g = torch.Generator().manual_seed(31)
+    z = torch.sort(torch.rand(n, 24, generator=g), -1)[0]
+    t_rand = torch.rand(n, 24, generator=g)
+    with injected_uniforms([t_rand]):
+        out["kat/perturbed"] = np32(npp.train.perturb_samples(z))
+    out["kat/z"], out["kat/t_rand"] = np32(z), np32(t_rand)
+    bins = torch.sort(torch.rand(n, 24, generator=g) * 3, -1)[0]
+    w = torch.rand(n, 23, generator=g) ** 3
+    w[0] = 0.0                                   # all-zero row: only the TINY floor remains
+    w[1] = 0.0; w[1, 7] = 5.0                    # one peaked bin
+    w[2, :5] = 0.0                               # leading zeros
+    w[3, -6:] = 0.0                              # trailing zeros
+    u = torch.rand(n, 40, generator=g)
+    u[:, 0] = 0.0
+    u[:, 1] = 1.0 - 1e-7
+    u[4] = torch.linspace(0, 1, 40)              # the deterministic draw incl. u == 1 exactly
+    with injected_uniforms([u]):
+        out["kat/pdf_samples"] = np32(npp.train.sample_pdf(bins, w, 40, det=False))
+    out["kat/pdf_det"] = np32(npp.train.sample_pdf(bins, w, 40, det=True))
+    out["kat/bins"], out["kat/weights"], out["kat/u"] = np32(bins), np32(w), np32(u)
+    depth = torch.rand(n, 16, generator=g) * 0.98 + 0.01
+    depth[:, 0] = 1.0
+    depth[:, 1] = 1e-3
+    oo, dd = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    pts, dreal = npp.ddp_model.depth2pts_outside(oo[:, None].expand(n, 16, 3), dd[:, None].expand(n, 16, 3), depth)
+    gp = torch.randn(pts.shape, generator=g)
+    (pts * gp).sum().backward()
+    out.update({"kat/bg_depth": np32(depth), "kat/bg_pts": np32(pts), "kat/bg_depth_real": np32(dreal),
+                "kat/bg_g_pts": np32(gp), "kat/bg_g_o": np32(oo.grad), "kat/bg_g_d": np32(dd.grad)})
+
+    # --- one NerfNet.forward with gradients (uneven sample counts, 40 rays)
+    n = 40
+    o, d, near = synth.nerfpp_rays(n, seed=23)
+    net = make_net(778)
+    oo, dd = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    far = npp.train.intersect_sphere(oo, dd)
+    gz = torch.Generator().manual_seed(41)
+    frac = torch.sort(torch.rand(n, 48, generator=gz), -1)[0]
+    fg_z = near[:, None] + frac * (far - near)[:, None]
+    bg_z = torch.sort(torch.rand(n, 40, generator=gz), -1)[0]
+    ret = net(oo, dd, far, fg_z, bg_z)
+    target = torch.rand(n, 3, generator=gz)
+    gw = torch.randn(n, 48, generator=gz) * 1e-2
+    loss = ((ret["rgb"] - target) ** 2).mean() + (ret["fg_weights"] * gw).sum() + ret["bg_depth"].mean() * 0.1 \
+        + ret["fg_depth"].mean() * 0.1
+    loss.backward()
+    k = "fwd/"
+    out.update({k + "ray_o": np32(o), k + "ray_d": np32(d), k + "frac": np32(frac), k + "bg_z": np32(bg_z),
+                k + "target": np32(target), k + "gw": np32(gw), k + "loss": np32(loss), k + "far": np32(far),
+                k + "g_ray_o": np32(oo.grad), k + "g_ray_d": np32(dd.grad)})
+    for name, v in ret.items():
+        out[k + "ret/" + name] = np32(v)
+    for name, v in _projections([(a, b.grad) for a, b in net.named_parameters()]).items():
+        out[k + "gproj/" + name] = v
+    for name in ("fg_net.base_layers.0.0.weight", "bg_net.base_layers.0.0.weight", "bg_net.sigma_layers.0.weight",
+                 "fg_net.rgb_layers.2.weight", "fg_net.rgb_layers.2.bias", "bg_net.base_remap_layers.0.bias"):
+        out[k + "g/" + name] = np32(dict(net.named_parameters())[name].grad)
+
+    # --- two-level cascade training step (ddp_train_nerf.py:430-489), 64 then 128 extra samples
+    n, s0, s1 = 32, 64, 128
+    o, d, near = synth.nerfpp_rays(n, seed=25)
+    rnd = synth.nerfpp_randoms(n, s0, s1, seed=26)
+    nets = [make_net(779), make_net(780)]
+    target = torch.rand(n, 3, generator=torch.Generator().manual_seed(27))
+    oo, dd = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    with injected_uniforms([rnd["t_fg"], rnd["t_bg"], rnd["u_fg"], rnd["u_bg"]]):
+        far = npp.train.intersect_sphere(oo, dd)
+        step = (far - near) / (s0 - 1)
+        fg_depth = torch.stack([near + i * step for i in range(s0)], dim=-1)
+        fg_depth = npp.train.perturb_samples(fg_depth)
+        bg_depth = torch.linspace(0., 1., s0).view(1, s0).expand(n, s0)
+        bg_depth = npp.train.perturb_samples(bg_depth)
+        ret0 = nets[0](oo, dd, far, fg_depth, bg_depth)
+        loss = ((ret0["rgb"] - target) ** 2).mean()
+        fg_w = ret0["fg_weights"].clone().detach()
+        fg_mid = .5 * (fg_depth[..., 1:] + fg_depth[..., :-1])
+        fg_s = npp.train.sample_pdf(bins=fg_mid, weights=fg_w[..., 1:-1], N_samples=s1, det=False)
+        fg_depth1, _ = torch.sort(torch.cat((fg_depth, fg_s), dim=-1))
+        bg_w = ret0["bg_weights"].clone().detach()
+        bg_mid = .5 * (bg_depth[..., 1:] + bg_depth[..., :-1])
+        bg_s = npp.train.sample_pdf(bins=bg_mid, weights=bg_w[..., 1:-1], N_samples=s1, det=False)
+        bg_depth1, _ = torch.sort(torch.cat((bg_depth, bg_s), dim=-1))
+        ret1 = nets[1](oo, dd, far, fg_depth1, bg_depth1)
+        loss = loss + ((ret1["rgb"] - target) ** 2).mean()
+    loss.backward()
+    k = "step/"
+    out.update({k + "ray_o": np32(o), k + "ray_d": np32(d), k + "target": np32(target), k + "loss": np32(loss),
+                k + "rgb0": np32(ret0["rgb"]), k + "rgb1": np32(ret1["rgb"]), k + "fg_depth0": np32(fg_depth),
+                k + "bg_depth0": np32(bg_depth), k + "fg_depth1": np32(fg_depth1), k + "bg_depth1": np32(bg_depth1),
+                k + "bg_lambda1": np32(ret1["bg_lambda"]), k + "fg_depth_map1": np32(ret1["fg_depth"]),
+                k + "g_ray_o": np32(oo.grad), k + "g_ray_d": np32(dd.grad)})
+    for lvl, nn_ in enumerate(nets):
+        for name, v in _projections([(a, b.grad) for a, b in nn_.named_parameters()]).items():
+            out[k + "gproj%d/" % lvl + name] = v
+
+    # --- ray generator (A18): both camera model classes
+    H, W = 60, 80
+    base = load_reference()
+    for tag, cls_name in (("plain", "PinholeModelRotNoiseLearning10kRayoRayd"),
+                          ("dist", "PinholeModelRotNoiseLearning10kRayoRaydDistortion")):
+        spec = synth.camera_spec(H, W, n_cams=4, seed=33, multiplicative=True, focal=70.0)
+        cargs = types.SimpleNamespace(
+            camera_model="x", grid_size=10, ray_o_noise_scale=spec["ray_o_noise_scale"],
+            ray_d_noise_scale=spec["ray_d_noise_scale"], extrinsics_noise_scale=spec["extrinsics_noise_scale"],
+            intrinsics_noise_scale=spec["intrinsics_noise_scale"], multiplicative_noise=True,
+            distortion_noise_scale=1e-1)
+        cls = getattr(base.camera_model, cls_name)
+        extra = (np.array([0.05, -0.02], np.float32),) if tag == "dist" else ()
+        cm = cls(spec["K_init"], list(spec["poses"].numpy()), cargs, H, W, *extra)
+        with torch.no_grad():
+            cm.intrinsics_noise.copy_(spec["intrinsics_noise"])
+            cm.extrinsics_noise.copy_(spec["extrinsics_noise"])
+            cm.ray_o_noise.copy_(spec["ray_o_noise"])
+            if cm.ray_d_noise.data_ptr() != cm.ray_o_noise.data_ptr():
+                cm.ray_d_noise.copy_(spec["ray_d_noise"])
+            if tag == "dist":
+                cm.distortion_noise.copy_(torch.tensor([0.3, -0.2]))
+        sel = torch.randint(0, H * W, (64,), generator=torch.Generator().manual_seed(34))
+        sel[0], sel[1] = 0, H * W - 1
+        ro, rd, dep = npp.rays.render_ray_from_camera(cm, 2, sel, "cpu")
+        g_o = torch.randn(ro.shape, generator=torch.Generator().manual_seed(35))
+        g_d = torch.randn(rd.shape, generator=torch.Generator().manual_seed(36))
+        ((ro * g_o).sum() + (rd * g_d).sum()).backward()
+        k = "rays_%s/" % tag
+        out.update({k + "select": sel.numpy(), k + "rays_o": np32(ro), k + "rays_d": np32(rd), k + "depth": np32(dep),
+                    k + "g_o": np32(g_o), k + "g_d": np32(g_d)})
+        for name, prm in cm.named_parameters():
+            if prm.grad is not None:
+                out[k + "g_" + name] = np32(prm.grad)
+        if tag == "dist":
+            out[k + "k"] = extra[0]
+    np.savez_compressed(os.path.join(GOLDEN, "nerfpp.npz"), **out)
+
+
 ALL = dict(optimizer=gen_optimizer, init=gen_init_check, embedder=gen_embedder, mlp=gen_mlp, sample_pdf=gen_sample_pdf,
            composite=gen_composite, render_rays=gen_render_rays, camera=gen_camera,
-           rowsum=gen_rowsum, prd=gen_prd, checkpoint=gen_checkpoint)
+           rowsum=gen_rowsum, prd=gen_prd, checkpoint=gen_checkpoint, nerfpp=gen_nerfpp)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -162,3 +162,56 @@ def matched_keypoints(H: int, W: int, K, E0, E1, n: int, seed=8, noise_px=0.7, o
     k0[:, 0].clamp_(0, W - 1); k1[:, 0].clamp_(0, W - 1)
     k0[:, 1].clamp_(0, H - 1); k1[:, 1].clamp_(0, H - 1)
     return k0.contiguous(), k1.contiguous()
+
+
+def nerfpp_params(seed: int = 777, n_freqs: int = 10, n_freqs_views: int = 4, D: int = 8, W: int = 256):
+    """State dict of a freshly constructed NeRF++ `NerfNet` (fg_net then bg_net, each: D trunk layers,
+    density layer, remap layer, two colour layers -- nerfplusplus/nerf_network.py:86-115) with torch's
+    default nn.Linear initialisation drawn in the reference's construction order under
+    torch.manual_seed(seed) -- pinned bit-for-bit by tests/golden/nerfpp.npz 'init/*'."""
+    import torch.nn as nn
+    state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    out = {}
+    try:
+        for prefix, in_dim in (("fg_net.", 3), ("bg_net.", 4)):
+            in_ch = in_dim + 2 * in_dim * n_freqs
+            in_views = 3 + 6 * n_freqs_views
+            dim = in_ch
+            layers = []
+            for i in range(D):
+                layers.append(("base_layers.%d.0" % i, nn.Linear(dim, W)))
+                dim = W
+                if i == 4 and i != D - 1:
+                    dim += in_ch
+            layers.append(("sigma_layers.0", nn.Linear(dim, 1)))
+            layers.append(("base_remap_layers.0", nn.Linear(dim, 256)))
+            layers.append(("rgb_layers.0", nn.Linear(256 + in_views, W // 2)))
+            layers.append(("rgb_layers.2", nn.Linear(W // 2, 3)))
+            for name, lin in layers:
+                out[prefix + name + ".weight"] = lin.weight.detach().clone()
+                out[prefix + name + ".bias"] = lin.bias.detach().clone()
+    finally:
+        torch.random.set_rng_state(state)
+    return out
+
+
+def nerfpp_rays(n: int, seed: int = 21):
+    """Rays of a camera inside the unit sphere (NeRF++ normalises scenes so): origins |o| <= 0.45,
+    directions of length ~1-1.4 (z = 1 before rotation, as K^-1 p gives), min_depth 1e-4."""
+    g = torch.Generator().manual_seed(seed)
+    o = torch.randn(n, 3, generator=g)
+    o = o / o.norm(dim=-1, keepdim=True) * (0.1 + 0.35 * torch.rand(n, 1, generator=g))
+    d = torch.cat([torch.rand(n, 2, generator=g) * 1.2 - 0.6, torch.ones(n, 1)], -1)
+    q = torch.randn(3, 3, generator=g)
+    q, _ = torch.linalg.qr(q)
+    d = d @ q.t()
+    return o.contiguous(), d.contiguous(), torch.full((n,), 1e-4)
+
+
+def nerfpp_randoms(n: int, s0: int, s1: int, seed: int = 22):
+    """Injected uniforms of one two-level cascade step: level-0 jitter of the fg / bg depths, level-1
+    inverse-CDF draws."""
+    g = torch.Generator().manual_seed(seed)
+    return {"t_fg": torch.rand(n, s0, generator=g), "t_bg": torch.rand(n, s0, generator=g),
+            "u_fg": torch.rand(n, s1, generator=g), "u_bg": torch.rand(n, s1, generator=g)}
