@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SCNERF_ABI_VERSION 1
+#define SCNERF_ABI_VERSION 2
 
 int scnerf_abi_version(void);
 
@@ -149,24 +149,29 @@ int scnerf_ray_reduce(const float* d_pts, const float* d_views, const float* z,
  * order described by the index tables of scnerf_amd/mlp_layout.py. */
 int scnerf_gather_f32(const float* src, const int* idx, float* dst, long long n, void* stream);
 
-/* Layout constants compiled into the kernels (checked against mlp_layout.py at load). */
-int scnerf_mlp_layout_info(int* out, int n);
+/* Layout constants compiled into the kernels (checked against mlp_layout.py at load) for the network
+ * variant pt_dims (see scnerf_mlp_fwd); n >= 22. */
+int scnerf_mlp_layout_info(int pt_dims, int* out, int n);
 
 /* Fused positional encoding + NeRF.forward for the standard network (D=8, W=256, skips=[4],
  * use_viewdirs, multires 10/4): replaces run_network + Embedder + NeRF.forward
- * (NeRF/create_nerf.py:18-32, NeRF/run_nerf_helpers.py:24-72, :105-128).
- * pts [n_samples, 3]; viewdirs row r at viewdirs + r * vd_stride (3 for a packed [n_rays, 3]
+ * (NeRF/create_nerf.py:18-32, NeRF/run_nerf_helpers.py:24-72, :105-128) and, with the parameters
+ * renamed, NeRF++'s Embedder + MLPNet.forward before its output non-linearities
+ * (nerfplusplus/nerf_network.py:41-60, :117-142).  pt_dims = 3: points (x, y, z), 63 encoded columns
+ * -- the SCNeRF networks and NeRF++'s foreground net; pt_dims = 4: points (x, y, z, 1/r), 84 encoded
+ * columns -- NeRF++'s background net (nerfplusplus/ddp_model.py:62-71).
+ * pts [n_samples, pt_dims]; viewdirs row r at viewdirs + r * vd_stride (3 for a packed [n_rays, 3]
  * tensor, 11 with viewdirs = ray_batch + 8), ray(p) = p / samples_per_ray;
  * wpacked = forward packed buffer (scnerf_gather_f32 with mlp_layout.forward_index());
  * raw [n_samples, 4] = (rgb logits, sigma).  save: NULL (inference) or the activation
  * workspace of mlp_layout.SAVE_FLOATS_PER_SAMPLE * n_samples floats (training). */
-int scnerf_mlp_fwd(const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
+int scnerf_mlp_fwd(int pt_dims, const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
                    const float* wpacked, float* raw, float* save, long long n_samples,
                    void* stream);
 
 /* Workspace sizes (floats) for n_samples samples: activations saved by the training forward
  * (rows + ReLU bit masks) and the per-layer output gradients written by scnerf_mlp_bwd. */
-long long scnerf_mlp_save_floats(long long n_samples);
+long long scnerf_mlp_save_floats(int pt_dims, long long n_samples);
 long long scnerf_mlp_grad_floats(long long n_samples);
 
 /* Data-gradient chain of the fused network (what autograd derives from NeRF.forward,
@@ -174,9 +179,9 @@ long long scnerf_mlp_grad_floats(long long n_samples);
  * d_raw [n_samples, 4]; wpacked_bwd = backward packed buffer (mlp_layout.backward_index());
  * save = workspace filled by scnerf_mlp_fwd on the same inputs.  Outputs: grads workspace
  * (dZ of the 8 trunk layers, d feature, dZ of the views layer: row-major, consumed by
- * scnerf_wgrad), d_pts [n_samples, 3], d_views [n_samples, 3] (per sample, not yet summed
+ * scnerf_wgrad), d_pts [n_samples, pt_dims], d_views [n_samples, 3] (per sample, not yet summed
  * per ray). */
-int scnerf_mlp_bwd(const float* d_raw, const float* pts, const float* viewdirs, int vd_stride,
+int scnerf_mlp_bwd(int pt_dims, const float* d_raw, const float* pts, const float* viewdirs, int vd_stride,
                    int samples_per_ray, const float* wpacked_bwd, const float* save,
                    float* grads, float* d_pts, float* d_views, long long n_samples, void* stream);
 
@@ -201,14 +206,14 @@ int scnerf_wgrad(const float* dz, int lda, int n_load, int n_out, int dz_tiled, 
 int scnerf_vecmat(const float* x_tiled256, const float* vec, int vec_stride, long long n_samples,
                   int n_chunks, float* workspace, float* dv, float* dvsum, void* stream);
 
-/* All weight and bias gradients of one standard NeRF, written into a flat gradient buffer in
- * the reference's parameter order (scnerf_nerf_param_count() floats; NeRF/run_nerf_helpers.py:
- * 88-103): 12 scnerf_wgrad calls over the workspaces of scnerf_mlp_fwd (save) and
- * scnerf_mlp_bwd (grads) and d_raw [n_samples, 4].  workspace:
+/* All weight and bias gradients of one network (variant pt_dims, see scnerf_mlp_fwd), written into a
+ * flat gradient buffer in the reference NeRF's parameter order (scnerf_nerf_param_count(pt_dims)
+ * floats; NeRF/run_nerf_helpers.py:88-103): 12 scnerf_wgrad calls over the workspaces of
+ * scnerf_mlp_fwd (save) and scnerf_mlp_bwd (grads) and d_raw [n_samples, 4].  workspace:
  * scnerf_nerf_wgrad_workspace_floats(n_chunks) floats. */
-int scnerf_nerf_param_count(void);
+int scnerf_nerf_param_count(int pt_dims);
 long long scnerf_nerf_wgrad_workspace_floats(int n_chunks);
-int scnerf_nerf_wgrad(const float* save, const float* grads, const float* d_raw,
+int scnerf_nerf_wgrad(int pt_dims, const float* save, const float* grads, const float* d_raw,
                       long long n_samples, int n_chunks, float* workspace, float* flat_grad,
                       void* stream);
 

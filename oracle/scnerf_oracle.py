@@ -81,7 +81,7 @@ def query_network(p, pts: Tensor, viewdirs: Optional[Tensor], multires=10,
     input_ch = emb.shape[-1]
     input_ch_views = 0
     if viewdirs is not None:
-        dirs = viewdirs[:, None].expand(pts.shape).reshape(-1, pts.shape[-1])
+        dirs = viewdirs[:, None].expand(*pts.shape[:-1], viewdirs.shape[-1]).reshape(-1, viewdirs.shape[-1])
         emb_d = positional_encoding(dirs, multires_views)
         input_ch_views = emb_d.shape[-1]
         emb = torch.cat([emb, emb_d], dim=-1)

@@ -40,18 +40,18 @@ PROTOTYPES = {
     "scnerf_composite_bwd": [P, P, P, I, P, I, P, P, P, P, P, P, P, I, I, P],
     "scnerf_ray_reduce": [P, P, P, P, P, I, I, I, I, P],
     "scnerf_gather_f32": [P, P, P, LL, P],
-    "scnerf_mlp_layout_info": [P, I],
-    "scnerf_mlp_fwd": [P, P, I, I, P, P, P, LL, P],
-    "scnerf_mlp_bwd": [P, P, P, I, I, P, P, P, P, P, LL, P],
-    "scnerf_nerf_param_count": [],
-    "scnerf_nerf_wgrad": [P, P, P, LL, I, P, P, P],
+    "scnerf_mlp_layout_info": [I, P, I],
+    "scnerf_mlp_fwd": [I, P, P, I, I, P, P, P, LL, P],
+    "scnerf_mlp_bwd": [I, P, P, P, I, I, P, P, P, P, P, LL, P],
+    "scnerf_nerf_param_count": [I],
+    "scnerf_nerf_wgrad": [I, P, P, P, LL, I, P, P, P],
     "scnerf_wgrad": [P, I, I, I, I, P, I, I, I, I, LL, I, P, P, I, I, P, P],
     "scnerf_vecmat": [P, P, I, LL, I, P, P, P, P],
 }
 
 
 # functions returning long long instead of a status
-SIZE_FUNCS = {"scnerf_mlp_save_floats": [LL], "scnerf_mlp_grad_floats": [LL],
+SIZE_FUNCS = {"scnerf_mlp_save_floats": [I, LL], "scnerf_mlp_grad_floats": [LL],
               "scnerf_wgrad_workspace_floats": [I, I, I],
               "scnerf_nerf_wgrad_workspace_floats": [I],
               "scnerf_camera_bwd_workspace_floats": [I]}
@@ -87,7 +87,7 @@ def load() -> ctypes.CDLL:
                 "libscnerf_hip.so is not built (%s). Run `python -m scnerf_amd.csrc.build` "
                 "(or __graft_entry__.build()); scnerf_amd has no CPU fallback." % LIB_PATH)
         _lib = bind(ctypes.CDLL(LIB_PATH))
-        if _lib.scnerf_abi_version() != 1:
+        if _lib.scnerf_abi_version() != 2:
             raise ScnerfLibraryError("ABI version mismatch")
     return _lib
 

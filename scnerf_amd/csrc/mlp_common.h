@@ -20,18 +20,49 @@ constexpr int kThreads = 256;           // 4 waves, one per SIMD (the kernel nee
 constexpr int kSamplesPerWave = 32;
 constexpr int kSamplesPerBlock = 128;
 
-// ---- packed parameter buffer offsets (floats); mirrored in scnerf_amd/mlp_layout.py ----
-constexpr int kFwdStream = 598016;
-constexpr int kFwdBias = kFwdStream;          // 8 trunk layers x 256, half-pair layout
-constexpr int kFwdBiasF = kFwdBias + 8 * 256;
-constexpr int kFwdBiasV = kFwdBiasF + 256;
-constexpr int kFwdBiasRGB = kFwdBiasV + 128;
-constexpr int kFwdAlphaW = kFwdBiasRGB + 32;
-constexpr int kFwdAlphaB = kFwdAlphaW + 256;
-constexpr int kFwdTotal = kFwdAlphaB + 4;
-constexpr int kBwdStream = 1024 + 64 * 9 * 64 + 3 * 65536 + 128 * 10 * 64 + 4 * 65536 + 128 * 2 * 64;
-constexpr int kBwdAlphaW = kBwdStream;
-constexpr int kBwdTotal = kBwdAlphaW + 256;
+// ---- network variants ---------------------------------------------------------------------------
+// PD = dimensions of the encoded point: 3 = (x, y, z), the SCNeRF / NeRF++-foreground network
+// (63 encoded columns, 32 PE slots per lane half); 4 = (x, y, z, 1/r), the NeRF++ background network
+// (nerfplusplus/ddp_model.py:62-71: 84 columns, 48 slots).  Everything else -- trunk, skip, heads -- is
+// identical, so the two variants share every part of the weight stream except the encoded-point ones.
+template <int PD>
+struct Var {
+    static_assert(PD == 3 || PD == 4, "point dimensions");
+    static constexpr int kInCh = PD + 2 * PD * 10;           // 63 / 84 encoded columns
+    static constexpr int kES = PD == 3 ? 32 : 48;            // PE slots (MFMA steps) of the encoded point
+    static constexpr int kEW = PD == 3 ? 64 : 128;           // row width of the saved encodings (wgrad K)
+    static constexpr int kET = PD == 3 ? 2 : 4;              // 32-column tiles of the dgrad's d-encoding
+    static constexpr int kECS = PD == 3 ? 64 : 32;           // dgrad chunk steps of those parts (8192-float chunks)
+    // ---- packed parameter buffer offsets (floats); mirrored in scnerf_amd/mlp_layout.py ----
+    static constexpr int kFwdStream = 2 * kES * 8 * 64 + 8 * 65536 + 128 * 4 * 64 + 16 * 4 * 64 + 64 * 64;
+    static constexpr int kFwdBias = kFwdStream;              // 8 trunk layers x 256, half-pair layout
+    static constexpr int kFwdBiasF = kFwdBias + 8 * 256;
+    static constexpr int kFwdBiasV = kFwdBiasF + 256;
+    static constexpr int kFwdBiasRGB = kFwdBiasV + 128;
+    static constexpr int kFwdAlphaW = kFwdBiasRGB + 32;
+    static constexpr int kFwdAlphaB = kFwdAlphaW + 256;
+    static constexpr int kFwdTotal = kFwdAlphaB + 4;
+    static constexpr int kBwdStream = 1024 + 64 * 9 * 64 + 8 * 65536 + 2 * 128 * kET * 64;
+    static constexpr int kBwdAlphaW = kBwdStream;
+    static constexpr int kBwdTotal = kBwdAlphaW + 256;
+    static constexpr int kSavePerSample = 8 * 256 + 256 + 128 + 32 + kEW;
+    // flat parameter offsets, reference registration order (mirrors mlp_layout.Layout.param_offsets)
+    static constexpr int kW0 = 0, kB0 = kW0 + 256 * kInCh;
+    static constexpr int kTrunk1 = kB0 + 256;                // layers 1..7: weight then bias
+    static constexpr int kSkipLd = 256 + kInCh;
+    static constexpr int trunk_w(int l) {
+        return l <= 5 ? kTrunk1 + (l - 1) * (256 * 256 + 256)
+                      : kTrunk1 + 4 * (256 * 256 + 256) + (256 * kSkipLd + 256) + (l - 6) * (256 * 256 + 256);
+    }
+    static constexpr int trunk_b(int l) { return trunk_w(l) + (l == 5 ? 256 * kSkipLd : 256 * 256); }
+    static constexpr int kWV = trunk_b(7) + 256, kBV = kWV + 128 * 283;
+    static constexpr int kWF = kBV + 128, kBF = kWF + 256 * 256;
+    static constexpr int kWA = kBF + 256, kBA = kWA + 256;
+    static constexpr int kWRGB = kBA + 1, kBRGB = kWRGB + 3 * 128;
+    static constexpr int kNParams = kBRGB + 3;
+};
+static_assert(Var<3>::kFwdStream == 598016 && Var<3>::kBwdStream == 594944 && Var<3>::kNParams == 595844, "standard network");
+static_assert(Var<4>::kNParams == 606596, "NeRF++ background network");
 
 constexpr int kMaxChunkFwd = 8192;      // floats: 32 KB, x2 buffers = 64 KB LDS
 constexpr int kMaxChunkBwd = 8192;      // floats: 32 KB, x2 buffers = 64 KB LDS
@@ -41,15 +72,16 @@ constexpr int kMaxChunkBwd = 8192;      // floats: 32 KB, x2 buffers = 64 KB LDS
 // per wave tile of 32 samples a block [t][q][lane][4] (t = 32-feature tile, q = 0..3, lane = (m, h)),
 // holding feature 32 t + 8 q + 4 h + j of sample m at element j -- exactly the registers a lane owns,
 // so every store instruction of the MLP kernels writes 1 KB contiguous.  The wgrad GEMM stages whole
-// tiles linearly into LDS and reads this layout there.  epts / eviews are row-major [P][64] / [P][32].
+// tiles linearly into LDS and reads this layout there.  eviews / epts are row-major [P][32] / [P][kEW]
+// (epts last: its width is the only variant-dependent one).
 constexpr int kSaveAct = 0;             // 8 sections of width 256
 constexpr int kSaveFeat = 8 * 256;
 constexpr int kSaveHv = kSaveFeat + 256;
-constexpr int kSaveEpts = kSaveHv + 128;
-constexpr int kSaveEviews = kSaveEpts + 64;
-constexpr int kSavePerSample = kSaveEviews + 32;   // 2592
-// after the row sections: ReLU bit masks, lane-native: [9 sections][wave tile][64 lanes][4 words]
-// (sections 0..7 = trunk layers, 8 = views layer); 8 words per (padded) sample and section.
+constexpr int kSaveEviews = kSaveHv + 128;
+constexpr int kSaveEpts = kSaveEviews + 32;
+// after the row sections (Var<PD>::kSavePerSample floats per sample): ReLU bit masks, lane-native:
+// [9 sections][wave tile][64 lanes][4 words] (sections 0..7 = trunk layers, 8 = views layer); 8 words
+// per (padded) sample and section.
 constexpr int kMaskSections = 9;
 constexpr int kMaskWordsPerSample = kMaskSections * 8;   // 72
 constexpr int kGradDz = 0;              // 8 x [P][256]
@@ -61,41 +93,68 @@ __host__ __device__ constexpr int feat_of(int t, int r, int h) {
     return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
 }
 
-// Embedding column of PE slot s on lane-half h (torch order: x, then per frequency
-// [sin xyz, cos xyz]); -1 = zero pad.  Mirrors mlp_layout.pe_col.
-__host__ __device__ constexpr int pe_col(int L, int s, int h) {
-    if (s < 3 * L) {
-        const int f = s / 3, j = s % 3;
-        if (j == 0) return 3 + 6 * f + h;
-        if (j == 1) return 3 + 6 * f + 3 + h;
-        return 3 + 6 * f + (h == 0 ? 2 : 5);
+// Embedding column of PE slot s on lane-half h (torch order: the raw coordinates, then per frequency
+// [sin of each, cos of each]); -1 = zero pad.  Mirrors mlp_layout.pe_col.
+//   PD == 3: slots 3f, 3f+1 = sin / cos of (h ? y : x) 2^f; slot 3f+2 = (h ? cos : sin)(z 2^f);
+//            slot 3L = raw x|y; slot 3L+1 = raw z | pad.
+//   PD == 4: half h owns coordinates (h ? y : x) and (h ? w : z): slots 4f .. 4f+3 = sin, cos of the
+//            first, sin, cos of the second; slots 4L, 4L+1 = the raw pair.
+__host__ __device__ constexpr int pe_col(int L, int s, int h, int PD = 3) {
+    if (PD == 3) {
+        if (s < 3 * L) {
+            const int f = s / 3, j = s % 3;
+            if (j == 0) return 3 + 6 * f + h;
+            if (j == 1) return 3 + 6 * f + 3 + h;
+            return 3 + 6 * f + (h == 0 ? 2 : 5);
+        }
+        if (s == 3 * L) return h;
+        if (s == 3 * L + 1) return h == 0 ? 2 : -1;
+        return -1;
     }
-    if (s == 3 * L) return h;
-    if (s == 3 * L + 1) return h == 0 ? 2 : -1;
+    if (s < 4 * L) {
+        const int f = s / 4, j = s % 4;
+        const int coord = (j < 2 ? 0 : 2) + h;              // x|y then z|w
+        return 4 + 8 * f + ((j & 1) ? 4 : 0) + coord;       // sin block then cos block of frequency f
+    }
+    if (s == 4 * L) return h;
+    if (s == 4 * L + 1) return 2 + h;
     return -1;
 }
 
-// Positional encoding of (x, y, z) straight into MFMA B-operand registers: NS slots.
-// Slots 3f, 3f+1 = sin / cos of (h ? y : x) * 2^f; slot 3f+2 = (h ? cos : sin)(z * 2^f);
-// slot 3L = raw x|y; slot 3L+1 = raw z | 0.  x * 2^f is exact, as in the reference.
-template <int L, int NS>
-__device__ __forceinline__ void pe_slots(float x, float y, float z, int h, float (&e)[NS]) {
-    const float xy = h ? y : x;
+// Positional encoding of a point straight into MFMA B-operand registers: NS slots (layout above).
+// x * 2^f is exact, as in the reference.  `w` is ignored for PD == 3.
+template <int PD, int L, int NS>
+__device__ __forceinline__ void pe_slots(float x, float y, float z, float w, int h, float (&e)[NS]) {
+    const float a = h ? y : x;
     float freq = 1.f;
+    if constexpr (PD == 3) {
 #pragma unroll
-    for (int f = 0; f < L; ++f) {
-        float s0, c0, s1, c1;
-        sincos(xy * freq, &s0, &c0);
-        sincos(z * freq, &s1, &c1);
-        e[3 * f + 0] = s0;
-        e[3 * f + 1] = c0;
-        e[3 * f + 2] = h ? c1 : s1;
-        freq *= 2.f;
+        for (int f = 0; f < L; ++f) {
+            float s0, c0, s1, c1;
+            sincos(a * freq, &s0, &c0);
+            sincos(z * freq, &s1, &c1);
+            e[3 * f + 0] = s0;
+            e[3 * f + 1] = c0;
+            e[3 * f + 2] = h ? c1 : s1;
+            freq *= 2.f;
+        }
+        e[3 * L] = a;
+        e[3 * L + 1] = h ? 0.f : z;
+#pragma unroll
+        for (int s = 3 * L + 2; s < NS; ++s) e[s] = 0.f;
+    } else {
+        const float b = h ? w : z;
+#pragma unroll
+        for (int f = 0; f < L; ++f) {
+            sincos(a * freq, &e[4 * f + 0], &e[4 * f + 1]);
+            sincos(b * freq, &e[4 * f + 2], &e[4 * f + 3]);
+            freq *= 2.f;
+        }
+        e[4 * L] = a;
+        e[4 * L + 1] = b;
+#pragma unroll
+        for (int s = 4 * L + 2; s < NS; ++s) e[s] = 0.f;
     }
-    e[3 * L] = xy;
-    e[3 * L + 1] = h ? 0.f : z;
-#pragma unroll
-    for (int s = 3 * L + 2; s < NS; ++s) e[s] = 0.f;
 }
 
 // ---- weight stream: global (L2) -> LDS, one chunk ahead of the MFMAs ---------------------
@@ -302,8 +361,9 @@ __device__ __forceinline__ float mask_select(float v, u32x4 bits, int i) {
     return __int_as_float(__float_as_int(v) & m);
 }
 
+template <int PD>
 __device__ __forceinline__ unsigned int* mask_ptr(float* save, long P, int section, long wave_tile, int lane) {
-    unsigned int* base = reinterpret_cast<unsigned int*>(save + (long)kSavePerSample * padded_samples(P));
+    unsigned int* base = reinterpret_cast<unsigned int*>(save + (long)Var<PD>::kSavePerSample * padded_samples(P));
     return base + ((long)section * (padded_samples(P) / 32) + wave_tile) * 256 + lane * 4;
 }
 

@@ -31,23 +31,24 @@ __device__ __forceinline__ void relu_to_regs(const f32x16 (&acc)[N / 16], float 
 }
 
 // encodings are saved in torch column order so the wgrad GEMM writes weight columns directly
-template <int L, int NS>
+template <int PD, int L, int NS>
 __device__ __forceinline__ void store_pe(const float (&e)[NS], float* __restrict__ base, long p, int ld,
                                          int h, bool live) {
     if (!live) return;
     float* row = base + p * ld;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const int c0 = pe_col(L, s, 0), c1 = pe_col(L, s, 1);
+        const int c0 = pe_col(L, s, 0, PD), c1 = pe_col(L, s, 1, PD);
         const int c = h ? c1 : c0;
         if (c >= 0) row[c] = e[s];
     }
     if (h == 1) {
         // zero the pad columns of the row (they are read, masked, by the wgrad GEMM)
-        for (int c = 3 + 6 * L; c < ld; ++c) row[c] = 0.f;
+        for (int c = PD + 2 * PD * L; c < ld; ++c) row[c] = 0.f;
     }
 }
 
+template <int PD>
 __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     const float* __restrict__ pts, const float* __restrict__ viewdirs, int vd_stride, int samples_per_ray,
     const float* __restrict__ wpk, float* __restrict__ raw, float* __restrict__ save, long P) {
@@ -58,6 +59,8 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     const bool live = p < P;
     const long pc = live ? p : P - 1;
     const long Ppad = padded_samples(P);
+    using V = Var<PD>;
+    constexpr int ES = V::kES;
 
     WStream ws;
     ws.g = reinterpret_cast<const f32x4*>(wpk);
@@ -65,7 +68,8 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     ws.buf[1] = ws.buf[0] + kMaxChunkFwd;
     stream_prime<8>(ws);   // first chunk of E0 (8 tiles x 16 steps)
 
-    const float px = pts[pc * 3 + 0], py = pts[pc * 3 + 1], pz = pts[pc * 3 + 2];
+    const float px = pts[pc * PD + 0], py = pts[pc * PD + 1], pz = pts[pc * PD + 2];
+    const float pw = PD == 4 ? pts[pc * PD + (PD - 1)] : 0.f;
 
     float hreg[256 / 2];           // this lane's 128 of the 256 trunk features
     f32x16 acc[8];
@@ -75,41 +79,41 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     // point is parked in LDS for the skip layer instead of staying live through layers 1..4.
     f32x4* park = reinterpret_cast<f32x4*>(ws.buf[0] + 2 * kMaxChunkFwd) + threadIdx.x;
     {
-        float e[32];
-        pe_slots<10, 32>(px, py, pz, h, e);
-        if (save) store_pe<10, 32>(e, save + (long)kSaveEpts * Ppad, pc, 64, h, live);
+        float e[ES];
+        pe_slots<PD, 10, ES>(px, py, pz, pw, h, e);
+        if (save) store_pe<PD, 10, ES>(e, save + (long)kSaveEpts * Ppad, pc, V::kEW, h, live);
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
+        for (int g = 0; g < ES / 4; ++g) {
             f32x4 v = {e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3]};
             park[g * kThreads] = v;
         }
-        init_bias<8>(acc, wpk + kFwdBias, h);
-        mfma_part<32, 8, 16, 8>(e, acc, ws);
+        init_bias<8>(acc, wpk + V::kFwdBias, h);
+        mfma_part<ES, 8, 16, 8>(e, acc, ws);
         relu_to_regs<128>(acc, hreg, true);
-        if (save) *reinterpret_cast<u32x4*>(mask_ptr(save, P, 0, wave_tile, lane)) = relu_bits<128>(hreg);
+        if (save) *reinterpret_cast<u32x4*>(mask_ptr<PD>(save, P, 0, wave_tile, lane)) = relu_bits<128>(hreg);
     }
 
     // trunk layers 1..7 and the (linear) feature layer as l == 8.  In training mode the output of
     // layer l-1 (the B operand of layer l's main part) is written to HBM chunk by chunk during layer l.
 #pragma unroll 1
     for (int l = 1; l <= 8; ++l) {
-        init_bias<8>(acc, wpk + (l < 8 ? kFwdBias + 256 * l : kFwdBiasF), h);
+        init_bias<8>(acc, wpk + (l < 8 ? V::kFwdBias + 256 * l : V::kFwdBiasF), h);
         if (l == 5) {
-            float e[32];
+            float e[ES];
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
+            for (int g = 0; g < ES / 4; ++g) {
                 const f32x4 v = park[g * kThreads];
                 e[4 * g] = v[0]; e[4 * g + 1] = v[1]; e[4 * g + 2] = v[2]; e[4 * g + 3] = v[3];
             }
-            mfma_part<32, 8, 16, 8>(e, acc, ws);
+            mfma_part<ES, 8, 16, 8>(e, acc, ws);
         }
         mfma_part<128, 8, 16, 8>(hreg, acc, ws,       // every chunk that can follow is 8 x 16 B / thread
                                  save ? tile_ptr(save + (long)(kSaveAct + 256 * (l - 1)) * Ppad, wave_tile, 256, lane) : nullptr);
         relu_to_regs<128>(acc, hreg, l < 8);
-        if (save && l < 8) *reinterpret_cast<u32x4*>(mask_ptr(save, P, l, wave_tile, lane)) = relu_bits<128>(hreg);
+        if (save && l < 8) *reinterpret_cast<u32x4*>(mask_ptr<PD>(save, P, l, wave_tile, lane)) = relu_bits<128>(hreg);
         if (l == 7) {
             // density head on the VALU: sigma = w_alpha . h8 + b  (half of the features per lane)
-            const float* wa = wpk + kFwdAlphaW;
+            const float* wa = wpk + V::kFwdAlphaW;
 #pragma unroll
             for (int i = 0; i < 128; ++i) {
                 const float w0 = wa[2 * i], w1 = wa[2 * i + 1];
@@ -121,22 +125,22 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     // colour head: views layer on [feature | encoded view direction]
     const long ray = pc / samples_per_ray;
     float ev[16];
-    pe_slots<4, 16>(viewdirs[ray * vd_stride + 0], viewdirs[ray * vd_stride + 1], viewdirs[ray * vd_stride + 2], h, ev);
-    if (save) store_pe<4, 16>(ev, save + (long)kSaveEviews * Ppad, pc, 32, h, live);
+    pe_slots<3, 4, 16>(viewdirs[ray * vd_stride + 0], viewdirs[ray * vd_stride + 1], viewdirs[ray * vd_stride + 2], 0.f, h, ev);
+    if (save) store_pe<3, 4, 16>(ev, save + (long)kSaveEviews * Ppad, pc, 32, h, live);
     f32x16 accv[4];
-    init_bias<4>(accv, wpk + kFwdBiasV, h);
+    init_bias<4>(accv, wpk + V::kFwdBiasV, h);
     mfma_part<128, 4, 32, 4>(hreg, accv, ws,             // then VE: 4 tiles x 16 steps = 4 f4
                              save ? tile_ptr(save + (long)kSaveFeat * Ppad, wave_tile, 256, lane) : nullptr);
     mfma_part<16, 4, 16, 4>(ev, accv, ws);               // then RGB: 1 tile x 64 steps = 4 f4
     float hv[64];
     relu_to_regs<64>(accv, hv, true);
-    if (save) *reinterpret_cast<u32x4*>(mask_ptr(save, P, 8, wave_tile, lane)) = relu_bits<64>(hv);
+    if (save) *reinterpret_cast<u32x4*>(mask_ptr<PD>(save, P, 8, wave_tile, lane)) = relu_bits<64>(hv);
 
     f32x16 accc[1];
-    init_bias<1>(accc, wpk + kFwdBiasRGB, h);
+    init_bias<1>(accc, wpk + V::kFwdBiasRGB, h);
     mfma_part<64, 1, 64, 0>(hv, accc, ws, save ? tile_ptr(save + (long)kSaveHv * Ppad, wave_tile, 128, lane) : nullptr);
 
-    const float sigma = sigma_part + shfl_xor(sigma_part, 32) + wpk[kFwdAlphaB];
+    const float sigma = sigma_part + shfl_xor(sigma_part, 32) + wpk[V::kFwdAlphaB];
     if (live && h == 0) {
         // rows 0,1,2 of the single tile are registers 0,1,2 of the h == 0 half
         f32x4 o = {accc[0][0], accc[0][1], accc[0][2], sigma};
@@ -162,38 +166,54 @@ extern "C" int scnerf_gather_f32(const float* src, const int* idx, float* dst, l
     return scn_launch_status();
 }
 
-extern "C" int scnerf_mlp_layout_info(int* out, int n) {
-    const int v[] = {kFwdStream, kFwdBias, kFwdBiasF, kFwdBiasV, kFwdBiasRGB, kFwdAlphaW, kFwdAlphaB,
-                     kFwdTotal, kBwdStream, kBwdAlphaW, kBwdTotal, kSavePerSample, kGradPerSample,
-                     kSaveFeat, kSaveHv, kSaveEpts, kSaveEviews, kGradDfeat, kGradDzv, kMaskWordsPerSample};
-    const int cnt = (int)(sizeof(v) / sizeof(v[0]));
-    SCN_RETURN_IF(!out || n < cnt, SCN_EINVAL);
-    for (int i = 0; i < cnt; ++i) out[i] = v[i];
+template <int PD>
+static void layout_values(int* v) {
+    using V = Var<PD>;
+    const int vals[] = {V::kFwdStream, V::kFwdBias, V::kFwdBiasF, V::kFwdBiasV, V::kFwdBiasRGB, V::kFwdAlphaW,
+                        V::kFwdAlphaB, V::kFwdTotal, V::kBwdStream, V::kBwdAlphaW, V::kBwdTotal, V::kSavePerSample,
+                        kGradPerSample, kSaveFeat, kSaveHv, kSaveEpts, kSaveEviews, kGradDfeat, kGradDzv,
+                        kMaskWordsPerSample, V::kNParams, V::kEW};
+    for (int i = 0; i < 22; ++i) v[i] = vals[i];
+}
+
+extern "C" int scnerf_mlp_layout_info(int pt_dims, int* out, int n) {
+    SCN_RETURN_IF(!out || n < 22 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
+    if (pt_dims == 3) layout_values<3>(out); else layout_values<4>(out);
     return 0;
 }
 
-extern "C" long long scnerf_mlp_save_floats(long long n_samples) {
-    return (long long)(kSavePerSample + kMaskWordsPerSample) * padded_samples(n_samples);
+extern "C" long long scnerf_mlp_save_floats(int pt_dims, long long n_samples) {
+    const int per = pt_dims == 4 ? Var<4>::kSavePerSample : Var<3>::kSavePerSample;
+    return (long long)(per + kMaskWordsPerSample) * padded_samples(n_samples);
 }
 
 extern "C" long long scnerf_mlp_grad_floats(long long n_samples) {
     return (long long)kGradPerSample * padded_samples(n_samples);
 }
 
-extern "C" int scnerf_mlp_fwd(const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
-                              const float* wpacked, float* raw, float* save, long long n_samples,
-                              void* stream) {
-    SCN_RETURN_IF(!pts || !viewdirs || !wpacked || !raw || samples_per_ray < 1 || vd_stride < 3 || n_samples < 0, SCN_EINVAL);
-    if (n_samples == 0) return 0;
-    const size_t lds = (size_t)(2 * kMaxChunkFwd + 32 * kThreads) * sizeof(float);   // weights + parked encodings
-    static bool lds_opt_in = false;          // 96 KB of dynamic LDS needs the per-kernel opt-in (> 64 KB)
+template <int PD>
+static int launch_fwd(const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
+                      const float* wpacked, float* raw, float* save, long long n_samples, hipStream_t st) {
+    // weights (2 x 32 KB) + the parked encoding of the 256 threads
+    const size_t lds = (size_t)(2 * kMaxChunkFwd + Var<PD>::kES * kThreads) * sizeof(float);
+    static bool lds_opt_in = false;          // > 64 KB of dynamic LDS needs the per-kernel opt-in
     if (!lds_opt_in) {
-        SCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel),
+        SCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<PD>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_opt_in = true;
     }
-    hipLaunchKernelGGL(mlp_fwd_kernel, dim3(scn_ceil_div(n_samples, kSamplesPerBlock)), dim3(kThreads), lds,
-                       (hipStream_t)stream, pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save,
-                       (long)n_samples);
+    hipLaunchKernelGGL(mlp_fwd_kernel<PD>, dim3(scn_ceil_div(n_samples, kSamplesPerBlock)), dim3(kThreads), lds,
+                       st, pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, (long)n_samples);
     return scn_launch_status();
+}
+
+extern "C" int scnerf_mlp_fwd(int pt_dims, const float* pts, const float* viewdirs, int vd_stride,
+                              int samples_per_ray, const float* wpacked, float* raw, float* save,
+                              long long n_samples, void* stream) {
+    SCN_RETURN_IF(!pts || !viewdirs || !wpacked || !raw || samples_per_ray < 1 || vd_stride < 3 || n_samples < 0, SCN_EINVAL);
+    SCN_RETURN_IF(pt_dims != 3 && pt_dims != 4, SCN_EINVAL);
+    if (n_samples == 0) return 0;
+    if (pt_dims == 3)
+        return launch_fwd<3>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, n_samples, (hipStream_t)stream);
+    return launch_fwd<4>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, n_samples, (hipStream_t)stream);
 }

@@ -303,9 +303,9 @@ int launch_wgrad(const WgradArgs& a, int G, hipStream_t stream) {
 struct Shape { int BN, BK; };
 
 bool pick_shape(int n_load, int k_load, Shape* s) {
-    // (BN, BK) of the five instantiations below
+    // (BN, BK) of the six instantiations below
     if (n_load > 256 || k_load > 256) return false;
-    if (n_load > 128) { s->BN = 256; s->BK = k_load > 64 ? 256 : 64; return true; }
+    if (n_load > 128) { s->BN = 256; s->BK = k_load > 128 ? 256 : (k_load > 64 ? 128 : 64); return true; }
     if (n_load > 64) { s->BN = 128; s->BK = k_load > 64 ? 256 : 64; return true; }
     s->BN = 64; s->BK = 128;
     return k_load <= 128;
@@ -344,6 +344,7 @@ extern "C" int scnerf_wgrad(const float* dz, int lda, int n_load, int n_out, int
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (s.BN == 256 && s.BK == 256) rc = launch_wgrad<4, 4>(a, G, st);
+    else if (s.BN == 256 && s.BK == 128) rc = launch_wgrad<4, 2>(a, G, st);
     else if (s.BN == 256 && s.BK == 64) rc = launch_wgrad<4, 1>(a, G, st);
     else if (s.BN == 128 && s.BK == 256) rc = launch_wgrad<2, 4>(a, G, st);
     else if (s.BN == 128 && s.BK == 64) rc = launch_wgrad<2, 1>(a, G, st);
@@ -366,61 +367,59 @@ extern "C" int scnerf_vecmat(const float* x_tiled256, const float* vec, int vec_
     return scn_launch_status();
 }
 
-// ---- all weight gradients of one standard NeRF (D=8, W=256, skip 4, view-dependent head) ----
+// ---- all weight gradients of one network (D=8, W=256, skip 4, view-dependent head; 3-D or 4-D point) ----
+extern "C" int scnerf_nerf_param_count(int pt_dims) {
+    return pt_dims == 4 ? scn::mlp::Var<4>::kNParams : scn::mlp::Var<3>::kNParams;
+}
+
 namespace {
-// flat parameter offsets, reference registration order (mirrors mlp_layout.PARAM_OFFSETS)
-constexpr int kW0 = 0, kB0 = kW0 + 256 * 63;
-constexpr int kTrunk1 = kB0 + 256;                       // layers 1..7: weight then bias
-constexpr int trunk_w(int l) { return l <= 5 ? kTrunk1 + (l - 1) * (256 * 256 + 256) : kTrunk1 + 4 * (256 * 256 + 256) + (256 * 319 + 256) + (l - 6) * (256 * 256 + 256); }
-constexpr int trunk_b(int l) { return trunk_w(l) + (l == 5 ? 256 * 319 : 256 * 256); }
-constexpr int kWV = trunk_b(7) + 256, kBV = kWV + 128 * 283;
-constexpr int kWF = kBV + 128, kBF = kWF + 256 * 256;
-constexpr int kWA = kBF + 256, kBA = kWA + 256;
-constexpr int kWRGB = kBA + 1, kBRGB = kWRGB + 3 * 128;
-constexpr int kNParams = kBRGB + 3;
-static_assert(kNParams == 595844, "parameter count of the standard NeRF");
-}  // namespace
-
-extern "C" int scnerf_nerf_param_count(void) { return kNParams; }
-
-extern "C" int scnerf_nerf_wgrad(const float* save, const float* grads, const float* d_raw,
-                                 long long n_samples, int n_chunks, float* workspace, float* flat_grad,
-                                 void* stream) {
+template <int PD>
+int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long long P, int n_chunks,
+               float* workspace, float* g, void* stream) {
     using namespace scn::mlp;
-    SCN_RETURN_IF(!save || !grads || !d_raw || !workspace || !flat_grad || n_samples < 1 || n_chunks < 1, SCN_EINVAL);
-    const long long P = n_samples;
+    using V = Var<PD>;
     const long long Ppad = scn::mlp::padded_samples(P);
     auto S = [&](int sec) { return save + (long long)sec * Ppad; };
     auto G = [&](int sec) { return grads + (long long)sec * Ppad; };
     auto act = [&](int l) { return S(kSaveAct + 256 * l); };
     auto dz = [&](int l) { return G(kGradDz + 256 * l); };
-    float* g = flat_grad;
+    constexpr int EW = V::kEW, IN = V::kInCh, SK = V::kSkipLd;
     int rc;
 #define SCN_WG(...)                          \
     rc = scnerf_wgrad(__VA_ARGS__, stream);  \
     if (rc != 0) return rc;
     // (dz, lda, n_load, n_out, tiled,  x, ldb, k_load, k_out, tiled,  P, chunks, ws, dW, ldo, col0, db)
-    // layer 0: X = encoded points (row-major, 63 valid of 64 columns)
-    SCN_WG(dz(0), 256, 256, 256, 1, S(kSaveEpts), 64, 64, 63, 0, P, n_chunks, workspace, g + kW0, 63, 0, g + kB0)
+    // layer 0: X = encoded points (row-major, IN valid of EW columns)
+    SCN_WG(dz(0), 256, 256, 256, 1, S(kSaveEpts), EW, EW, IN, 0, P, n_chunks, workspace, g + V::kW0, IN, 0, g + V::kB0)
     for (int l = 1; l <= 7; ++l) {
         if (l == 5) {
-            SCN_WG(dz(5), 256, 256, 256, 1, S(kSaveEpts), 64, 64, 63, 0, P, n_chunks, workspace, g + trunk_w(5), 319, 0, nullptr)
-            SCN_WG(dz(5), 256, 256, 256, 1, act(4), 256, 256, 256, 1, P, n_chunks, workspace, g + trunk_w(5), 319, 63, g + trunk_b(5))
+            SCN_WG(dz(5), 256, 256, 256, 1, S(kSaveEpts), EW, EW, IN, 0, P, n_chunks, workspace, g + V::trunk_w(5), SK, 0, nullptr)
+            SCN_WG(dz(5), 256, 256, 256, 1, act(4), 256, 256, 256, 1, P, n_chunks, workspace, g + V::trunk_w(5), SK, IN, g + V::trunk_b(5))
         } else {
-            SCN_WG(dz(l), 256, 256, 256, 1, act(l - 1), 256, 256, 256, 1, P, n_chunks, workspace, g + trunk_w(l), 256, 0, g + trunk_b(l))
+            SCN_WG(dz(l), 256, 256, 256, 1, act(l - 1), 256, 256, 256, 1, P, n_chunks, workspace, g + V::trunk_w(l), 256, 0, g + V::trunk_b(l))
         }
     }
     // feature_linear; alpha_linear (one output row) = d sigma^T . act7 with d sigma = d_raw[:, 3]
-    SCN_WG(G(kGradDfeat), 256, 256, 256, 1, act(7), 256, 256, 256, 1, P, n_chunks, workspace, g + kWF, 256, 0, g + kBF)
-    rc = scnerf_vecmat(act(7), d_raw + 3, 4, P, n_chunks, workspace, g + kWA, g + kBA, stream);
+    SCN_WG(G(kGradDfeat), 256, 256, 256, 1, act(7), 256, 256, 256, 1, P, n_chunks, workspace, g + V::kWF, 256, 0, g + V::kBF)
+    rc = scnerf_vecmat(act(7), d_raw + 3, 4, P, n_chunks, workspace, g + V::kWA, g + V::kBA, stream);
     if (rc != 0) return rc;
     // views layer: [feature | encoded direction]
-    SCN_WG(G(kGradDzv), 128, 128, 128, 1, S(kSaveFeat), 256, 256, 256, 1, P, n_chunks, workspace, g + kWV, 283, 0, g + kBV)
-    SCN_WG(G(kGradDzv), 128, 128, 128, 1, S(kSaveEviews), 32, 32, 27, 0, P, n_chunks, workspace, g + kWV, 283, 256, nullptr)
+    SCN_WG(G(kGradDzv), 128, 128, 128, 1, S(kSaveFeat), 256, 256, 256, 1, P, n_chunks, workspace, g + V::kWV, 283, 0, g + V::kBV)
+    SCN_WG(G(kGradDzv), 128, 128, 128, 1, S(kSaveEviews), 32, 32, 27, 0, P, n_chunks, workspace, g + V::kWV, 283, 256, nullptr)
     // rgb_linear: dZ = d_raw[:, 0:3] (row-major), X = hidden of the views layer
-    SCN_WG(d_raw, 4, 4, 3, 0, S(kSaveHv), 128, 128, 128, 1, P, n_chunks, workspace, g + kWRGB, 128, 0, g + kBRGB)
+    SCN_WG(d_raw, 4, 4, 3, 0, S(kSaveHv), 128, 128, 128, 1, P, n_chunks, workspace, g + V::kWRGB, 128, 0, g + V::kBRGB)
 #undef SCN_WG
     return 0;
+}
+}  // namespace
+
+extern "C" int scnerf_nerf_wgrad(int pt_dims, const float* save, const float* grads, const float* d_raw,
+                                 long long n_samples, int n_chunks, float* workspace, float* flat_grad,
+                                 void* stream) {
+    SCN_RETURN_IF(!save || !grads || !d_raw || !workspace || !flat_grad || n_samples < 1 || n_chunks < 1, SCN_EINVAL);
+    SCN_RETURN_IF(pt_dims != 3 && pt_dims != 4, SCN_EINVAL);
+    if (pt_dims == 3) return nerf_wgrad<3>(save, grads, d_raw, n_samples, n_chunks, workspace, flat_grad, stream);
+    return nerf_wgrad<4>(save, grads, d_raw, n_samples, n_chunks, workspace, flat_grad, stream);
 }
 
 extern "C" long long scnerf_nerf_wgrad_workspace_floats(int n_chunks) {

@@ -142,36 +142,49 @@ def fine_sample(rays: Tensor, z_c: Tensor, w_c: Tensor, u: Tensor, want_inds=Fal
 _index_cache = {}
 
 
-def _device_index(kind: str, device) -> Tensor:
-    key = (kind, str(device))
+def _device_index(kind: str, device, pd: int = 3, remap=None) -> Tensor:
+    """int32 gather table (flat parameter buffer -> streaming order) of network variant `pd` on the
+    device.  `remap` = (key, int64 array [n_params]) translates the table's canonical parameter offsets
+    (mlp_layout.Layout order) into the offsets of a module that registers the same tensors in another
+    order (NeRF++'s MLPNet)."""
+    key = (kind, str(device), pd, None if remap is None else remap[0])
     if key not in _index_cache:
-        idx = ML.forward_index() if kind == "fwd" else ML.backward_index()
+        lay = ML.layout(pd)
+        idx = lay.forward_index() if kind == "fwd" else lay.backward_index()
+        if remap is not None:
+            table = np.asarray(remap[1], dtype=np.int64)
+            idx = np.where(idx >= 0, table[np.maximum(idx, 0)], -1).astype(np.int32)
         _index_cache[key] = torch.from_numpy(idx).to(device)
     return _index_cache[key]
 
 
 def check_layout():
-    out = (np.zeros(32, np.int32))
     import ctypes
-    st = _capi.load().scnerf_mlp_layout_info(out.ctypes.data_as(ctypes.c_void_p), 32)
-    _capi.check(st, "scnerf_mlp_layout_info")
-    exp = [ML.FWD_STREAM, ML.FWD_BIAS, ML.FWD_BIAS_F, ML.FWD_BIAS_V, ML.FWD_BIAS_RGB, ML.FWD_ALPHA_W,
-           ML.FWD_ALPHA_B, ML.FWD_TOTAL, ML.BWD_STREAM, ML.BWD_ALPHA_W, ML.BWD_TOTAL,
-           ML.SAVE_FLOATS_PER_SAMPLE, ML.GRAD_FLOATS_PER_SAMPLE]
     lib = _capi.load()
-    for P in (1, 128, 4097):
-        if lib.scnerf_mlp_save_floats(P) != ML.save_floats(P) or lib.scnerf_mlp_grad_floats(P) != ML.grad_floats(P):
-            raise RuntimeError("workspace size formulas disagree between the kernels and mlp_layout.py")
-    if out[:len(exp)].tolist() != exp:
-        raise RuntimeError("kernel / mlp_layout.py constants disagree: %s vs %s" % (out[:len(exp)].tolist(), exp))
+    for pd in (3, 4):
+        lay = ML.layout(pd)
+        out = np.zeros(32, np.int32)
+        st = lib.scnerf_mlp_layout_info(pd, out.ctypes.data_as(ctypes.c_void_p), 32)
+        _capi.check(st, "scnerf_mlp_layout_info")
+        exp = [lay.fwd_stream, lay.fwd_bias, lay.fwd_bias_f, lay.fwd_bias_v, lay.fwd_bias_rgb, lay.fwd_alpha_w,
+               lay.fwd_alpha_b, lay.fwd_total, lay.bwd_stream, lay.bwd_alpha_w, lay.bwd_total,
+               lay.save_floats_per_sample, ML.GRAD_FLOATS_PER_SAMPLE]
+        for P in (1, 128, 4097):
+            if lib.scnerf_mlp_save_floats(pd, P) != lay.save_floats(P) or lib.scnerf_mlp_grad_floats(P) != ML.grad_floats(P):
+                raise RuntimeError("workspace size formulas disagree between the kernels and mlp_layout.py")
+        if out[:len(exp)].tolist() != exp or int(out[20]) != lay.n_params or int(out[21]) != lay.e_width:
+            raise RuntimeError("kernel / mlp_layout.py constants disagree (pd=%d): %s vs %s"
+                               % (pd, out[:22].tolist(), exp))
 
 
-def pack_weights(flat_params: Tensor, kind: str = "fwd", out: Optional[Tensor] = None) -> Tensor:
-    """flat parameter buffer (reference order, 595 844 floats) -> packed streaming buffer."""
+def pack_weights(flat_params: Tensor, kind: str = "fwd", out: Optional[Tensor] = None, pd: int = 3,
+                 remap=None) -> Tensor:
+    """flat parameter buffer (595 844 floats for pd = 3, 606 596 for pd = 4) -> packed streaming buffer."""
     _f(flat_params, "flat_params")
-    if flat_params.numel() != ML.N_PARAMS:
-        raise ValueError("expected %d parameters, got %d" % (ML.N_PARAMS, flat_params.numel()))
-    idx = _device_index(kind, flat_params.device)
+    lay = ML.layout(pd)
+    if flat_params.numel() != lay.n_params:
+        raise ValueError("expected %d parameters, got %d" % (lay.n_params, flat_params.numel()))
+    idx = _device_index(kind, flat_params.device, pd, remap)
     if out is None:
         out = torch.empty(idx.numel(), dtype=torch.float32, device=flat_params.device)
     st = _capi.load().scnerf_gather_f32(_p(flat_params), _p(idx), _p(out), idx.numel(), _stream())
@@ -189,44 +202,52 @@ def _vd(viewdirs: Tensor):
     return viewdirs.data_ptr(), int(viewdirs.stride(0)) if viewdirs.shape[0] > 1 else 3
 
 
+_MAC_PER_SAMPLE = {3: 593408, 4: 593408 + 2 * 256 * 21}       # layer 0 and the skip layer are 21 columns wider
+
+
 def mlp_fwd(pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked: Tensor,
-            save: Optional[Tensor] = None) -> Tensor:
+            save: Optional[Tensor] = None, pd: int = 3) -> Tensor:
+    """pts [P, pd] (pd = 3: x y z; pd = 4: x y z 1/r) -> raw [P, 4] (rgb logits, sigma pre-activation)."""
     _f(pts, "pts"), _f(wpacked, "wpacked")
     vptr, vstride = _vd(viewdirs)
-    P = pts.numel() // 3
-    if wpacked.numel() != ML.FWD_TOTAL:
+    lay = ML.layout(pd)
+    P = pts.numel() // pd
+    if wpacked.numel() != lay.fwd_total:
         raise ValueError("wpacked has the wrong size")
     if save is not None:
         _f(save, "save")
-        if save.numel() < ML.save_floats(P):
+        if save.numel() < lay.save_floats(P):
             raise ValueError("activation workspace too small")
     raw = torch.empty((P, 4), dtype=torch.float32, device=pts.device)
-    with PROFILE.region("mlp_fwd_kernel/P=%d/%s" % (P, "train" if save is not None else "infer"), 2 * 593408 * P):
-        st = _capi.load().scnerf_mlp_fwd(_p(pts), vptr, vstride, int(samples_per_ray), _p(wpacked), _p(raw),
+    tag = "" if pd == 3 else "/pd4"
+    with PROFILE.region("mlp_fwd_kernel%s/P=%d/%s" % (tag, P, "train" if save is not None else "infer"),
+                        2 * _MAC_PER_SAMPLE[pd] * P):
+        st = _capi.load().scnerf_mlp_fwd(pd, _p(pts), vptr, vstride, int(samples_per_ray), _p(wpacked), _p(raw),
                                          _p(save), P, _stream())
     _capi.check(st, "scnerf_mlp_fwd")
     return raw
 
 
-def save_workspace(P: int, device) -> Tensor:
-    return torch.empty(ML.save_floats(P), dtype=torch.float32, device=device)
+def save_workspace(P: int, device, pd: int = 3) -> Tensor:
+    return torch.empty(ML.layout(pd).save_floats(P), dtype=torch.float32, device=device)
 
 
 def mlp_bwd(d_raw: Tensor, pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked_bwd: Tensor,
-            save: Tensor):
-    """-> (grads workspace, d_pts [P,3], d_views [P,3])."""
+            save: Tensor, pd: int = 3):
+    """-> (grads workspace, d_pts [P,pd], d_views [P,3])."""
     _f(d_raw, "d_raw"), _f(pts, "pts"), _f(wpacked_bwd, "wpacked_bwd"), _f(save, "save")
     vptr, vstride = _vd(viewdirs)
-    P = pts.numel() // 3
-    if wpacked_bwd.numel() != ML.BWD_TOTAL:
+    lay = ML.layout(pd)
+    P = pts.numel() // pd
+    if wpacked_bwd.numel() != lay.bwd_total:
         raise ValueError("wpacked_bwd has the wrong size")
     dev = pts.device
     grads = torch.empty(ML.grad_floats(P), dtype=torch.float32, device=dev)
-    d_pts = torch.empty((P, 3), dtype=torch.float32, device=dev)
+    d_pts = torch.empty((P, pd), dtype=torch.float32, device=dev)
     d_views = torch.empty((P, 3), dtype=torch.float32, device=dev)
-    with PROFILE.region("mlp_bwd_kernel/P=%d" % P, 2 * 593408 * P):
-        st = _capi.load().scnerf_mlp_bwd(_p(d_raw), _p(pts), vptr, vstride, int(samples_per_ray), _p(wpacked_bwd),
-                                         _p(save), _p(grads), _p(d_pts), _p(d_views), P, _stream())
+    with PROFILE.region("mlp_bwd_kernel%s/P=%d" % ("" if pd == 3 else "/pd4", P), 2 * _MAC_PER_SAMPLE[pd] * P):
+        st = _capi.load().scnerf_mlp_bwd(pd, _p(d_raw), _p(pts), vptr, vstride, int(samples_per_ray),
+                                         _p(wpacked_bwd), _p(save), _p(grads), _p(d_pts), _p(d_views), P, _stream())
     _capi.check(st, "scnerf_mlp_bwd")
     return grads, d_pts, d_views
 
@@ -239,8 +260,9 @@ def wgrad_chunks(P: int) -> int:
 _wgrad_ws = {}
 
 
-def nerf_wgrad(save: Tensor, grads: Tensor, d_raw: Tensor, P: int, flat_grad: Optional[Tensor] = None) -> Tensor:
-    """All parameter gradients of one network -> flat buffer (reference parameter order)."""
+def nerf_wgrad(save: Tensor, grads: Tensor, d_raw: Tensor, P: int, flat_grad: Optional[Tensor] = None,
+               pd: int = 3) -> Tensor:
+    """All parameter gradients of one network -> flat buffer (mlp_layout.Layout parameter order)."""
     lib = _capi.load()
     chunks = wgrad_chunks(P)
     key = (chunks, str(save.device))
@@ -248,10 +270,11 @@ def nerf_wgrad(save: Tensor, grads: Tensor, d_raw: Tensor, P: int, flat_grad: Op
         _wgrad_ws[key] = torch.empty(lib.scnerf_nerf_wgrad_workspace_floats(chunks), dtype=torch.float32,
                                      device=save.device)
     if flat_grad is None:
-        flat_grad = torch.empty(ML.N_PARAMS, dtype=torch.float32, device=save.device)
-    with PROFILE.region("wgrad(12 GEMMs + reduces)/P=%d" % P, 2 * 593408 * P, group=True):
-        st = lib.scnerf_nerf_wgrad(_p(save), _p(grads), _p(d_raw), P, chunks, _p(_wgrad_ws[key]), _p(flat_grad),
-                                   _stream())
+        flat_grad = torch.empty(ML.layout(pd).n_params, dtype=torch.float32, device=save.device)
+    with PROFILE.region("wgrad(12 GEMMs + reduces)%s/P=%d" % ("" if pd == 3 else "/pd4", P),
+                        2 * _MAC_PER_SAMPLE[pd] * P, group=True):
+        st = lib.scnerf_nerf_wgrad(pd, _p(save), _p(grads), _p(d_raw), P, chunks, _p(_wgrad_ws[key]),
+                                   _p(flat_grad), _stream())
     _capi.check(st, "scnerf_nerf_wgrad")
     return flat_grad
 

@@ -6,14 +6,40 @@ from scnerf_amd import mlp_layout as ML
 from tests.emu import harness as H
 
 
-def flat_params(p):
-    return np.concatenate([p[name].detach().numpy().reshape(-1) for name, _ in ML.PARAM_SHAPES]).astype(np.float32)
+NPP_NAMES = {"alpha_linear": "sigma_layers.0", "feature_linear": "base_remap_layers.0",
+             "views_linears.0": "rgb_layers.0", "rgb_linear": "rgb_layers.2"}
 
 
-def pack_forward(p):
-    src = flat_params(p)
-    assert src.shape[0] == ML.N_PARAMS
-    idx = ML.forward_index()
+def npp_to_nerf_names(p, prefix):
+    """NeRF++ MLPNet parameters (nerfplusplus/nerf_network.py:86-115) under the NeRF names the layout
+    tables use: same tensors, same shapes (base_layers.i.0 = pts_linears.i, sigma = alpha, base_remap =
+    feature, rgb_layers.0 / .2 = views_linears.0 / rgb_linear)."""
+    out = {}
+    for i in range(8):
+        for wb in ("weight", "bias"):
+            out["pts_linears.%d.%s" % (i, wb)] = p[prefix + "base_layers.%d.0.%s" % (i, wb)]
+    for a, b in NPP_NAMES.items():
+        for wb in ("weight", "bias"):
+            out[a + "." + wb] = p[prefix + b + "." + wb]
+    return out
+
+
+def network_params(seed, pd=3):
+    """pd = 3: the synthetic SCNeRF network; pd = 4: the background net of a synthetic NeRF++ model."""
+    from scnerf_amd import synthetic as synth
+    if pd == 3:
+        return synth.network_params(seed=seed)
+    return {k: v.clone() for k, v in npp_to_nerf_names(synth.nerfpp_params(seed), "bg_net.").items()}
+
+
+def flat_params(p, pd=3):
+    return np.concatenate([p[name].detach().numpy().reshape(-1) for name, _ in ML.layout(pd).param_shapes]).astype(np.float32)
+
+
+def pack_forward(p, pd=3):
+    src = flat_params(p, pd)
+    assert src.shape[0] == ML.layout(pd).n_params
+    idx = ML.layout(pd).forward_index()
     dst = np.zeros(idx.shape[0], np.float32)
     H.call("scnerf_gather_f32", src, idx, dst, idx.shape[0], None)
     ref = np.where(idx >= 0, src[np.maximum(idx, 0)], 0).astype(np.float32)
@@ -21,21 +47,22 @@ def pack_forward(p):
     return dst
 
 
-def pack_backward(p):
-    src = flat_params(p)
-    idx = ML.backward_index()
+def pack_backward(p, pd=3):
+    src = flat_params(p, pd)
+    idx = ML.layout(pd).backward_index()
     dst = np.zeros(idx.shape[0], np.float32)
     H.call("scnerf_gather_f32", src, idx, dst, idx.shape[0], None)
     return dst
 
 
-def save_views(save, P):
+def save_views(save, P, pd=3):
     """row-major [P, width] views of every section of the activation workspace (+ the bit masks)."""
-    off, total = ML.section_offsets(ML.SAVE_SECTIONS, P)
-    assert save.shape[0] == ML.save_floats(P)
+    lay = ML.layout(pd)
+    off, total = ML.section_offsets(lay.save_sections, P)
+    assert save.shape[0] == lay.save_floats(P)
     Pp = ML.padded_samples(P)
     out = {"mask": save[total:].view(np.uint32).reshape(9, Pp // 32, 64, 4)}
-    for name, w in ML.SAVE_SECTIONS:
+    for name, w in lay.save_sections:
         blk = save[off[name]: off[name] + w * Pp]
         out[name] = ML.untile(blk, w, P) if name in ML.TILED_SECTIONS else blk.reshape(Pp, w)[:P]
     return out

@@ -9,7 +9,7 @@ from oracle import scnerf_oracle as O
 from scnerf_amd import mlp_layout as ML
 from scnerf_amd import synthetic as synth
 from tests.emu import harness as H
-from tests.emu_mlp_util import pack_forward, pack_backward, grad_views
+from tests.emu_mlp_util import network_params, pack_forward, pack_backward, grad_views
 
 pytestmark = pytest.mark.emu
 
@@ -43,23 +43,25 @@ def oracle_backward(p, pts, vd, spr, d_raw):
     return dict(dz=[z.grad for z in zs], dfeat=feat.grad, dzv=zv.grad, d_pts=pts.grad, d_vd=vd.grad)
 
 
+@pytest.mark.parametrize("pd", [3, 4])
 @pytest.mark.parametrize("n_rays,spr", [(5, 32), (1, 70)])
-def test_mlp_dgrad_matches_autograd(n_rays, spr):
-    p = synth.network_params(seed=2)
-    wpk, wbk = pack_forward(p), pack_backward(p)
+def test_mlp_dgrad_matches_autograd(n_rays, spr, pd):
+    lay = ML.layout(pd)
+    p = network_params(2 if pd == 3 else 778, pd)
+    wpk, wbk = pack_forward(p, pd), pack_backward(p, pd)
     P = n_rays * spr
     g = torch.Generator().manual_seed(9)
-    pts = torch.rand(P, 3, generator=g) * 2.4 - 1.2
+    pts = torch.rand(P, pd, generator=g) * 2.4 - 1.2
     vd = torch.randn(n_rays, 3, generator=g)
     vd = vd / vd.norm(dim=-1, keepdim=True)
     d_raw = torch.randn(P, 4, generator=g)
     raw = np.zeros((P, 4), np.float32)
-    save = np.full(ML.save_floats(P), np.nan, np.float32)
-    H.call("scnerf_mlp_fwd", pts.numpy(), vd.numpy(), 3, spr, wpk, raw, save, P, None)
+    save = np.full(lay.save_floats(P), np.nan, np.float32)
+    H.call("scnerf_mlp_fwd", pd, pts.numpy(), vd.numpy(), 3, spr, wpk, raw, save, P, None)
     grads = np.full(ML.grad_floats(P), np.nan, np.float32)
-    d_pts = np.full((P, 3), np.nan, np.float32)
+    d_pts = np.full((P, pd), np.nan, np.float32)
     d_views = np.full((P, 3), np.nan, np.float32)
-    H.call("scnerf_mlp_bwd", d_raw.numpy(), pts.numpy(), vd.numpy(), 3, spr, wbk, save, grads, d_pts, d_views, P, None)
+    H.call("scnerf_mlp_bwd", pd, d_raw.numpy(), pts.numpy(), vd.numpy(), 3, spr, wbk, save, grads, d_pts, d_views, P, None)
     ref = oracle_backward(p, pts, vd, spr, d_raw)
     gv = grad_views(grads, P)
 
@@ -79,35 +81,37 @@ def test_mlp_dgrad_matches_autograd(n_rays, spr):
     close(d_views.reshape(n_rays, spr, 3).sum(1), ref["d_vd"].numpy(), "d_viewdirs")
 
 
-def test_full_network_weight_gradients_match_autograd():
+@pytest.mark.parametrize("pd", [3, 4])
+def test_full_network_weight_gradients_match_autograd(pd):
     """fwd (train) -> dgrad -> scnerf_nerf_wgrad: every parameter gradient of the network."""
-    p = {k: v.clone().requires_grad_(True) for k, v in synth.network_params(seed=4).items()}
-    pd = {k: v.detach() for k, v in p.items()}
-    wpk, wbk = pack_forward(pd), pack_backward(pd)
+    lay = ML.layout(pd)
+    p = {k: v.clone().requires_grad_(True) for k, v in network_params(4 if pd == 3 else 779, pd).items()}
+    pdet = {k: v.detach() for k, v in p.items()}
+    wpk, wbk = pack_forward(pdet, pd), pack_backward(pdet, pd)
     n_rays, spr = 3, 50
     P = n_rays * spr
     g = torch.Generator().manual_seed(12)
-    pts = torch.rand(P, 3, generator=g) * 2.4 - 1.2
+    pts = torch.rand(P, pd, generator=g) * 2.4 - 1.2
     vd = torch.randn(n_rays, 3, generator=g)
     vd = vd / vd.norm(dim=-1, keepdim=True)
     d_raw = torch.randn(P, 4, generator=g)
     raw = np.zeros((P, 4), np.float32)
-    save = np.full(ML.save_floats(P), np.nan, np.float32)
-    H.call("scnerf_mlp_fwd", pts.numpy(), vd.numpy(), 3, spr, wpk, raw, save, P, None)
+    save = np.full(lay.save_floats(P), np.nan, np.float32)
+    H.call("scnerf_mlp_fwd", pd, pts.numpy(), vd.numpy(), 3, spr, wpk, raw, save, P, None)
     grads = np.full(ML.grad_floats(P), np.nan, np.float32)
-    d_pts = np.zeros((P, 3), np.float32)
+    d_pts = np.zeros((P, pd), np.float32)
     d_views = np.zeros((P, 3), np.float32)
-    H.call("scnerf_mlp_bwd", d_raw.numpy(), pts.numpy(), vd.numpy(), 3, spr, wbk, save, grads, d_pts, d_views, P, None)
+    H.call("scnerf_mlp_bwd", pd, d_raw.numpy(), pts.numpy(), vd.numpy(), 3, spr, wbk, save, grads, d_pts, d_views, P, None)
     chunks = 3
     ws = np.full(H.lib().scnerf_nerf_wgrad_workspace_floats(chunks), np.nan, np.float32)
-    flat = np.full(ML.N_PARAMS, np.nan, np.float32)
-    assert H.lib().scnerf_nerf_param_count() == ML.N_PARAMS
-    H.call("scnerf_nerf_wgrad", save, grads, d_raw.numpy(), P, chunks, ws, flat, None)
-    out = O.query_network(p, pts.reshape(n_rays, spr, 3), vd).reshape(P, 4)
+    flat = np.full(lay.n_params, np.nan, np.float32)
+    assert H.lib().scnerf_nerf_param_count(pd) == lay.n_params
+    H.call("scnerf_nerf_wgrad", pd, save, grads, d_raw.numpy(), P, chunks, ws, flat, None)
+    out = O.query_network(p, pts.reshape(n_rays, spr, pd), vd).reshape(P, 4)
     (out * d_raw).sum().backward()
     assert not np.isnan(flat).any()
-    for name, shape in ML.PARAM_SHAPES:
-        o = ML.PARAM_OFFSETS[name]
+    for name, shape in lay.param_shapes:
+        o = lay.param_offsets[name]
         got = flat[o:o + int(np.prod(shape))].reshape(shape)
         ref = p[name].grad.numpy()
         scale = float(np.abs(ref).max()) + 1e-12

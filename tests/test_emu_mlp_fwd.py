@@ -7,35 +7,45 @@ from oracle import scnerf_oracle as O
 from scnerf_amd import mlp_layout as ML
 from scnerf_amd import synthetic as synth
 from tests.emu import harness as H
-from tests.emu_mlp_util import pack_forward, save_views, oracle_activations
+from tests.emu_mlp_util import network_params, pack_forward, save_views, oracle_activations
 
 pytestmark = pytest.mark.emu
 
 
-def test_layout_constants_match_kernel():
+PDS = [3, 4]
+
+
+@pytest.mark.parametrize("pd", PDS)
+def test_layout_constants_match_kernel(pd):
+    lay = ML.layout(pd)
     out = np.zeros(32, np.int32)
-    H.call("scnerf_mlp_layout_info", out, 32)
-    exp = [ML.FWD_STREAM, ML.FWD_BIAS, ML.FWD_BIAS_F, ML.FWD_BIAS_V, ML.FWD_BIAS_RGB, ML.FWD_ALPHA_W,
-           ML.FWD_ALPHA_B, ML.FWD_TOTAL, ML.BWD_STREAM, ML.BWD_ALPHA_W, ML.BWD_TOTAL,
-           ML.SAVE_FLOATS_PER_SAMPLE, ML.GRAD_FLOATS_PER_SAMPLE]
+    H.call("scnerf_mlp_layout_info", pd, out, 32)
+    exp = [lay.fwd_stream, lay.fwd_bias, lay.fwd_bias_f, lay.fwd_bias_v, lay.fwd_bias_rgb, lay.fwd_alpha_w,
+           lay.fwd_alpha_b, lay.fwd_total, lay.bwd_stream, lay.bwd_alpha_w, lay.bwd_total,
+           lay.save_floats_per_sample, ML.GRAD_FLOATS_PER_SAMPLE]
     assert out[:len(exp)].tolist() == exp
-    so, _ = ML.section_offsets(ML.SAVE_SECTIONS, 128)       # offsets per padded sample
+    so, _ = ML.section_offsets(lay.save_sections, 128)       # offsets per padded sample
     go, _ = ML.section_offsets(ML.GRAD_SECTIONS, 128)
     assert out[13:19].tolist() == [so[k] // 128 for k in ("feat", "hv", "epts", "eviews")] + [go[k] // 128 for k in ("dfeat", "dzv")]
     assert int(out[19]) == ML.MASK_WORDS_PER_SAMPLE
-    assert ML.N_PARAMS == 595844
+    assert int(out[20]) == lay.n_params == {3: 595844, 4: 606596}[pd] == H.lib().scnerf_nerf_param_count(pd)
+    assert int(out[21]) == lay.e_width
+    for P in (1, 128, 4097):
+        assert H.lib().scnerf_mlp_save_floats(pd, P) == lay.save_floats(P)
 
 
-def test_forward_index_is_a_permutation_of_the_weights():
-    idx = ML.forward_index()
+@pytest.mark.parametrize("pd", PDS)
+def test_forward_index_is_a_permutation_of_the_weights(pd):
+    lay = ML.layout(pd)
+    idx = lay.forward_index()
     used = idx[idx >= 0]
     # every parameter is referenced exactly once by the forward buffer
-    cnt = np.bincount(used, minlength=ML.N_PARAMS)
+    cnt = np.bincount(used, minlength=lay.n_params)
     assert cnt.min() == 1 and cnt.max() == 1
-    bidx = ML.backward_index()
-    cntb = np.bincount(bidx[bidx >= 0], minlength=ML.N_PARAMS)
-    po = ML.PARAM_OFFSETS
-    for name, shape in ML.PARAM_SHAPES:
+    bidx = lay.backward_index()
+    cntb = np.bincount(bidx[bidx >= 0], minlength=lay.n_params)
+    po = lay.param_offsets
+    for name, shape in lay.param_shapes:
         sl = slice(po[name], po[name] + int(np.prod(shape)))
         if name.endswith(".weight"):
             # alpha_linear.weight appears once in the dgrad stream too (VALU table)
@@ -44,26 +54,32 @@ def test_forward_index_is_a_permutation_of_the_weights():
             assert cntb[sl].max() == 0, name
 
 
+@pytest.mark.parametrize("pd", PDS)
 @pytest.mark.parametrize("n_rays,spr,save", [(5, 32, True), (3, 64, False)])
-def test_mlp_forward_matches_oracle(n_rays, spr, save):
-    p = synth.network_params(seed=0)
-    wpk = pack_forward(p)
+def test_mlp_forward_matches_oracle(n_rays, spr, save, pd):
+    """pd = 3: the SCNeRF network vs the NeRF oracle; pd = 4: NeRF++'s background net (4-D points) --
+    the same oracle formulas apply, its parameters being the NeRF layers under other names."""
+    lay = ML.layout(pd)
+    IN = lay.in_pts
+    p = network_params(0 if pd == 3 else 777, pd)
+    wpk = pack_forward(p, pd)
     P = n_rays * spr           # 160: one full workgroup + a ragged one;  192: 1.5 workgroups
     g = torch.Generator().manual_seed(3)
-    pts = (torch.rand(P, 3, generator=g) * 3 - 1.5)
+    pts = (torch.rand(P, pd, generator=g) * 3 - 1.5)
     vd = torch.randn(n_rays, 3, generator=g)
     vd = vd / vd.norm(dim=-1, keepdim=True)
     raw = np.full((P, 4), np.nan, np.float32)
-    sv = np.full(ML.save_floats(P), np.nan, np.float32) if save else None
-    H.call("scnerf_mlp_fwd", pts.numpy(), vd.numpy(), 3, spr, wpk, raw, sv, P, None)
-    ref = O.query_network(p, pts.reshape(n_rays, spr, 3), vd).reshape(P, 4)
+    sv = np.full(lay.save_floats(P), np.nan, np.float32) if save else None
+    H.call("scnerf_mlp_fwd", pd, pts.numpy(), vd.numpy(), 3, spr, wpk, raw, sv, P, None)
+    ref = O.query_network(p, pts.reshape(n_rays, spr, pd), vd).reshape(P, 4)
     np.testing.assert_allclose(raw, ref.numpy(), rtol=2e-5, atol=2e-5)
     if save:
         vps = vd[:, None, :].expand(n_rays, spr, 3).reshape(P, 3)
         oa = oracle_activations(p, pts, vps)
-        s = save_views(sv, P)
-        np.testing.assert_allclose(s["epts"][:, :63], oa["e"].numpy(), rtol=0, atol=2e-6)
-        assert np.all(s["epts"][:, 63] == 0)
+        s = save_views(sv, P, pd)
+        assert s["epts"].shape[1] == lay.e_width
+        np.testing.assert_allclose(s["epts"][:, :IN], oa["e"].numpy(), rtol=0, atol=2e-6)
+        assert np.all(s["epts"][:, IN:] == 0)
         np.testing.assert_allclose(s["eviews"][:, :27], oa["ev"].numpy(), rtol=0, atol=2e-6)
         assert np.all(s["eviews"][:, 27:] == 0)
         for l in range(8):

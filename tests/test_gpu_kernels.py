@@ -86,35 +86,84 @@ def test_fine_sample_bit_exact(ops, sc, sf, det, n):
     np.testing.assert_allclose(z_std.cpu().numpy(), torch.std(so, -1, unbiased=False).numpy(), rtol=1e-5, atol=1e-8)
 
 
-def _flat(p):
-    return torch.cat([p[name].reshape(-1) for name, _ in ML.PARAM_SHAPES])
+def _flat(p, pd=3):
+    return torch.cat([p[name].reshape(-1) for name, _ in ML.layout(pd).param_shapes])
 
 
+@pytest.mark.parametrize("pd", [3, 4])
 @pytest.mark.parametrize("n_rays,spr,save", [(37, 64, True), (16, 192, False)])
-def test_mlp_forward_matches_oracle(ops, n_rays, spr, save):
-    from tests.emu_mlp_util import oracle_activations
-    p = synth.network_params(seed=0)
-    wpk = ops.pack_weights(dev(_flat(p)), "fwd")
-    idx = ML.forward_index()
-    src = _flat(p).numpy()
+def test_mlp_forward_matches_oracle(ops, n_rays, spr, save, pd):
+    """pd = 3: the SCNeRF network; pd = 4: NeRF++'s background network (points x, y, z, 1/r)."""
+    from tests.emu_mlp_util import network_params, oracle_activations
+    lay = ML.layout(pd)
+    p = network_params(0 if pd == 3 else 777, pd)
+    wpk = ops.pack_weights(dev(_flat(p, pd)), "fwd", pd=pd)
+    idx = lay.forward_index()
+    src = _flat(p, pd).numpy()
     np.testing.assert_array_equal(wpk.cpu().numpy(), np.where(idx >= 0, src[np.maximum(idx, 0)], 0).astype(np.float32))
     P = n_rays * spr
     g = torch.Generator().manual_seed(3)
-    pts = torch.rand(P, 3, generator=g) * 3 - 1.5
+    pts = torch.rand(P, pd, generator=g) * 3 - 1.5
     vd = torch.randn(n_rays, 3, generator=g)
     vd = vd / vd.norm(dim=-1, keepdim=True)
-    sv = torch.full((ML.save_floats(P),), float("nan"), device="cuda") if save else None
-    raw = ops.mlp_fwd(dev(pts), dev(vd), spr, wpk, sv).cpu()
-    ref = O.query_network(p, pts.reshape(n_rays, spr, 3), vd).reshape(P, 4)
+    sv = torch.full((lay.save_floats(P),), float("nan"), device="cuda") if save else None
+    raw = ops.mlp_fwd(dev(pts), dev(vd), spr, wpk, sv, pd=pd).cpu()
+    ref = O.query_network(p, pts.reshape(n_rays, spr, pd), vd).reshape(P, 4)
     np.testing.assert_allclose(raw.numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
     if save:
         from tests.emu_mlp_util import save_views
         vps = vd[:, None, :].expand(n_rays, spr, 3).reshape(P, 3)
         oa = oracle_activations(p, pts, vps)
-        s = save_views(sv.cpu().numpy(), P)
-        np.testing.assert_allclose(s["epts"][:, :63], oa["e"].numpy(), rtol=0, atol=2e-6)
+        s = save_views(sv.cpu().numpy(), P, pd)
+        np.testing.assert_allclose(s["epts"][:, :lay.in_pts], oa["e"].numpy(), rtol=0, atol=2e-6)
+        assert np.all(s["epts"][:, lay.in_pts:] == 0)
         np.testing.assert_allclose(s["eviews"][:, :27], oa["ev"].numpy(), rtol=0, atol=2e-6)
         for l in range(8):
             np.testing.assert_allclose(s["act%d" % l], oa["acts"][l].numpy(), rtol=2e-5, atol=2e-5)
         np.testing.assert_allclose(s["feat"], oa["feat"].numpy(), rtol=2e-5, atol=2e-5)
         np.testing.assert_allclose(s["hv"], oa["hv"].numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("pd", [3, 4])
+def test_mlp_backward_and_weight_gradients_match_autograd(ops, pd):
+    """train forward -> dgrad -> 12 wgrad GEMMs for both network variants vs torch autograd on the oracle."""
+    from tests.emu_mlp_util import network_params
+    lay = ML.layout(pd)
+    p = {k: v.clone().requires_grad_(True) for k, v in network_params(4 if pd == 3 else 779, pd).items()}
+    flat = dev(_flat({k: v.detach() for k, v in p.items()}, pd))
+    n_rays, spr = 21, 50                       # 1050 samples: ragged last workgroup
+    P = n_rays * spr
+    g = torch.Generator().manual_seed(12)
+    pts = (torch.rand(P, pd, generator=g) * 2.4 - 1.2).requires_grad_(True)
+    vd = torch.randn(n_rays, 3, generator=g)
+    vd = (vd / vd.norm(dim=-1, keepdim=True)).requires_grad_(True)
+    d_raw = torch.randn(P, 4, generator=g)
+    save = ops.save_workspace(P, "cuda", pd)
+    raw = ops.mlp_fwd(dev(pts.detach()), dev(vd.detach()), spr, ops.pack_weights(flat, "fwd", pd=pd), save, pd=pd)
+    grads, d_pts, d_views = ops.mlp_bwd(dev(d_raw), dev(pts.detach()), dev(vd.detach()), spr,
+                                        ops.pack_weights(flat, "bwd", pd=pd), save, pd=pd)
+    fg = ops.nerf_wgrad(save, grads, dev(d_raw), P, pd=pd).cpu().numpy()
+    out = O.query_network(p, pts.reshape(n_rays, spr, pd), vd).reshape(P, 4)
+    np.testing.assert_allclose(raw.cpu().numpy(), out.detach().numpy(), rtol=2e-5, atol=2e-5)
+    (out * d_raw).sum().backward()
+
+    def close(a, b, tol, what):
+        scale = float(np.abs(b).max()) + 1e-12
+        err = float(np.abs(a - b).max())
+        assert err <= tol * scale + 1e-6, "%s: err %g scale %g" % (what, err, scale)
+    # A pre-activation within an ulp of zero can land on the other side of the ReLU than on the CPU; that
+    # sample's point gradient (amplified 2^9 by the encoding) then differs.  Per-sample: nearly all rows
+    # tight; sums over samples (view / weight gradients): loose.
+    ref_pts = pts.grad.numpy()
+    row_err = np.abs(d_pts.cpu().numpy() - ref_pts).max(1)
+    assert (row_err <= 1e-4 * np.abs(ref_pts).max() + 1e-6).mean() >= 0.99, (row_err > 1e-4 * np.abs(ref_pts).max()).sum()
+    def grad_close(a, b, what, q=0.999, tol_q=1e-3, tol_max=5e-2):
+        scale = float(np.abs(b).max()) + 1e-12
+        err = np.abs(a - b).reshape(-1)
+        assert np.quantile(err, q) <= tol_q * scale + 1e-7 and err.max() <= tol_max * scale + 1e-6, \
+            "%s: q%.3f err %g, max err %g, scale %g" % (what, q, np.quantile(err, q), err.max(), scale)
+    grad_close(d_views.cpu().numpy().reshape(n_rays, spr, 3).sum(1), vd.grad.numpy(), "d_views", q=0.9, tol_q=2e-3)
+    assert np.isfinite(fg).all()
+    for name, shape in lay.param_shapes:
+        o = lay.param_offsets[name]
+        grad_close(fg[o:o + int(np.prod(shape))].reshape(shape), p[name].grad.numpy(), name, q=0.99, tol_q=2e-3)
