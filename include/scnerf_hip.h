@@ -240,6 +240,64 @@ int scnerf_prd_loss_bwd(const float* kps0, const float* kps1, const float* rays0
                         const float* g_loss, float* g_rays0_o, float* g_rays0_d, float* g_rays1_o,
                         float* g_rays1_d, float* g_K, float* g_E2, float* workspace36, void* stream);
 
+/* ------------------------------------------------------------------ NeRF++ ----------- */
+/* The per-ray pieces of the NeRF++ path around the fused networks; the foreground
+ * network is scnerf_mlp_* with pt_dims = 3, the background one with pt_dims = 4. */
+
+/* intersect_sphere (nerfplusplus/ddp_train_nerf.py:50-68): depth at which each ray leaves the unit
+ * sphere.  *outside_flag (optional device int, zeroed by the caller) is set when a ray's closest
+ * point to the centre lies outside the sphere -- the reference raises there (:60-64).  _bwd: what
+ * autograd derives (gradients to ray_o, ray_d). */
+int scnerf_npp_intersect_fwd(const float* ray_o, const float* ray_d, float* far, int* outside_flag, int n,
+                             void* stream);
+int scnerf_npp_intersect_bwd(const float* ray_o, const float* ray_d, const float* g_far, float* g_ray_o,
+                             float* g_ray_d, int n, void* stream);
+
+/* perturb_samples (ddp_train_nerf.py:71-80) with the uniforms t_rand [n,s] supplied by the caller:
+ * out = lower + (upper - lower) t, lower / upper the mid points to the neighbours; _bwd: d z. */
+int scnerf_npp_perturb_fwd(const float* z, const float* t_rand, float* out, int n, int s, void* stream);
+int scnerf_npp_perturb_bwd(const float* g_out, const float* t_rand, float* g_z, int n, int s, void* stream);
+
+/* sample_pdf of NeRF++ (ddp_train_nerf.py:83-132): bins [n,m+1], weights [n,m] (+1e-6, normalised,
+ * cumulated with a leading 0), u [n,ns]; upper index = count of cdf[0..m-1] <= u (:113), denominators
+ * under 1e-6 -> 1, bin width + 1e-6 (:130).  below_above (int, lower | upper << 16) and t [n,ns] are
+ * optional outputs for _bwd, which returns d bins [n,m+1] (the weights are detached by the caller). */
+int scnerf_npp_sample_pdf(const float* bins, const float* weights, const float* u, float* samples,
+                          int* below_above, float* t, int n, int m, int ns, void* stream);
+int scnerf_npp_sample_pdf_bwd(const float* g_samples, const int* below_above, const float* t, float* g_bins,
+                              int n, int m, int ns, void* stream);
+
+/* Sample placement of NerfNet.forward (nerfplusplus/ddp_model.py:80-89, :105-114): fg_pts [n,sf,3] =
+ * o + z d; bg_pts [n,sb,4] = depth2pts_outside (:16-45) of bg_z in FLIPPED order (the network sees the
+ * background far -> near); viewdirs [n,3] = d / |d|.  _bwd: gradients of the two point sets, of the
+ * per-sample view directions of both networks and of |d| (scnerf_npp_composite_bwd) summed into d ray_o,
+ * d ray_d [n,3]; d fg_z [n,sf] = d_fg_pts . d + g_fg_z_in (optional).  The inverse radii bg_z carry no
+ * gradient (they never depend on learnable quantities). */
+int scnerf_npp_points_fwd(const float* ray_o, const float* ray_d, const float* fg_z, const float* bg_z,
+                          float* fg_pts, float* bg_pts, float* viewdirs, int n, int sf, int sb, void* stream);
+int scnerf_npp_points_bwd(const float* ray_o, const float* ray_d, const float* fg_z, const float* bg_z,
+                          const float* d_fg_pts, const float* d_bg_pts, const float* d_views_fg,
+                          const float* d_views_bg, const float* d_norm, const float* g_fg_z_in,
+                          float* g_ray_o, float* g_ray_d, float* g_fg_z, int n, int sf, int sb, void* stream);
+
+/* Compositing of NerfNet.forward (ddp_model.py:90-143) from the raw network outputs (rgb logits, sigma
+ * before abs -- MLPNet's sigmoid / abs, nerf_network.py:133,140, are applied here): foreground intervals
+ * scaled by |ray_d| with the last reaching fg_z_max, T = cumprod(1 - alpha + 1e-6), bg_lambda = T behind
+ * the last sample; background over the flipped inverse radii with a 1e10 last interval; bg_rgb /
+ * bg_depth already scaled by bg_lambda; rgb = fg_rgb + bg_rgb.  raw_bg / bg_weights are in the flipped
+ * (network) order, bg_z in the caller's ascending order.  _bwd: any incoming gradient may be NULL;
+ * returns d raw of both networks, d fg_z, d fg_z_max, d |ray_d|. */
+int scnerf_npp_composite_fwd(const float* raw_fg, const float* raw_bg, const float* fg_z, const float* fg_z_max,
+                             const float* bg_z, const float* ray_d, float* rgb, float* fg_weights,
+                             float* bg_weights, float* fg_rgb, float* fg_depth, float* bg_rgb, float* bg_depth,
+                             float* bg_lambda, int n, int sf, int sb, void* stream);
+int scnerf_npp_composite_bwd(const float* raw_fg, const float* raw_bg, const float* fg_z, const float* fg_z_max,
+                             const float* bg_z, const float* ray_d, const float* g_rgb, const float* g_fg_weights,
+                             const float* g_bg_weights, const float* g_fg_rgb, const float* g_fg_depth,
+                             const float* g_bg_rgb, const float* g_bg_depth, const float* g_bg_lambda,
+                             float* d_raw_fg, float* d_raw_bg, float* d_fg_z, float* d_fg_z_max, float* d_norm,
+                             int n, int sf, int sb, void* stream);
+
 /* ------------------------------------------------------------------ optimizer -------- */
 
 /* One Adam step over a flat fp32 segment (f_custom_adam / torch.optim.Adam without amsgrad,

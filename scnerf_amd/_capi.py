@@ -35,6 +35,16 @@ PROTOTYPES = {
     "scnerf_upsample_grid_bwd": [P, F, I, I, I, I, P, P],
     "scnerf_prd_loss_fwd": [P, P, P, P, P, P, P, P, F, F, I, I, I, P, P, P, P],
     "scnerf_prd_loss_bwd": [P, P, P, P, P, P, P, P, F, F, I, I, P, P, P, P, P, P, P, P, P, P],
+    "scnerf_npp_intersect_fwd": [P, P, P, P, I, P],
+    "scnerf_npp_intersect_bwd": [P, P, P, P, P, I, P],
+    "scnerf_npp_perturb_fwd": [P, P, P, I, I, P],
+    "scnerf_npp_perturb_bwd": [P, P, P, I, I, P],
+    "scnerf_npp_sample_pdf": [P, P, P, P, P, P, I, I, I, P],
+    "scnerf_npp_sample_pdf_bwd": [P, P, P, P, I, I, I, P],
+    "scnerf_npp_points_fwd": [P, P, P, P, P, P, P, I, I, I, P],
+    "scnerf_npp_points_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "scnerf_npp_composite_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "scnerf_npp_composite_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],
     "scnerf_adam_step": [P, P, P, P, LL, D, D, D, D, D, LL, P],
     "scnerf_composite_fwd": [P, P, P, I, P, I, P, P, P, P, P, I, I, P],
     "scnerf_composite_bwd": [P, P, P, I, P, I, P, P, P, P, P, P, P, I, I, P],

@@ -1,0 +1,208 @@
+"""NeRF++ per-ray kernels (HIP source under the CPU SIMT interpreter) vs golden vectors of the
+reference's nerfplusplus/ code and the reference-pinned oracle (autograd for the backward passes)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerfpp_oracle as NO
+from tests.emu import harness as H
+from test_nerfpp_oracle import G, T
+
+pytestmark = pytest.mark.emu
+
+
+def close(a, b, tol, what, atol=0.0):
+    b = b.detach().numpy() if torch.is_tensor(b) else np.asarray(b)
+    scale = float(np.abs(b).max()) + 1e-30
+    err = float(np.abs(a - b).max())
+    assert np.isfinite(a).all(), what
+    assert err <= tol * scale + atol, "%s: err %g scale %g" % (what, err, scale)
+
+
+def test_intersect_sphere_fwd_bwd():
+    o, d = G["kat/ray_o"], G["kat/ray_d"]
+    n = o.shape[0]
+    far = np.full(n, np.nan, np.float32)
+    flag = np.zeros(1, np.int32)
+    H.call("scnerf_npp_intersect_fwd", o, d, far, flag, n, None)
+    np.testing.assert_allclose(far, G["kat/far"], rtol=2e-6)
+    assert flag[0] == 0
+    o_out = (o * 3.0).astype(np.float32)          # cameras outside the unit sphere: flagged (the reference raises)
+    H.call("scnerf_npp_intersect_fwd", o_out, d, far.copy(), flag, n, None)
+    assert flag[0] == 1
+    to, td = torch.tensor(o, requires_grad=True), torch.tensor(d, requires_grad=True)
+    g = torch.randn(n, generator=torch.Generator().manual_seed(1))
+    (NO.intersect_sphere(to, td) * g).sum().backward()
+    go, gd = np.full((n, 3), np.nan, np.float32), np.full((n, 3), np.nan, np.float32)
+    H.call("scnerf_npp_intersect_bwd", o, d, g.numpy(), go, gd, n, None)
+    close(go, to.grad, 2e-5, "g_o")
+    close(gd, td.grad, 2e-5, "g_d")
+
+
+def test_perturb_samples_fwd_bwd():
+    z, t = G["kat/z"], G["kat/t_rand"]
+    n, s = z.shape
+    out = np.full((n, s), np.nan, np.float32)
+    H.call("scnerf_npp_perturb_fwd", z, t, out, n, s, None)
+    np.testing.assert_array_equal(out, G["kat/perturbed"])
+    tz = torch.tensor(z, requires_grad=True)
+    g = torch.randn(n, s, generator=torch.Generator().manual_seed(2))
+    (NO.perturb_samples(tz, torch.tensor(t)) * g).sum().backward()
+    gz = np.full((n, s), np.nan, np.float32)
+    H.call("scnerf_npp_perturb_bwd", g.numpy(), t, gz, n, s, None)
+    close(gz, tz.grad, 2e-6, "g_z")
+    one = np.full((3, 1), 0.7, np.float32)                    # a single sample: lower = upper = z
+    H.call("scnerf_npp_perturb_fwd", one, np.full((3, 1), 0.3, np.float32), one_out := np.zeros((3, 1), np.float32), 3, 1, None)
+    np.testing.assert_array_equal(one_out, one)
+
+
+@pytest.mark.parametrize("key,ukey", [("kat/pdf_samples", "kat/u"), ("kat/pdf_det", None)])
+def test_sample_pdf_matches_reference(key, ukey):
+    bins, w = G["kat/bins"], G["kat/weights"]
+    n, m = w.shape
+    u = G[ukey] if ukey else np.ascontiguousarray(np.broadcast_to(torch.linspace(0.0, 1.0, 40).numpy(), (n, 40)))
+    ns = u.shape[1]
+    out = np.full((n, ns), np.nan, np.float32)
+    ba = np.full((n, ns), -1, np.int32)
+    t = np.full((n, ns), np.nan, np.float32)
+    H.call("scnerf_npp_sample_pdf", bins, w, u, out, ba, t, n, m, ns, None)
+    ref = G[key]
+    e = np.abs(out - ref)
+    # bit-exact except where u sits within an ulp of a cdf knot (the count flips between two bins whose
+    # interpolants agree there up to the knot spacing): none expected on these vectors
+    assert (e == 0).mean() > 0.999, (e == 0).mean()
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-6)
+    below, above = ba & 0xffff, ba >> 16
+    assert below.min() >= 0 and above.max() <= m and np.all((above - below <= 1))
+    # backward w.r.t. the bins vs autograd on the oracle
+    tb = torch.tensor(bins, requires_grad=True)
+    g = torch.randn(n, ns, generator=torch.Generator().manual_seed(3))
+    (NO.sample_pdf(tb, torch.tensor(w), torch.tensor(u)) * g).sum().backward()
+    gb = np.full((n, m + 1), np.nan, np.float32)
+    H.call("scnerf_npp_sample_pdf_bwd", g.numpy(), ba, t, gb, n, m, ns, None)
+    close(gb, tb.grad, 1e-5, "g_bins")
+
+
+def test_points_fwd_bwd():
+    o, d = G["kat/ray_o"], G["kat/ray_d"]
+    n = o.shape[0]
+    depth = G["kat/bg_depth"]                        # [n, 16] inverse radii (not sorted: order is irrelevant here)
+    sb = depth.shape[1]
+    gen = torch.Generator().manual_seed(5)
+    sf = 70                                          # more than one pass of 64
+    fg_z = torch.sort(torch.rand(n, sf, generator=gen), -1)[0].numpy()
+    fg_pts = np.full((n, sf, 3), np.nan, np.float32)
+    bg_pts = np.full((n, sb, 4), np.nan, np.float32)
+    vd = np.full((n, 3), np.nan, np.float32)
+    H.call("scnerf_npp_points_fwd", o, d, fg_z, depth, fg_pts, bg_pts, vd, n, sf, sb, None)
+    np.testing.assert_allclose(bg_pts[:, ::-1], G["kat/bg_pts"], rtol=1e-5, atol=2e-6)     # stored flipped
+    np.testing.assert_allclose(fg_pts, o[:, None] + fg_z[..., None] * d[:, None], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(vd, d / np.linalg.norm(d, axis=-1, keepdims=True), rtol=1e-6)
+
+    to, td = torch.tensor(o, requires_grad=True), torch.tensor(d, requires_grad=True)
+    tz = torch.tensor(fg_z, requires_grad=True)
+    g_fg = torch.randn(n, sf, 3, generator=gen)
+    g_bg = torch.randn(n, sb, 4, generator=gen)
+    g_vf = torch.randn(n, sf, 3, generator=gen) * 0.1
+    g_vb = torch.randn(n, sb, 3, generator=gen) * 0.1
+    g_norm = torch.randn(n, generator=gen)
+    g_zin = torch.randn(n, sf, generator=gen)
+    pts_b, _ = NO.depth2pts_outside(to[:, None].expand(n, sb, 3), td[:, None].expand(n, sb, 3), torch.tensor(depth))
+    pts_b = torch.flip(pts_b, dims=[-2])
+    pts_f = to[:, None] + tz[..., None] * td[:, None]
+    norm = torch.norm(td, dim=-1)
+    view = td / norm[:, None]
+    loss = (pts_f * g_fg).sum() + (pts_b[..., :3] * g_bg[..., :3]).sum() + (view[:, None] * g_vf).sum() \
+        + (view[:, None] * g_vb).sum() + (norm * g_norm).sum() + (tz * g_zin).sum()
+    loss.backward()
+    go, gd = np.full((n, 3), np.nan, np.float32), np.full((n, 3), np.nan, np.float32)
+    gz = np.full((n, sf), np.nan, np.float32)
+    H.call("scnerf_npp_points_bwd", o, d, fg_z, depth, g_fg.numpy(), g_bg.numpy(), g_vf.numpy(), g_vb.numpy(),
+           g_norm.numpy(), g_zin.numpy(), go, gd, gz, n, sf, sb, None)
+    close(go, to.grad, 2e-4, "g_o")
+    close(gd, td.grad, 2e-4, "g_d")
+    close(gz, tz.grad, 1e-5, "g_fg_z")
+
+
+def _composite_inputs(n=23, sf=70, sb=40, seed=7):
+    gen = torch.Generator().manual_seed(seed)
+    raw_fg = torch.randn(n, sf, 4, generator=gen)
+    raw_bg = torch.randn(n, sb, 4, generator=gen)
+    raw_fg[..., 3] *= 4.0
+    raw_fg[0, 3, 3] = 0.0                         # |x| at 0: zero gradient, like torch.abs
+    fg_z = torch.sort(torch.rand(n, sf, generator=gen) * 2.0 + 0.05, -1)[0]
+    z_max = fg_z[:, -1] + torch.rand(n, generator=gen) * 0.2 + 0.01
+    bg_z = torch.sort(torch.rand(n, sb, generator=gen), -1)[0]
+    rd = torch.randn(n, 3, generator=gen)
+    return raw_fg, raw_bg, fg_z, z_max, bg_z, rd
+
+
+def _oracle_composite(raw_fg, raw_bg, fg_z, z_max, bg_z, rd):
+    """the compositing half of NerfNet.forward on given raw outputs (raw_bg in flipped order)"""
+    norm = torch.norm(rd, dim=-1, keepdim=True)
+    rgb, sigma = torch.sigmoid(raw_fg[..., :3]), torch.abs(raw_fg[..., 3])
+    dist = norm * torch.cat([fg_z[..., 1:] - fg_z[..., :-1], z_max[..., None] - fg_z[..., -1:]], -1)
+    alpha = 1.0 - torch.exp(-sigma * dist)
+    Tt = torch.cumprod(1.0 - alpha + NO.TINY, -1)
+    lam = Tt[..., -1]
+    Tt = torch.cat([torch.ones_like(Tt[..., :1]), Tt[..., :-1]], -1)
+    fw = alpha * Tt
+    f_rgb = (fw[..., None] * rgb).sum(-2)
+    f_depth = (fw * fg_z).sum(-1)
+    zf = torch.flip(bg_z, dims=[-1])
+    rgb_b, sig_b = torch.sigmoid(raw_bg[..., :3]), torch.abs(raw_bg[..., 3])
+    dist_b = torch.cat([zf[..., :-1] - zf[..., 1:], NO.HUGE * torch.ones_like(zf[..., :1])], -1)
+    alpha_b = 1.0 - torch.exp(-sig_b * dist_b)
+    Tb = torch.cumprod(1.0 - alpha_b + NO.TINY, -1)[..., :-1]
+    Tb = torch.cat([torch.ones_like(Tb[..., :1]), Tb], -1)
+    bw = alpha_b * Tb
+    b_rgb = lam[..., None] * (bw[..., None] * rgb_b).sum(-2)
+    b_depth = lam * (bw * zf).sum(-1)
+    return {"rgb": f_rgb + b_rgb, "fg_weights": fw, "bg_weights": bw, "fg_rgb": f_rgb, "fg_depth": f_depth,
+            "bg_rgb": b_rgb, "bg_depth": b_depth, "bg_lambda": lam}
+
+
+KEYS = ("rgb", "fg_weights", "bg_weights", "fg_rgb", "fg_depth", "bg_rgb", "bg_depth", "bg_lambda")
+
+
+def test_composite_fwd_bwd():
+    raw_fg, raw_bg, fg_z, z_max, bg_z, rd = _composite_inputs()
+    n, sf, sb = raw_fg.shape[0], raw_fg.shape[1], raw_bg.shape[1]
+    shapes = {"rgb": (n, 3), "fg_weights": (n, sf), "bg_weights": (n, sb), "fg_rgb": (n, 3), "fg_depth": (n,),
+              "bg_rgb": (n, 3), "bg_depth": (n,), "bg_lambda": (n,)}
+    out = {k: np.full(shapes[k], np.nan, np.float32) for k in KEYS}
+    H.call("scnerf_npp_composite_fwd", raw_fg.numpy(), raw_bg.numpy(), fg_z.numpy(), z_max.numpy(), bg_z.numpy(),
+           rd.numpy(), *[out[k] for k in KEYS], n, sf, sb, None)
+    leaves = [t.clone().requires_grad_(True) for t in (raw_fg, raw_bg, fg_z, z_max, rd)]
+    ref = _oracle_composite(leaves[0], leaves[1], leaves[2], leaves[3], bg_z, leaves[4])
+    for k in KEYS:
+        np.testing.assert_allclose(out[k], ref[k].detach().numpy(), rtol=2e-5, atol=2e-7, err_msg=k)
+    gen = torch.Generator().manual_seed(11)
+    gs = {k: torch.randn(shapes[k], generator=gen) for k in KEYS}
+    sum((ref[k] * gs[k]).sum() for k in KEYS).backward()
+    d_raw_fg = np.full((n, sf, 4), np.nan, np.float32)
+    d_raw_bg = np.full((n, sb, 4), np.nan, np.float32)
+    d_z = np.full((n, sf), np.nan, np.float32)
+    d_zmax = np.full(n, np.nan, np.float32)
+    d_norm = np.full(n, np.nan, np.float32)
+    H.call("scnerf_npp_composite_bwd", raw_fg.numpy(), raw_bg.numpy(), fg_z.numpy(), z_max.numpy(), bg_z.numpy(),
+           rd.numpy(), *[gs[k].numpy() for k in KEYS], d_raw_fg, d_raw_bg, d_z, d_zmax, d_norm, n, sf, sb, None)
+    close(d_raw_fg, leaves[0].grad, 2e-5, "d_raw_fg")
+    close(d_raw_bg, leaves[1].grad, 2e-5, "d_raw_bg")
+    close(d_z, leaves[2].grad, 5e-5, "d_fg_z")
+    close(d_zmax, leaves[3].grad, 2e-5, "d_z_max")
+    norm = torch.norm(rd, dim=-1)
+    close(d_norm, (leaves[4].grad * rd).sum(-1) / norm, 5e-5, "d_norm")       # rd enters only through |rd|
+    assert d_raw_fg[0, 3, 3] == 0.0
+
+    # only the loss-relevant gradient (rgb) supplied, the rest NULL
+    for t in leaves:
+        t.grad = None
+    ref = _oracle_composite(leaves[0], leaves[1], leaves[2], leaves[3], bg_z, leaves[4])
+    (ref["rgb"] * gs["rgb"]).sum().backward()
+    H.call("scnerf_npp_composite_bwd", raw_fg.numpy(), raw_bg.numpy(), fg_z.numpy(), z_max.numpy(), bg_z.numpy(),
+           rd.numpy(), gs["rgb"].numpy(), None, None, None, None, None, None, None, d_raw_fg, d_raw_bg, d_z, d_zmax,
+           d_norm, n, sf, sb, None)
+    close(d_raw_fg, leaves[0].grad, 2e-5, "d_raw_fg (rgb only)")
+    close(d_raw_bg, leaves[1].grad, 2e-5, "d_raw_bg (rgb only)")
+    close(d_z, leaves[2].grad, 5e-5, "d_fg_z (rgb only)")
