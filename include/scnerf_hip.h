@@ -298,6 +298,28 @@ int scnerf_npp_composite_bwd(const float* raw_fg, const float* raw_bg, const flo
                              float* d_raw_fg, float* d_raw_bg, float* d_fg_z, float* d_fg_z_max, float* d_norm,
                              int n, int sf, int sb, void* stream);
 
+/* render_ray_from_camera (nerfplusplus/nerf_sample_ray_split.py:196-257): rays of the
+ * row-major pixel indices select [n] (int64) through the CENTRES of those pixels, optional radial
+ * distortion dist2 = (k0, k1): p <- (p - c)(1 + r^2 k0 + r^4 k1) + c, r = (p - c) / c per axis (:225-232);
+ * K^-1 [u, v, 1] without axis flips; pose = camera `camera_idx` of the model, or the explicit c2w
+ * `extrinsic` [4,4] when non-NULL; the ray noise images sampled at the selected pixels; direction
+ * renormalised without an epsilon.  Camera-model arguments as scnerf_camera_rays_fwd.  _bwd additionally
+ * returns d dist2 [2]; workspace: scnerf_camera_bwd_workspace_floats(n_cams or 1). */
+int scnerf_npp_camera_rays_fwd(const long long* select, const float* dist2, int camera_idx,
+                               const float* extrinsic, const float* intr_init, const float* intr_noise,
+                               float intr_scale, int multiplicative, const float* extr_init,
+                               const float* extr_noise, float extr_scale, int n_cams, const float* grid_o,
+                               float scale_o, const float* grid_d, float scale_d, int gh, int gw, int H, int W,
+                               float* rays_o, float* rays_d, int n, void* stream);
+int scnerf_npp_camera_rays_bwd(const long long* select, const float* dist2, int camera_idx,
+                               const float* extrinsic, const float* intr_init, const float* intr_noise,
+                               float intr_scale, int multiplicative, const float* extr_init,
+                               const float* extr_noise, float extr_scale, int n_cams, const float* grid_o,
+                               float scale_o, const float* grid_d, float scale_d, int gh, int gw, int H, int W,
+                               const float* g_o, const float* g_d, float* d_intr_noise, float* d_extr_noise,
+                               float* d_grid_o, float* d_grid_d, float* d_extrinsic, float* d_dist2,
+                               float* workspace, int n, void* stream);
+
 /* ------------------------------------------------------------------ optimizer -------- */
 
 /* One Adam step over a flat fp32 segment (f_custom_adam / torch.optim.Adam without amsgrad,

@@ -45,6 +45,9 @@ PROTOTYPES = {
     "scnerf_npp_points_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],
     "scnerf_npp_composite_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],
     "scnerf_npp_composite_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "scnerf_npp_camera_rays_fwd": [P, P, I, P, P, P, F, I, P, P, F, I, P, F, P, F, I, I, I, I, P, P, I, P],
+    "scnerf_npp_camera_rays_bwd": [P, P, I, P, P, P, F, I, P, P, F, I, P, F, P, F, I, I, I, I, P, P, P, P, P, P, P,
+                                   P, P, I, P],
     "scnerf_adam_step": [P, P, P, P, LL, D, D, D, D, D, LL, P],
     "scnerf_composite_fwd": [P, P, P, I, P, I, P, P, P, P, P, I, I, P],
     "scnerf_composite_bwd": [P, P, P, I, P, I, P, P, P, P, P, P, P, I, I, P],

@@ -135,6 +135,9 @@ struct CamArgs {
     const float* extr_init; const float* extr_noise; float extr_scale; int n_cams;
     const float* grid_o; float scale_o; const float* grid_d; float scale_d; int gh, gw;
     int H, W, n;
+    // NeRF++ generator (render_ray_from_camera, nerfplusplus/nerf_sample_ray_split.py:196-257):
+    const long long* select;     // non-NULL selects it: row-major pixel indices, rays through pixel CENTRES
+    const float* dist;           // [2] radial distortion (k0, k1) or NULL
 };
 
 struct Intrinsics { float fx, fy, cx, cy; };
@@ -160,17 +163,38 @@ struct RayFwd {
     float x, y;
     int cam;
     GramSchmidt gs;
+    float ux, uy, rx, ry, sx, sy;      // NeRF++ distortion: offsets from the centre, r = u / c, scale 1 + r^2 k0 + r^4 k1
 };
 
 __device__ __forceinline__ void ray_forward(const CamArgs& a, int i, const Intrinsics& K, RayFwd* f, Vec3* ro,
                                             Vec3* rd) {
     float x, y;
-    if (a.kps) { x = a.kps[(size_t)i * 2]; y = a.kps[(size_t)i * 2 + 1]; }
-    else { x = (float)(i % a.W); y = (float)(i / a.W); }
-    f->x = x; f->y = y;
-    // dirs = [x, y, 1] K^-T with K^-1 = [[1/fx, 0, -cx/fx], [0, 1/fy, -cy/fy], [0, 0, 1]]  (get_rays.py:119-125)
+    int px = 0, py = 0;                  // pixel whose ray-noise sample is used
     const float ia = 1.f / K.fx, ic = -K.cx / K.fx, ib = 1.f / K.fy, id = -K.cy / K.fy;
-    f->dirs = v3(x * ia + ic, -(y * ib + id), -1.f);
+    if (a.select) {
+        const long long sel = a.select[i];
+        px = (int)(sel % a.W); py = (int)(sel / a.W);
+        x = (float)px + 0.5f; y = (float)py + 0.5f;                    // pixel centres (:220-221)
+        if (a.dist) {                                                   // (:225-232)
+            const float k0 = a.dist[0], k1 = a.dist[1];
+            f->ux = x - K.cx; f->uy = y - K.cy;
+            f->rx = f->ux / K.cx; f->ry = f->uy / K.cy;
+            const float rx2 = f->rx * f->rx, ry2 = f->ry * f->ry;
+            f->sx = 1.f + rx2 * k0 + rx2 * rx2 * k1;
+            f->sy = 1.f + ry2 * k0 + ry2 * ry2 * k1;
+            x = f->ux * f->sx + K.cx;
+            y = f->uy * f->sy + K.cy;
+        }
+        f->x = x; f->y = y;
+        f->dirs = v3(x * ia + ic, y * ib + id, 1.f);                    // K^-1 [u, v, 1], no axis flips (:234-243)
+    } else {
+        if (a.kps) { x = a.kps[(size_t)i * 2]; y = a.kps[(size_t)i * 2 + 1]; }
+        else { x = (float)(i % a.W); y = (float)(i / a.W); }
+        px = (int)x; py = (int)y;                                       // .long() truncation
+        f->x = x; f->y = y;
+        // dirs = [x, y, 1] K^-T with K^-1 = [[1/fx, 0, -cx/fx], [0, 1/fy, -cy/fy], [0, 0, 1]]  (get_rays.py:119-125)
+        f->dirs = v3(x * ia + ic, -(y * ib + id), -1.f);
+    }
     if (a.extrinsic) {
         const float* E = a.extrinsic + (size_t)(a.n_ext == 1 ? 0 : i) * 16;
         f->R.x = v3(E[0], E[4], E[8]);
@@ -193,13 +217,13 @@ __device__ __forceinline__ void ray_forward(const CamArgs& a, int i, const Intri
                 d.x * f->R.x.y + d.y * f->R.y.y + d.z * f->R.z.y,
                 d.x * f->R.x.z + d.y * f->R.y.z + d.z * f->R.z.z);
     Vec3 o = f->t;
-    if (a.grid_o || a.grid_d) f->taps = bilinear_taps((int)y, (int)x, a.gh, a.gw, a.H, a.W);   // .long() truncation
+    if (a.grid_o || a.grid_d) f->taps = bilinear_taps(py, px, a.gh, a.gw, a.H, a.W);
     if (a.grid_o) o = o + a.scale_o * sample_grid(a.grid_o, a.gw, f->taps);
     if (a.grid_d) {
         r = r + a.scale_d * sample_grid(a.grid_d, a.gw, f->taps);
         f->rd_raw = r;
         f->nrm = sqrtf(dot(r, r));
-        const float den = f->nrm + 1e-10f;
+        const float den = a.select ? f->nrm : f->nrm + 1e-10f;        // NeRF++ renormalises without an epsilon (:254)
         r = v3(r.x / den, r.y / den, r.z / den);
     }
     *ro = o;
@@ -222,9 +246,9 @@ __global__ __launch_bounds__(256) void camera_rays_fwd_kernel(CamArgs a, float* 
 // then per camera (or per explicit matrix) 12 floats: dR columns x, y, z (9) + dt (3).
 __global__ __launch_bounds__(256) void camera_rays_bwd_kernel(CamArgs a, const float* __restrict__ g_o,
                                                               const float* __restrict__ g_d, float* acc,
-                                                              float* d_grid_o, float* d_grid_d) {
+                                                              float* d_grid_o, float* d_grid_d, float* acc_dist) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    float gk[4] = {0.f, 0.f, 0.f, 0.f};
+    float gk[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // fx, fy, cx, cy, (k0, k1)
     if (i < a.n) {
         const Intrinsics K = intrinsics_of(a);
         RayFwd f;
@@ -233,7 +257,7 @@ __global__ __launch_bounds__(256) void camera_rays_bwd_kernel(CamArgs a, const f
         const Vec3 go = g_o ? v3(g_o[(size_t)i * 3], g_o[(size_t)i * 3 + 1], g_o[(size_t)i * 3 + 2]) : v3(0, 0, 0);
         Vec3 gr = g_d ? v3(g_d[(size_t)i * 3], g_d[(size_t)i * 3 + 1], g_d[(size_t)i * 3 + 2]) : v3(0, 0, 0);
         if (a.grid_d) {
-            const float den = f.nrm + 1e-10f;
+            const float den = a.select ? f.nrm : f.nrm + 1e-10f;
             Vec3 g = (1.f / den) * gr;
             if (f.nrm > 0.f) g = g - (dot(gr, f.rd_raw) / (den * den * f.nrm)) * f.rd_raw;
             gr = g;
@@ -250,18 +274,39 @@ __global__ __launch_bounds__(256) void camera_rays_bwd_kernel(CamArgs a, const f
         atomic_add(ar + 9, go.x); atomic_add(ar + 10, go.y); atomic_add(ar + 11, go.z);
         // dirs -> intrinsics
         const float gdx = dot(gr, f.R.x), gdy = dot(gr, f.R.y);
-        gk[0] = gdx * (-(f.x - K.cx) / (K.fx * K.fx));
-        gk[2] = gdx * (-1.f / K.fx);
-        gk[1] = gdy * ((f.y - K.cy) / (K.fy * K.fy));
-        gk[3] = gdy * (1.f / K.fy);
+        if (!a.select) {
+            gk[0] = gdx * (-(f.x - K.cx) / (K.fx * K.fx));
+            gk[2] = gdx * (-1.f / K.fx);
+            gk[1] = gdy * ((f.y - K.cy) / (K.fy * K.fy));
+            gk[3] = gdy * (1.f / K.fy);
+        } else {
+            // dirs_x = x' / fx - cx / fx,  dirs_y = y' / fy - cy / fy  (no sign flip)
+            gk[0] = gdx * (-(f.x - K.cx) / (K.fx * K.fx));
+            gk[1] = gdy * (-(f.y - K.cy) / (K.fy * K.fy));
+            float dxdc = 0.f, dydc = 0.f;                // d x' / d cx, d y' / d cy
+            if (a.dist) {
+                // x' = u s + c, u = p - c, r = u / c, s = 1 + r^2 k0 + r^4 k1
+                const float k0 = a.dist[0], k1 = a.dist[1];
+                const float px = f.ux + K.cx, py = f.uy + K.cy;          // the undistorted pixel centre
+                const float dsx = (2.f * f.rx * k0 + 4.f * f.rx * f.rx * f.rx * k1) * (-px / (K.cx * K.cx));
+                const float dsy = (2.f * f.ry * k0 + 4.f * f.ry * f.ry * f.ry * k1) * (-py / (K.cy * K.cy));
+                dxdc = -f.sx + f.ux * dsx + 1.f;
+                dydc = -f.sy + f.uy * dsy + 1.f;
+                const float gx = gdx / K.fx, gy = gdy / K.fy;            // d L / d x', d L / d y'
+                gk[4] = gx * f.ux * f.rx * f.rx + gy * f.uy * f.ry * f.ry;
+                gk[5] = gx * f.ux * f.rx * f.rx * f.rx * f.rx + gy * f.uy * f.ry * f.ry * f.ry * f.ry;
+            }
+            gk[2] = gdx * ((dxdc - 1.f) / K.fx);
+            gk[3] = gdy * ((dydc - 1.f) / K.fy);
+        }
     }
     // wave reduce, then one atomic per wave
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 6; ++k) {
         float v = gk[k];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += shfl_xor(v, o);
-        if (lane_id() == 0) atomic_add(acc + k, v);
+        if (lane_id() == 0 && (k < 4 || acc_dist)) atomic_add(k < 4 ? acc + k : acc_dist + (k - 4), v);
     }
 }
 
@@ -412,12 +457,13 @@ CamArgs make_args(const float* kps, const long long* cam_idx, int single_idx, co
     a.extr_init = extr_init; a.extr_noise = extr_noise; a.extr_scale = extr_scale; a.n_cams = n_cams;
     a.grid_o = grid_o; a.scale_o = scale_o; a.grid_d = grid_d; a.scale_d = scale_d; a.gh = gh; a.gw = gw;
     a.H = H; a.W = W; a.n = n;
+    a.select = nullptr; a.dist = nullptr;
     return a;
 }
 
 int check_args(const CamArgs& a) {
     SCN_RETURN_IF(a.n < 0 || a.H < 1 || a.W < 1 || !a.intr_init || !a.intr_noise, SCN_EINVAL);
-    SCN_RETURN_IF(!a.kps && a.n != a.H * a.W, SCN_EINVAL);
+    SCN_RETURN_IF(!a.kps && !a.select && a.n != a.H * a.W, SCN_EINVAL);
     if (a.extrinsic) { SCN_RETURN_IF(a.n_ext != 1 && a.n_ext != a.n, SCN_EINVAL); }
     else {
         SCN_RETURN_IF(!a.extr_init || !a.extr_noise || a.n_cams < 1, SCN_EINVAL);
@@ -472,7 +518,59 @@ extern "C" int scnerf_camera_rays_bwd(const float* kps, const long long* cam_idx
     if (d_extr_noise) SCN_HIP(hipMemsetAsync(d_extr_noise, 0, sizeof(float) * 9 * (size_t)n_cams, st));
     if (n > 0)
         hipLaunchKernelGGL(camera_rays_bwd_kernel, dim3(scn_ceil_div(n, 256)), dim3(256), 0, st, a, g_o, g_d,
-                           workspace, d_grid_o, d_grid_d);
+                           workspace, d_grid_o, d_grid_d, (float*)nullptr);
+    hipLaunchKernelGGL(camera_finish_kernel, dim3(scn_ceil_div(slots, 64)), dim3(64), 0, st, a, workspace,
+                       d_intr_noise, d_extr_noise, d_extrinsic);
+    return scn_launch_status();
+}
+
+// ---- NeRF++ generator: same camera model, pixel centres of selected pixels, optional radial distortion ----
+extern "C" int scnerf_npp_camera_rays_fwd(const long long* select, const float* dist2, int camera_idx,
+                                          const float* extrinsic, const float* intr_init, const float* intr_noise,
+                                          float intr_scale, int multiplicative, const float* extr_init,
+                                          const float* extr_noise, float extr_scale, int n_cams,
+                                          const float* grid_o, float scale_o, const float* grid_d, float scale_d,
+                                          int gh, int gw, int H, int W, float* rays_o, float* rays_d, int n,
+                                          void* stream) {
+    CamArgs a = make_args(nullptr, nullptr, camera_idx, extrinsic, extrinsic ? 1 : 0, intr_init, intr_noise,
+                          intr_scale, multiplicative, extr_init, extr_noise, extr_scale, n_cams, grid_o, scale_o,
+                          grid_d, scale_d, gh, gw, H, W, n);
+    a.select = select; a.dist = dist2;
+    SCN_RETURN_IF(!select || !rays_o || !rays_d, SCN_EINVAL);
+    const int rc = check_args(a);
+    SCN_RETURN_IF(rc != 0, rc);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(camera_rays_fwd_kernel, dim3(scn_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       rays_o, rays_d);
+    return scn_launch_status();
+}
+
+extern "C" int scnerf_npp_camera_rays_bwd(const long long* select, const float* dist2, int camera_idx,
+                                          const float* extrinsic, const float* intr_init, const float* intr_noise,
+                                          float intr_scale, int multiplicative, const float* extr_init,
+                                          const float* extr_noise, float extr_scale, int n_cams,
+                                          const float* grid_o, float scale_o, const float* grid_d, float scale_d,
+                                          int gh, int gw, int H, int W, const float* g_o, const float* g_d,
+                                          float* d_intr_noise, float* d_extr_noise, float* d_grid_o,
+                                          float* d_grid_d, float* d_extrinsic, float* d_dist2, float* workspace,
+                                          int n, void* stream) {
+    CamArgs a = make_args(nullptr, nullptr, camera_idx, extrinsic, extrinsic ? 1 : 0, intr_init, intr_noise,
+                          intr_scale, multiplicative, extr_init, extr_noise, extr_scale, n_cams, grid_o, scale_o,
+                          grid_d, scale_d, gh, gw, H, W, n);
+    a.select = select; a.dist = dist2;
+    SCN_RETURN_IF(!select || !workspace || (dist2 && !d_dist2), SCN_EINVAL);
+    const int rc = check_args(a);
+    SCN_RETURN_IF(rc != 0, rc);
+    hipStream_t st = (hipStream_t)stream;
+    const int slots = extrinsic ? 1 : n_cams;
+    SCN_HIP(hipMemsetAsync(workspace, 0, sizeof(float) * (4 + 12 * (size_t)slots), st));
+    if (d_dist2) SCN_HIP(hipMemsetAsync(d_dist2, 0, 2 * sizeof(float), st));      // accumulated into directly
+    if (d_grid_o) SCN_HIP(hipMemsetAsync(d_grid_o, 0, sizeof(float) * 3 * (size_t)gh * gw, st));
+    if (d_grid_d && d_grid_d != d_grid_o) SCN_HIP(hipMemsetAsync(d_grid_d, 0, sizeof(float) * 3 * (size_t)gh * gw, st));
+    if (d_extr_noise) SCN_HIP(hipMemsetAsync(d_extr_noise, 0, sizeof(float) * 9 * (size_t)n_cams, st));
+    if (n > 0)
+        hipLaunchKernelGGL(camera_rays_bwd_kernel, dim3(scn_ceil_div(n, 256)), dim3(256), 0, st, a, g_o, g_d,
+                           workspace, d_grid_o, d_grid_d, dist2 ? d_dist2 : (float*)nullptr);
     hipLaunchKernelGGL(camera_finish_kernel, dim3(scn_ceil_div(slots, 64)), dim3(64), 0, st, a, workspace,
                        d_intr_noise, d_extr_noise, d_extrinsic);
     return scn_launch_status();

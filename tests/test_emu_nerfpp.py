@@ -206,3 +206,41 @@ def test_composite_fwd_bwd():
     close(d_raw_fg, leaves[0].grad, 2e-5, "d_raw_fg (rgb only)")
     close(d_raw_bg, leaves[1].grad, 2e-5, "d_raw_bg (rgb only)")
     close(d_z, leaves[2].grad, 5e-5, "d_fg_z (rgb only)")
+
+
+@pytest.mark.parametrize("tag", ["plain", "dist"])
+def test_pixel_centre_ray_generator_golden(tag):
+    """scnerf_npp_camera_rays_fwd / _bwd vs the reference's render_ray_from_camera + autograd (A18)."""
+    import ctypes
+    from scnerf_amd import synthetic as synth
+    from test_emu_camera import cam_arrays
+    Hh, Ww = 60, 80
+    k = "rays_%s/" % tag
+    spec = synth.camera_spec(Hh, Ww, n_cams=4, seed=33, multiplicative=True, focal=70.0)
+    a = cam_arrays(spec, aliased=(tag == "dist"))            # the distortion class aliases the two noise grids
+    sel = G[k + "select"].astype(np.int64)
+    n = sel.shape[0]
+    dist = (G[k + "k"] + np.array([0.3, -0.2], np.float32) * np.float32(1e-1)).astype(np.float32) if tag == "dist" else None
+    gh, gw = a["grid_o"].shape[:2]
+    common = (a["intr_init"], a["intr_noise"], ctypes.c_float(spec["intrinsics_noise_scale"]), 1, a["extr_init"],
+              a["extr_noise"], ctypes.c_float(spec["extrinsics_noise_scale"]), 4, a["grid_o"],
+              ctypes.c_float(spec["ray_o_noise_scale"]), a["grid_d"], ctypes.c_float(spec["ray_d_noise_scale"]),
+              gh, gw, Hh, Ww)
+    ro, rd = np.full((n, 3), np.nan, np.float32), np.full((n, 3), np.nan, np.float32)
+    H.call("scnerf_npp_camera_rays_fwd", sel, dist, 2, None, *common, ro, rd, n, None)
+    np.testing.assert_allclose(ro, G[k + "rays_o"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rd, G[k + "rays_d"], rtol=1e-5, atol=1e-6)
+    out = dict(di=np.full(4, np.nan, np.float32), de=np.full((4, 9), np.nan, np.float32),
+               dgo=np.full((gh, gw, 3), np.nan, np.float32), dgd=np.full((gh, gw, 3), np.nan, np.float32),
+               dd=np.full(2, np.nan, np.float32))
+    ws = np.zeros(H.lib().scnerf_camera_bwd_workspace_floats(4), np.float32)
+    aliased = tag == "dist"
+    H.call("scnerf_npp_camera_rays_bwd", sel, dist, 2, None, *common, G[k + "g_o"], G[k + "g_d"], out["di"], out["de"],
+           out["dgo"], out["dgd"], None, out["dd"] if dist is not None else None, ws, n, None)
+    close(out["di"], G[k + "g_intrinsics_noise"], 1e-4, "intrinsics_noise")
+    close(out["de"], G[k + "g_extrinsics_noise"], 1e-4, "extrinsics_noise")
+    # (aliased: two Parameters over one storage are still two autograd leaves, each with its own gradient)
+    close(out["dgo"], G[k + "g_ray_o_noise"], 1e-4, "ray_o_noise")
+    close(out["dgd"], G[k + "g_ray_d_noise"], 1e-4, "ray_d_noise")
+    if aliased:
+        close(out["dd"] * np.float32(1e-1), G[k + "g_distortion_noise"], 1e-4, "distortion_noise")
