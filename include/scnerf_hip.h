@@ -269,12 +269,14 @@ int scnerf_npp_sample_pdf_bwd(const float* g_samples, const int* below_above, co
 
 /* Sample placement of NerfNet.forward (nerfplusplus/ddp_model.py:80-89, :105-114): fg_pts [n,sf,3] =
  * o + z d; bg_pts [n,sb,4] = depth2pts_outside (:16-45) of bg_z in FLIPPED order (the network sees the
- * background far -> near); viewdirs [n,3] = d / |d|.  _bwd: gradients of the two point sets, of the
+ * background far -> near); viewdirs [n,3] = d / |d| (optional); bg_depth_real [n,sb] (optional) = the
+ * metric depth of the background samples (:44); sf may be 0.  _bwd: gradients of the two point sets, of the
  * per-sample view directions of both networks and of |d| (scnerf_npp_composite_bwd) summed into d ray_o,
  * d ray_d [n,3]; d fg_z [n,sf] = d_fg_pts . d + g_fg_z_in (optional).  The inverse radii bg_z carry no
  * gradient (they never depend on learnable quantities). */
 int scnerf_npp_points_fwd(const float* ray_o, const float* ray_d, const float* fg_z, const float* bg_z,
-                          float* fg_pts, float* bg_pts, float* viewdirs, int n, int sf, int sb, void* stream);
+                          float* fg_pts, float* bg_pts, float* viewdirs, float* bg_depth_real, int n, int sf,
+                          int sb, void* stream);
 int scnerf_npp_points_bwd(const float* ray_o, const float* ray_d, const float* fg_z, const float* bg_z,
                           const float* d_fg_pts, const float* d_bg_pts, const float* d_views_fg,
                           const float* d_views_bg, const float* d_norm, const float* g_fg_z_in,

@@ -254,7 +254,7 @@ __device__ __forceinline__ BgPoint bg_point(const BgRay& b, float depth) {
 __global__ __launch_bounds__(256) void npp_points_fwd_kernel(
     const float* __restrict__ ro, const float* __restrict__ rd, const float* __restrict__ fg_z,
     const float* __restrict__ bg_z, float* __restrict__ fg_pts, float* __restrict__ bg_pts,
-    float* __restrict__ viewdirs, int n, int sf, int sb) {
+    float* __restrict__ viewdirs, float* __restrict__ bg_depth_real, int n, int sf, int sb) {
     const int lane = lane_id();
     const int ray = blockIdx.x * kRaysPerBlock + wave_id();
     if (ray >= n) return;
@@ -270,9 +270,11 @@ __global__ __launch_bounds__(256) void npp_points_fwd_kernel(
             const BgPoint p = bg_point(b, depth);
             f32x4 v = {p.unit.x, p.unit.y, p.unit.z, depth};
             *reinterpret_cast<f32x4*>(bg_pts + ((size_t)ray * sb + j) * 4) = v;
+            if (bg_depth_real)      // metric depth along the ray (ddp_model.py:44), same flipped order
+                bg_depth_real[(size_t)ray * sb + j] = 1.f / (depth + kTiny) * cosf(p.theta) * b.s.inv_len + b.s.d1;
         }
     }
-    if (lane == 0) {
+    if (lane == 0 && viewdirs) {
         const float len = sqrtf(dot(d, d));
         st3(viewdirs, ray, mk(d.x / len, d.y / len, d.z / len));
     }
@@ -643,13 +645,13 @@ extern "C" int scnerf_npp_sample_pdf_bwd(const float* g_samples, const int* belo
 }
 
 extern "C" int scnerf_npp_points_fwd(const float* ray_o, const float* ray_d, const float* fg_z, const float* bg_z,
-                                     float* fg_pts, float* bg_pts, float* viewdirs, int n, int sf, int sb,
-                                     void* stream) {
-    SCN_RETURN_IF(!ray_o || !ray_d || !fg_z || !fg_pts || !viewdirs || n < 0 || sf < 1 || sb < 0, SCN_EINVAL);
+                                     float* fg_pts, float* bg_pts, float* viewdirs, float* bg_depth_real, int n,
+                                     int sf, int sb, void* stream) {
+    SCN_RETURN_IF(!ray_o || !ray_d || n < 0 || sf < 0 || sb < 0 || (sf > 0 && (!fg_z || !fg_pts)), SCN_EINVAL);
     SCN_RETURN_IF(sb > 0 && (!bg_z || !bg_pts), SCN_EINVAL);
     if (n == 0) return 0;
     hipLaunchKernelGGL(npp_points_fwd_kernel, dim3(scn_ceil_div(n, kRaysPerBlock)), dim3(256), 0,
-                       (hipStream_t)stream, ray_o, ray_d, fg_z, bg_z, fg_pts, bg_pts, viewdirs, n, sf, sb);
+                       (hipStream_t)stream, ray_o, ray_d, fg_z, bg_z, fg_pts, bg_pts, viewdirs, bg_depth_real, n, sf, sb);
     return scn_launch_status();
 }
 

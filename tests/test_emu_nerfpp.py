@@ -94,8 +94,10 @@ def test_points_fwd_bwd():
     fg_pts = np.full((n, sf, 3), np.nan, np.float32)
     bg_pts = np.full((n, sb, 4), np.nan, np.float32)
     vd = np.full((n, 3), np.nan, np.float32)
-    H.call("scnerf_npp_points_fwd", o, d, fg_z, depth, fg_pts, bg_pts, vd, n, sf, sb, None)
+    dreal = np.full((n, sb), np.nan, np.float32)
+    H.call("scnerf_npp_points_fwd", o, d, fg_z, depth, fg_pts, bg_pts, vd, dreal, n, sf, sb, None)
     np.testing.assert_allclose(bg_pts[:, ::-1], G["kat/bg_pts"], rtol=1e-5, atol=2e-6)     # stored flipped
+    np.testing.assert_allclose(dreal[:, ::-1], G["kat/bg_depth_real"], rtol=2e-5, atol=1e-5)
     np.testing.assert_allclose(fg_pts, o[:, None] + fg_z[..., None] * d[:, None], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(vd, d / np.linalg.norm(d, axis=-1, keepdims=True), rtol=1e-6)
 
