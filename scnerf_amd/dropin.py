@@ -23,6 +23,42 @@ _MAP = {
 }
 
 
+# the NeRF++ scripts import these as top-level modules of nerfplusplus/ (ddp_train_nerf.py:8-25)
+_MAP_NERFPP = {
+    "nerf_network": "scnerf_amd.nerfplusplus.nerf_network",
+    "ddp_model": "scnerf_amd.nerfplusplus.ddp_model",
+    "nerf_sample_ray_split": "scnerf_amd.nerfplusplus.nerf_sample_ray_split",
+    "camera_model": "scnerf_amd.camera_model",
+    "model.camera_model": "scnerf_amd.camera_model",
+    "model.camera_utils": "scnerf_amd.camera_utils",
+    "model.ray_dist_loss": "scnerf_amd.ray_dist_loss",
+}
+
+
+def install_nerfplusplus():
+    """As install(), for the module names nerfplusplus/ddp_train_nerf.py imports; its own per-ray helpers
+    (intersect_sphere, perturb_samples, sample_pdf) live in scnerf_amd.nerfplusplus.ddp_train_nerf and
+    `create_nerf` in scnerf_amd.nerfplusplus.create_nerf (same names / signatures).  The reference's
+    render_ray_from_camera is only one function of nerf_sample_ray_split.py: the remaining names of that
+    module (RaySamplerSingleImage ...) are host-side data handling and stay the reference's."""
+    for alias, target in _MAP_NERFPP.items():
+        if alias == "nerf_sample_ray_split":
+            continue                      # patched function-wise below when the reference module is importable
+        sys.modules[alias] = importlib.import_module(target)
+    if "model" not in sys.modules or not hasattr(sys.modules["model"], "__path__"):
+        pkg = types.ModuleType("model")
+        pkg.__path__ = []
+        sys.modules["model"] = pkg
+    for name in ("camera_model", "camera_utils", "ray_dist_loss"):
+        setattr(sys.modules["model"], name, sys.modules["model." + name])
+    try:
+        ref = importlib.import_module("nerf_sample_ray_split")
+        ref.render_ray_from_camera = importlib.import_module(_MAP_NERFPP["nerf_sample_ray_split"]).render_ray_from_camera
+    except Exception:
+        sys.modules["nerf_sample_ray_split"] = importlib.import_module(_MAP_NERFPP["nerf_sample_ray_split"])
+    return sorted(_MAP_NERFPP)
+
+
 def install():
     for alias, target in _MAP.items():
         sys.modules[alias] = importlib.import_module(target)

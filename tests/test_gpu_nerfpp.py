@@ -188,3 +188,64 @@ def test_render_ray_from_camera_vs_reference(tag, key):
     E = cm.get_extrinsic()[2].detach().cpu().numpy()
     ro2, rd2, dep2 = render_ray_from_camera(cm, None, sel, "cuda", extrinsic=E)
     np.testing.assert_allclose(rd2.detach().cpu().numpy(), G[k + "rays_d"], rtol=2e-5, atol=2e-6)
+
+
+def test_create_nerf_models_optimizer_and_checkpoint(tmp_path):
+    """nerfplusplus/create_nerf.py: cascade models (`module.`-prefixed state-dict keys as under DDP), the
+    custom optimizer over [nets..., camera], a `.pth` checkpoint written like ddp_train_nerf.py:604-617
+    restoring networks, optimizer moments and camera."""
+    import os
+    from collections import OrderedDict
+    from scnerf_amd.nerfplusplus.create_nerf import create_nerf
+    Hh, Ww = 60, 80
+    spec = synth.camera_spec(Hh, Ww, n_cams=4, seed=33, multiplicative=True, focal=70.0)
+    os.makedirs(tmp_path / "exp")
+    args = types.SimpleNamespace(
+        max_freq_log2=10, max_freq_log2_viewdirs=4, netdepth=8, netwidth=256, use_viewdirs=True, use_camera=True,
+        camera_model="pinhole_rot_noise_10k_rayo_rayd", cascade_level=2, cascade_samples="16,32", optim_autoexpo=False,
+        basedir=str(tmp_path), expname="exp", use_custom_optim=True, lrate=5e-4, non_linear_weight_decay=0.1,
+        ckpt_path=None, no_reload=False, load_camera=False, load_test=True, add_ie=0, add_radial=0, add_od=0,
+        grid_size=10, ray_o_noise_scale=1e-3, ray_d_noise_scale=1e-3, extrinsics_noise_scale=1.0,
+        intrinsics_noise_scale=1.0, multiplicative_noise=True)
+    info = {"intrinsics": spec["K_init"], "extrinsics": list(spec["poses"].numpy()), "H": Hh, "W": Ww}
+    start, models, cm = create_nerf(0, args, info)
+    assert start == -1 and models["cascade_samples"] == [16, 32]
+    keys = list(models["net_0"].state_dict().keys())
+    assert keys[0] == "module.nerf_net.fg_net.base_layers.0.0.weight" and len(keys) == 48
+    n_net = 2 * 48
+    assert len(models["optim"].param_groups[0]["params"]) == n_net + len(list(cm.parameters()))
+
+    from scnerf_amd.nerfplusplus import ddp_train_nerf as TR
+    o, d, near = (t.cuda() for t in synth.nerfpp_rays(64, seed=5))
+    target = torch.rand(64, 3, device="cuda")
+
+    def step(models, cm):
+        optim = models["optim"]
+        optim.zero_grad()
+        far = TR.intersect_sphere(o, d)
+        frac = torch.linspace(0, 1, 16, device="cuda")
+        fg = near[:, None] + frac * (far - near)[:, None]
+        bg = torch.linspace(0, 1, 16, device="cuda").expand(64, 16)
+        loss = 0.0
+        for m in range(2):
+            ret = models["net_%d" % m](o, d, far, fg, bg)
+            loss = loss + ((ret["rgb"] - target) ** 2).mean()
+        loss.backward()
+        optim.step()
+        return float(loss.detach())
+    l0 = step(models, cm)
+    l1 = step(models, cm)
+    assert np.isfinite(l0) and l1 < l0                       # the same batch twice: the loss goes down
+    to_save = OrderedDict(optim=models["optim"].state_dict())
+    for m in range(2):
+        to_save["net_%d" % m] = models["net_%d" % m].state_dict()
+    to_save["camera_model"] = cm.state_dict()
+    torch.save(to_save, str(tmp_path / "exp" / "model_000002.pth"))
+    start2, models2, cm2 = create_nerf(0, args, info)
+    assert start2 == 2
+    for k, v in models["net_1"].state_dict().items():
+        assert torch.equal(v, models2["net_1"].state_dict()[k]), k
+    l2a, l2b = step(models, cm), step(models2, cm2)          # restored moments + step counts: identical next step
+    assert l2a == l2b
+    for a, b in zip(models["net_0"].parameters(), models2["net_0"].parameters()):
+        assert torch.equal(a, b)

@@ -1,0 +1,68 @@
+"""NeRF++ training-step rate (BASELINE config 5 shape: two cascade levels of 64 then +128 samples, foreground
+and background networks): fwd + bwd of both levels on synthetic rays inside the unit sphere.  Prints one
+JSON line (not the driver's bench)."""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rays", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    a = ap.parse_args()
+    from scnerf_amd import synthetic as synth
+    from scnerf_amd.nerfplusplus import ddp_train_nerf as TR
+    from scnerf_amd.nerfplusplus.ddp_model import NerfNet
+    args = types.SimpleNamespace(max_freq_log2=10, max_freq_log2_viewdirs=4, netdepth=8, netwidth=256, use_viewdirs=True)
+    torch.manual_seed(777)
+    nets = [NerfNet(args).cuda(), NerfNet(args).cuda()]
+    n, s0, s1 = a.rays, 64, 128
+    o, d, near = (t.cuda() for t in synth.nerfpp_rays(n, seed=5))
+    o.requires_grad_(True), d.requires_grad_(True)
+    target = torch.rand(n, 3, device="cuda")
+
+    def step():
+        for net in nets:
+            for p in net.parameters():
+                p.grad = None
+        o.grad = d.grad = None
+        far = TR.intersect_sphere(o, d, check=False)
+        st = (far - near) / (s0 - 1)
+        fg = TR.perturb_samples(torch.stack([near + i * st for i in range(s0)], dim=-1))
+        bg = TR.perturb_samples(torch.linspace(0., 1., s0, device="cuda").expand(n, s0))
+        ret = nets[0](o, d, far, fg, bg)
+        loss = ((ret["rgb"] - target) ** 2).mean()
+        fg_s = TR.sample_pdf(.5 * (fg[..., 1:] + fg[..., :-1]), ret["fg_weights"].detach()[..., 1:-1], s1)
+        fg1, _ = torch.sort(torch.cat((fg, fg_s), dim=-1))
+        bg_s = TR.sample_pdf(.5 * (bg[..., 1:] + bg[..., :-1]), ret["bg_weights"].detach()[..., 1:-1], s1)
+        bg1, _ = torch.sort(torch.cat((bg, bg_s), dim=-1))
+        ret1 = nets[1](o, d, far, fg1, bg1)
+        loss = loss + ((ret1["rgb"] - target) ** 2).mean()
+        loss.backward()
+        return loss
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    mac_fg, mac_bg = 593408, 593408 + 2 * 256 * 21
+    flop = n * (s0 + s0 + s1) * (mac_fg + mac_bg) * 2 * 3            # fwd + dgrad + wgrad
+    print(json.dumps({"metric": "rays/sec NeRF++ train-step (2 levels: 64 / 192 samples, fg + bg nets)",
+                      "value": n / dt, "unit": "rays/s", "rays": n, "ms_per_step": dt * 1e3,
+                      "tflops_algorithmic": flop / dt / 1e12}))
+
+
+if __name__ == "__main__":
+    main()
