@@ -44,6 +44,23 @@ __device__ __forceinline__ void block_sync() { __syncthreads(); }
 // Compiler-only fence: instructions are not moved across it by the machine scheduler (used to keep
 // prefetches where they were written; no instruction is emitted).
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// scheduling-group hints (LLVM AMDGPU sched_group_barrier): the next `n` MFMA / VALU instructions of the
+// region form one group; groups are emitted in the order the hints appear
+// max without the canonicalising self-max the compiler adds in front of fmaxf under IEEE mode (v_max_f32
+// quiets signalling NaNs by itself): one instruction, and VALU instructions are not free next to fp32
+// MFMAs -- both run on the SIMD's fp32 lanes (tools/ubench/mfma_valu.hip: ~4.5 cycles per VALU op).
+__device__ __forceinline__ float max_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// bits = 2 * bits + (v > 0): one compare into VCC and one add-with-carry
+__device__ __forceinline__ unsigned shift_in_positive(unsigned bits, float v) {
+    asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(v) : "vcc");
+    return bits;
+}
+template <int N> __device__ __forceinline__ void sched_group_mfma() { __builtin_amdgcn_sched_group_barrier(0x008, N, 0); }
+template <int N> __device__ __forceinline__ void sched_group_valu() { __builtin_amdgcn_sched_group_barrier(0x002, N, 0); }
 
 // Dynamic LDS of the launch (16-byte aligned; no static __shared__ anywhere, so the
 // dynamic region starts at offset 0: cdna_hip_programming.md guideline 17).

@@ -96,8 +96,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
 
     WStream ws;
     ws.g = reinterpret_cast<const f32x4*>(wbk);
-    ws.buf[0] = dynamic_lds<float>();
-    ws.buf[1] = ws.buf[0] + kMaxChunkBwd;
     stream_prime<1>(ws);           // RGBT: 4 tiles x 4 steps = 1024 floats
 
     // dead lanes (p >= P) must contribute exact zeros: their d_raw is forced to 0
@@ -144,14 +142,14 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
 
     // ---- feature_linear^T + alpha_linear^T : d h8 = W_f^T d feature + w_alpha d sigma -----
     {
-        const float* wa = wbk + V::kBwdAlphaW;
+        const float* wa = wbk + V::kBwdAlphaW;          // lane-vector layout
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = 16 * t + r;
-                const float w0 = wa[2 * i], w1 = wa[2 * i + 1];
-                acc[t][r] = (h ? w1 : w0) * dsigma;
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 w = lane_vec(wa, t, q, h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t][4 * q + j] = w[j] * dsigma;
             }
     }
     mfma_part<128, 8, 16, 8>(dz, acc, ws, tile_ptr(grads + (long)kGradDfeat * Ppad, wave_tile, 256, lane));
@@ -214,7 +212,15 @@ extern "C" int scnerf_mlp_bwd(int pt_dims, const float* d_raw, const float* pts,
     SCN_RETURN_IF(!d_raw || !pts || !viewdirs || !wpacked_bwd || !save || !grads || !d_pts || !d_views, SCN_EINVAL);
     SCN_RETURN_IF(samples_per_ray < 1 || vd_stride < 3 || n_samples < 0 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
     if (n_samples == 0) return 0;
-    const size_t lds = (size_t)2 * kMaxChunkBwd * sizeof(float);
+    const size_t lds = (size_t)kStreamBufs * kMaxChunkBwd * sizeof(float);      // 96 KB: needs the opt-in
+    static bool lds_opt_in = false;
+    if (!lds_opt_in) {
+        SCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<3>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_opt_in = true;
+    }
     const dim3 grid(scn_ceil_div(n_samples, kSamplesPerBlock));
     if (pt_dims == 3)
         hipLaunchKernelGGL(mlp_bwd_kernel<3>, grid, dim3(kThreads), lds, (hipStream_t)stream, d_raw, pts, viewdirs,

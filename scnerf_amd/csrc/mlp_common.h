@@ -11,6 +11,8 @@
 // scnerf_gather_f32) streams L2 -> LDS in double-buffered chunks shared by the 4 waves of
 // a workgroup and is read with ds_read_b128 (4 consecutive steps per lane).
 #pragma once
+#include <type_traits>
+
 #include <scn_wave.h>
 
 namespace scn {
@@ -64,8 +66,10 @@ struct Var {
 static_assert(Var<3>::kFwdStream == 598016 && Var<3>::kBwdStream == 594944 && Var<3>::kNParams == 595844, "standard network");
 static_assert(Var<4>::kNParams == 606596, "NeRF++ background network");
 
-constexpr int kMaxChunkFwd = 8192;      // floats: 32 KB, x2 buffers = 64 KB LDS
-constexpr int kMaxChunkBwd = 8192;      // floats: 32 KB, x2 buffers = 64 KB LDS
+constexpr int kMaxChunkFwd = 8192;      // floats: 32 KB, x3 buffers = 96 KB LDS
+constexpr int kMaxChunkBwd = 8192;      // floats: 32 KB, x3 buffers = 96 KB LDS
+constexpr int kStreamBufs = 3;
+static_assert(kMaxChunkFwd == 8192 && kMaxChunkBwd == 8192, "WStream::buf stride");
 
 // Activation / gradient workspaces.  Offsets are in floats per (padded) sample: a section starts at
 // offset * padded_samples(P).  The wide sections (act*, feat, hv, dz*, dfeat, dzv) are TILE-NATIVE:
@@ -158,10 +162,19 @@ __device__ __forceinline__ void pe_slots(float x, float y, float z, float w, int
 }
 
 // ---- weight stream: global (L2) -> LDS, one chunk ahead of the MFMAs ---------------------
+// THREE LDS buffers.  While chunk c is consumed from buf[c % 3], the staged registers of chunk c+1 are
+// written to buf[(c+1) % 3] half-way through the chunk and the workgroup barrier sits at three quarters:
+// behind it chunk c+1 is complete, so its first A fragments are fetched during the tail of chunk c and no
+// chunk boundary ever waits for LDS (with two buffers the barrier had to sit AT the boundary: ~250 idle
+// cycles per 8192-cycle chunk).  The third buffer is what makes the early write safe: buf[(c+1) % 3] was
+// last read as chunk c-2, which every wave had finished when it passed the barrier inside chunk c-1.
 struct WStream {
     const f32x4* g;      // next chunk to fetch
-    float* buf[2];       // LDS double buffer
-    int cur;             // buffer holding the chunk being consumed
+    int cur;             // LDS buffer (0..2) holding the chunk being consumed
+    __device__ __forceinline__ int next() const { return cur == 2 ? 0 : cur + 1; }
+    // Buffers are addressed as offsets from the dynamic-LDS symbol, never through stored pointers: a
+    // pointer selected at run time loses its address space and the reads degrade to FLAT loads.
+    static __device__ __forceinline__ float* buf(int i) { return dynamic_lds<float>() + i * 8192; }
 };
 
 // All counts are compile-time so the staging registers stay registers.
@@ -180,7 +193,7 @@ __device__ __forceinline__ void stream_issue(const WStream& ws, f32x4 (&stage)[N
 template <int N_F4>
 __device__ __forceinline__ void stream_commit(WStream& ws, const f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1]) {
     const int tid = threadIdx.x;
-    f32x4* dst = reinterpret_cast<f32x4*>(ws.buf[ws.cur ^ 1]);
+    f32x4* dst = reinterpret_cast<f32x4*>(WStream::buf(ws.next()));
 #pragma unroll
     for (int i = 0; i < N_F4; ++i) dst[i * kThreads + tid] = stage[i];
     ws.g += N_F4 * kThreads;
@@ -190,7 +203,7 @@ __device__ __forceinline__ void stream_commit(WStream& ws, const f32x4 (&stage)[
 template <int N_F4>
 __device__ __forceinline__ void stream_prime(WStream& ws) {
     f32x4 stage[N_F4];
-    ws.cur = 1;                        // commit() writes buf[cur ^ 1] = buf[0]
+    ws.cur = 2;                        // commit() writes buf[next()] = buf[0]
     stream_issue<N_F4>(ws, stage);
     stream_commit<N_F4>(ws, stage);
     ws.cur = 0;
@@ -216,34 +229,53 @@ __device__ __forceinline__ void store_tiles(const float (&regs)[N], float* tile)
         }
 }
 
-// One chunk: CS steps x NT tiles out of LDS buffer `A`, B operands b[B0 .. B0 + CS).
-// The A fragments (one ds_read_b128 = 4 consecutive steps of one tile) go through a 3-deep register
-// ring with prefetch distance 2 -- 512 MFMA cycles ahead of use, so LDS latency never reaches the
-// matrix pipe (the compiler's own schedule kept one read in flight and waited on it: ~20 % idle).
-// At 3/4 of the chunk the staged registers of the NEXT chunk are written to the other LDS buffer,
-// overlapping the ds_write burst with MFMAs instead of serialising it in front of the barrier.
-template <int NSTEP, int NT, int CS, int B0, int N_F4>
+// One chunk: CS steps x NT tiles out of LDS buffer buf[cur], B operands b[B0 .. B0 + CS).
+// The A fragments (one ds_read_b128 = 4 consecutive steps of one tile) go through a register ring with
+// prefetch distance one pair -- 512 MFMA cycles ahead of use, so LDS latency never reaches the matrix pipe
+// (the compiler's own schedule kept one read in flight and waited on it: ~20 % idle).  Half-way the staged
+// registers of the NEXT chunk are written to the next LDS buffer, at three quarters the workgroup
+// synchronises; CONT_IN: the ring already holds this chunk's first pair (fetched by the previous chunk);
+// CONT_OUT: fetch the next chunk's first pair from the next buffer (same part: same fragment geometry).
+template <int NSTEP, int NT, int CS, int B0, int N_F4, bool CONT_IN, bool CONT_OUT>
 __device__ __forceinline__ void mfma_chunk(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
-                                           const f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1], int lane) {
+                                           const f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1], f32x4 (&ring)[4], int lane) {
     constexpr int G = CS / 4;
     constexpr int NF = G * NT;                 // fragments, order f = g * NT + t
-    const f32x4* A = reinterpret_cast<const f32x4*>(ws.buf[ws.cur]) + lane;
+    const f32x4* A = reinterpret_cast<const f32x4*>(WStream::buf(ws.cur)) + lane;
     if constexpr (NT % 2 == 0) {
         // Two tiles are interleaved so that consecutive MFMAs never target the same accumulator
         // (a 4-deep dependent chain on one accumulator issues measurably slower than 64 cycles).
         constexpr int NP = NF / 2;             // fragment pairs (tiles t, t+1 of the same 4 steps)
-        constexpr int COMMIT_AT = (NP * 3) / 4;
-        f32x4 ring[4];
-        ring[0] = A[((0 % NT) * G + 0 / NT) * 64];
-        ring[1] = A[((1 % NT) * G + 1 / NT) * 64];
+        static_assert(NP % 2 == 0 || !(CONT_IN || CONT_OUT), "ring parity across chunks");
+#ifndef SCN_COMMIT_NUM
+#define SCN_COMMIT_NUM 2
+#define SCN_COMMIT_DEN 4
+#define SCN_SYNC_NUM 3
+#define SCN_SYNC_DEN 4
+#endif
+        constexpr int COMMIT_AT = (NP * SCN_COMMIT_NUM) / SCN_COMMIT_DEN;
+        constexpr int SYNC_AT = (NP * SCN_SYNC_NUM) / SCN_SYNC_DEN >= NP ? NP - 1 : (NP * SCN_SYNC_NUM) / SCN_SYNC_DEN;
+        const f32x4* An = reinterpret_cast<const f32x4*>(WStream::buf(ws.next())) + lane;
+        if constexpr (!CONT_IN) {
+            ring[0] = A[((0 % NT) * G + 0 / NT) * 64];
+            ring[1] = A[((1 % NT) * G + 1 / NT) * 64];
+        }
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
+            if (p == COMMIT_AT) stream_commit<N_F4>(ws, stage);
+            if (p == SYNC_AT) {
+#ifndef SCN_ABLATE_NO_BARRIER      // (timing experiments only: tools/ablate.sh)
+                block_sync();
+#endif
+            }
             if (p + 1 < NP) {
                 const int f = 2 * p + 2;
                 ring[2 * ((p + 1) & 1) + 0] = A[((f % NT) * G + f / NT) * 64];
                 ring[2 * ((p + 1) & 1) + 1] = A[(((f + 1) % NT) * G + (f + 1) / NT) * 64];
+            } else if constexpr (CONT_OUT) {
+                ring[0] = An[((0 % NT) * G + 0 / NT) * 64];
+                ring[1] = An[((1 % NT) * G + 1 / NT) * 64];
             }
-            if (p == COMMIT_AT) stream_commit<N_F4>(ws, stage);
             sched_fence();      // keep the reads one pair (512 MFMA cycles) ahead of their use
             const int f = 2 * p, g = f / NT, t = f % NT;
             const f32x4 a0 = ring[2 * (p & 1)], a1 = ring[2 * (p & 1) + 1];
@@ -253,74 +285,182 @@ __device__ __forceinline__ void mfma_chunk(const float (&b)[NSTEP], f32x16 (&acc
                 acc[t + 1] = mfma_32x32x2(a1[j], b[B0 + 4 * g + j], acc[t + 1]);
             }
         }
-        if (COMMIT_AT >= NP) stream_commit<N_F4>(ws, stage);
     } else {
-        constexpr int COMMIT_AT = (NF * 3) / 4;
-        f32x4 ring[3];
-        ring[0] = A[((0 % NT) * G + 0 / NT) * 64];
-        if (NF > 1) ring[1] = A[((1 % NT) * G + 1 / NT) * 64];
+        static_assert(!CONT_IN && !CONT_OUT, "single-tile parts do not chain");
+        constexpr int COMMIT_AT = NF / 2;
+        constexpr int SYNC_AT = (NF * 3) / 4;
+        f32x4 r3[3];
+        r3[0] = A[((0 % NT) * G + 0 / NT) * 64];
+        if (NF > 1) r3[1] = A[((1 % NT) * G + 1 / NT) * 64];
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            if (f + 2 < NF) ring[(f + 2) % 3] = A[(((f + 2) % NT) * G + (f + 2) / NT) * 64];
             if (f == COMMIT_AT) stream_commit<N_F4>(ws, stage);
+            if (f == SYNC_AT) {
+#ifndef SCN_ABLATE_NO_BARRIER
+                block_sync();
+#endif
+            }
+            if (f + 2 < NF) r3[(f + 2) % 3] = A[(((f + 2) % NT) * G + (f + 2) / NT) * 64];
             sched_fence();
             const int g = f / NT, t = f % NT;
-            const f32x4 a = ring[f % 3];
+            const f32x4 a = r3[f % 3];
             acc[t] = mfma_32x32x2(a[0], b[B0 + 4 * g + 0], acc[t]);
             acc[t] = mfma_32x32x2(a[1], b[B0 + 4 * g + 1], acc[t]);
             acc[t] = mfma_32x32x2(a[2], b[B0 + 4 * g + 2], acc[t]);
             acc[t] = mfma_32x32x2(a[3], b[B0 + 4 * g + 3], acc[t]);
         }
-        if (COMMIT_AT >= NF) stream_commit<N_F4>(ws, stage);
     }
 }
 
-template <int NSTEP, int NT, int CS, int NEXT_F4, int C>
+// ---- last chunk of a layer with the layer's epilogue folded in --------------------------------------
+// A layer's epilogue (ReLU, mask bits, bias of the next layer: ~5 VALU instructions per accumulator
+// register, ~700 per layer) cannot overlap anything when it runs after the last MFMA: one wave per SIMD
+// means nobody else feeds the matrix pipe meanwhile (~8 % of a layer).  In the LAST chunk the fragments
+// are therefore walked tile-pair-major instead of step-major: output tiles (2P, 2P+1) are final after a
+// quarter of the chunk, and their epilogue is issued in eight-register slices between the MFMAs of the
+// following pairs; only the last pair's epilogue remains exposed.  (Safe w.r.t. the B operands: the last
+// chunk contracts over the registers of the LAST tile only, which the early slices do not write.)
+struct NoEpi {
+    template <int P, int G, int J> __device__ __forceinline__ void slice() {}
+};
+
+template <int NSTEP, int NT, int CS, int B0, int N_F4, bool CONT_IN, class EPI, int Q>
+struct LastChunk {
+    static constexpr int G = CS / 4, NPAIR = NT / 2, NQ = NPAIR * G;
+    static constexpr int P = Q / G, g = Q % G;
+    static __device__ __forceinline__ void run(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
+                                               const f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1], f32x4 (&ring)[4],
+                                               const f32x4* A, EPI& epi) {
+        if constexpr (Q == NQ / 2) stream_commit<N_F4>(ws, stage);
+        if constexpr (Q == (NQ * 3) / 4) {
+#ifndef SCN_ABLATE_NO_BARRIER
+            block_sync();
+#endif
+        }
+        if constexpr (Q + 1 < NQ) {
+            constexpr int P1 = (Q + 1) / G, g1 = (Q + 1) % G;
+            ring[2 * ((Q + 1) & 1) + 0] = A[((2 * P1) * G + g1) * 64];
+            ring[2 * ((Q + 1) & 1) + 1] = A[((2 * P1 + 1) * G + g1) * 64];
+        }
+        sched_fence();
+        const f32x4 a0 = ring[2 * (Q & 1)], a1 = ring[2 * (Q & 1) + 1];
+        constexpr int t = 2 * P;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[t] = mfma_32x32x2(a0[j], b[B0 + 4 * g + j], acc[t]);
+            acc[t + 1] = mfma_32x32x2(a1[j], b[B0 + 4 * g + j], acc[t + 1]);
+        }
+        if constexpr (P >= 1) {
+            // the slice is independent of this step's MFMAs: the hints ask for it to be spread between them
+            epi.template slice<P - 1, g, 0>();
+            epi.template slice<P - 1, g, 1>();
+            epi.template slice<P - 1, g, 2>();
+            epi.template slice<P - 1, g, 3>();
+#ifdef SCN_GROUP_HINTS         // (experiment: explicit MFMA/VALU interleave hints were slower than the default schedule)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                sched_group_mfma<1>();
+                sched_group_valu<EPI::kValuPerMfma>();
+            }
+#endif
+        }
+        if constexpr (Q + 1 < NQ) {
+            LastChunk<NSTEP, NT, CS, B0, N_F4, CONT_IN, EPI, Q + 1>::run(b, acc, ws, stage, ring, A, epi);
+        } else {
+            sched_fence();
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {       // the last pair: exposed
+                if constexpr (G == 4) {
+                    if (gg == 0) { epi.template slice<NPAIR - 1, 0, 0>(); epi.template slice<NPAIR - 1, 0, 1>(); epi.template slice<NPAIR - 1, 0, 2>(); epi.template slice<NPAIR - 1, 0, 3>(); }
+                    if (gg == 1) { epi.template slice<NPAIR - 1, 1, 0>(); epi.template slice<NPAIR - 1, 1, 1>(); epi.template slice<NPAIR - 1, 1, 2>(); epi.template slice<NPAIR - 1, 1, 3>(); }
+                    if (gg == 2) { epi.template slice<NPAIR - 1, 2, 0>(); epi.template slice<NPAIR - 1, 2, 1>(); epi.template slice<NPAIR - 1, 2, 2>(); epi.template slice<NPAIR - 1, 2, 3>(); }
+                    if (gg == 3) { epi.template slice<NPAIR - 1, 3, 0>(); epi.template slice<NPAIR - 1, 3, 1>(); epi.template slice<NPAIR - 1, 3, 2>(); epi.template slice<NPAIR - 1, 3, 3>(); }
+                }
+            }
+        }
+    }
+};
+
+template <int NSTEP, int NT, int CS, int B0, int N_F4, bool CONT_IN, class EPI>
+__device__ __forceinline__ void mfma_chunk_last(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
+                                                const f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1], f32x4 (&ring)[4],
+                                                int lane, EPI& epi) {
+    static_assert(NT % 2 == 0 && CS == 16, "tile-pair-major last chunk: 4 step groups");
+    constexpr int G = CS / 4;
+    const f32x4* A = reinterpret_cast<const f32x4*>(WStream::buf(ws.cur)) + lane;
+    if constexpr (!CONT_IN) {
+        ring[0] = A[(0 * G + 0) * 64];
+        ring[1] = A[(1 * G + 0) * 64];
+    }
+    LastChunk<NSTEP, NT, CS, B0, N_F4, CONT_IN, EPI, 0>::run(b, acc, ws, stage, ring, A, epi);
+}
+
+template <int NSTEP, int NT, int CS, int NEXT_F4, int C, class EPI = NoEpi>
 struct PartLoop {
     static constexpr int NC = NSTEP / CS;
     static constexpr int CHUNK_F4 = NT * CS * 64 / 4 / kThreads;
     static constexpr int N_F4 = (C + 1 < NC) ? CHUNK_F4 : NEXT_F4;
+#ifdef SCN_NO_CHAIN
+    static constexpr bool CHAIN = false;
+#else
+    static constexpr bool CHAIN = (NT % 2 == 0) && (((CS / 4) * NT / 2) % 2 == 0);
+#endif
     static __device__ __forceinline__ void run(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
-                                               int lane, float* save_tile) {
+                                               f32x4 (&ring)[4], int lane, float* save_tile, EPI& epi) {
         f32x4 stage[N_F4 > 0 ? N_F4 : 1];
         stream_issue<N_F4>(ws, stage);
-        sched_fence();      // the loads stay at the head of the chunk: a whole chunk of MFMAs covers them
+        sched_fence();      // the loads stay at the head of the chunk: half a chunk of MFMAs covers them
         // the B operands of this part are the previous layer's activations (forward) / this layer's
         // output gradient (backward): the slice this chunk contracts over is stored now, so the
         // training-mode HBM writes trickle out under the MFMAs instead of bursting at a layer end
         if constexpr (CS >= 16) store_tiles<(C * CS) / 16, ((C + 1) * CS) / 16, NSTEP>(b, save_tile);
-        mfma_chunk<NSTEP, NT, CS, C * CS, N_F4>(b, acc, ws, stage, lane);
-#ifndef SCN_ABLATE_NO_BARRIER      // (timing experiments only: tools/ablate.sh)
-        block_sync();
-#endif
-        ws.cur ^= 1;
-        if constexpr (C + 1 < NC) PartLoop<NSTEP, NT, CS, NEXT_F4, C + 1>::run(b, acc, ws, lane, save_tile);
+        if constexpr (C + 1 == NC && !std::is_same<EPI, NoEpi>::value)
+            mfma_chunk_last<NSTEP, NT, CS, C * CS, N_F4, CHAIN && (C > 0), EPI>(b, acc, ws, stage, ring, lane, epi);
+        else
+            mfma_chunk<NSTEP, NT, CS, C * CS, N_F4, CHAIN && (C > 0), CHAIN && (C + 1 < NC)>(b, acc, ws, stage, ring, lane);
+        ws.cur = ws.next();
+        if constexpr (C + 1 < NC) PartLoop<NSTEP, NT, CS, NEXT_F4, C + 1, EPI>::run(b, acc, ws, ring, lane, save_tile, epi);
     }
 };
 
 // One "part" = NSTEP MFMA steps over NT output tiles with B operands taken from registers
 // b[0..NSTEP).  CS steps per LDS chunk; NEXT_F4 = 16-byte loads per thread of the chunk that
 // follows this part in the stream (0 at the end of the stream).  save_tile: this lane's slot in the
-// tile-native HBM section its B operands are saved to (tile_ptr), or nullptr.
+// tile-native HBM section its B operands are saved to (tile_ptr), or nullptr.  The overload with `epi`
+// folds the layer's epilogue into the last chunk (see LastChunk).
 template <int NSTEP, int NT, int CS, int NEXT_F4>
 __device__ __forceinline__ void mfma_part(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
                                           float* save_tile = nullptr) {
     static_assert(NSTEP % CS == 0 && CS % 4 == 0, "chunking");
     static_assert((NT * CS * 64) % (4 * kThreads) == 0, "chunk must be whole 16-byte loads per thread");
-    PartLoop<NSTEP, NT, CS, NEXT_F4, 0>::run(b, acc, ws, lane_id(), save_tile);
+    f32x4 ring[4];
+    NoEpi none;
+    PartLoop<NSTEP, NT, CS, NEXT_F4, 0, NoEpi>::run(b, acc, ws, ring, lane_id(), save_tile, none);
 }
 
-// acc[t][r] = bias of feature feat_of(t, r, h); bias_hp is the half-pair table
-// [(16 t + r) * 2 + h] (wave-uniform address -> scalar loads + one select per register).
+template <int NSTEP, int NT, int CS, int NEXT_F4, class EPI>
+__device__ __forceinline__ void mfma_part_epi(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
+                                              float* save_tile, EPI& epi) {
+    static_assert(NSTEP % CS == 0 && CS % 4 == 0, "chunking");
+    f32x4 ring[4];
+    PartLoop<NSTEP, NT, CS, NEXT_F4, 0, EPI>::run(b, acc, ws, ring, lane_id(), save_tile, epi);
+}
+
+// acc[t][r] = bias of feature feat_of(t, r, h); `table` is in lane-vector layout (mlp_layout.
+// lane_vector_table): entry ((4 t + q) * 2 + h) * 4 + j  <->  register 4 q + j of tile t on lane half h.
+__device__ __forceinline__ f32x4 lane_vec(const float* __restrict__ table, int t, int q, int h) {
+    return *reinterpret_cast<const f32x4*>(table + ((4 * t + q) * 2 + h) * 4);
+}
+
 template <int NT>
-__device__ __forceinline__ void init_bias(f32x16 (&acc)[NT], const float* __restrict__ bias_hp, int h) {
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[NT], const float* __restrict__ table, int h) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float b0 = bias_hp[(16 * t + r) * 2 + 0];
-            const float b1 = bias_hp[(16 * t + r) * 2 + 1];
-            acc[t][r] = h ? b1 : b0;
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = lane_vec(table, t, q, h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t][4 * q + j] = b[j];
         }
 }
 
@@ -350,7 +490,7 @@ __device__ __forceinline__ u32x4 relu_bits(const float (&v)[N]) {
     u32x4 bits = {0u, 0u, 0u, 0u};
 #ifndef SCN_ABLATE_NO_MASK         // (timing experiments only)
 #pragma unroll
-    for (int i = 0; i < N; ++i) bits[i >> 5] = bits[i >> 5] + bits[i >> 5] + (v[i] > 0.f ? 1u : 0u);
+    for (int i = 0; i < N; ++i) bits[i >> 5] = shift_in_positive(bits[i >> 5], v[i]);
 #endif
     return bits;
 }

@@ -27,7 +27,7 @@ __device__ __forceinline__ void relu_to_regs(const f32x16 (&acc)[N / 16], float 
 #pragma unroll
     for (int t = 0; t < N / 16; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dst[16 * t + r] = relu ? fmaxf(acc[t][r], 0.f) : acc[t][r];
+        for (int r = 0; r < 16; ++r) dst[16 * t + r] = relu ? max_raw(acc[t][r], 0.f) : acc[t][r];
 }
 
 // encodings are saved in torch column order so the wgrad GEMM writes weight columns directly
@@ -48,10 +48,52 @@ __device__ __forceinline__ void store_pe(const float (&e)[NS], float* __restrict
     }
 }
 
-template <int PD>
+// Epilogue of a trunk layer, register by register (LastChunk issues it between the MFMAs of the layer's
+// last chunk): activation -> B-operand register of the next layer, ReLU mask bit, bias of the next layer
+// into the accumulator.  `lo` = 0 (ReLU) or -inf (the linear feature layer).
+template <bool TRAIN>
+struct FwdEpi {
+    static constexpr int kValuPerMfma = 5;
+    f32x16 (&acc)[8];
+    float (&hreg)[128];
+    const float* bias_next;      // lane-vector table of the layer that follows
+    int h;
+    float lo;
+    unsigned (&bits)[4];
+    unsigned ha, hb;
+    f32x4 ba, bb;
+    template <int P, int G, int J>
+    __device__ __forceinline__ void slice() {
+        constexpr int r = 4 * G + J;
+        if constexpr (G == 0 && J == 0) { ha = 0u; hb = 0u; }
+        if constexpr (J == 0) {
+            ba = lane_vec(bias_next, 2 * P, G, h);
+            bb = lane_vec(bias_next, 2 * P + 1, G, h);
+        }
+        {
+            constexpr int t = 2 * P, i = 16 * t + r;
+            const float v = max_raw(acc[t][r], lo);
+            hreg[i] = v;
+            if constexpr (TRAIN) ha = shift_in_positive(ha, v);
+            acc[t][r] = ba[J];
+        }
+        {
+            constexpr int t = 2 * P + 1, i = 16 * t + r;
+            const float v = max_raw(acc[t][r], lo);
+            hreg[i] = v;
+            if constexpr (TRAIN) hb = shift_in_positive(hb, v);
+            acc[t][r] = bb[J];
+        }
+        if constexpr (TRAIN && G == 3 && J == 3) bits[P] = (ha << 16) | hb;      // element i: word i >> 5, bit 31 - (i & 31)
+    }
+};
+
+// TRAIN: also leave the activations / encodings / ReLU masks in `save` for the dgrad and wgrad kernels
+template <int PD, bool TRAIN>
 __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     const float* __restrict__ pts, const float* __restrict__ viewdirs, int vd_stride, int samples_per_ray,
-    const float* __restrict__ wpk, float* __restrict__ raw, float* __restrict__ save, long P) {
+    const float* __restrict__ wpk, float* __restrict__ raw, float* __restrict__ save_arg, long P) {
+    float* const save = TRAIN ? save_arg : nullptr;
     const int lane = lane_id();
     const int m = lane & 31, h = lane >> 5;
     const long wave_tile = (long)blockIdx.x * 4 + wave_id();
@@ -64,8 +106,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
 
     WStream ws;
     ws.g = reinterpret_cast<const f32x4*>(wpk);
-    ws.buf[0] = dynamic_lds<float>();
-    ws.buf[1] = ws.buf[0] + kMaxChunkFwd;
     stream_prime<8>(ws);   // first chunk of E0 (8 tiles x 16 steps)
 
     const float px = pts[pc * PD + 0], py = pts[pc * PD + 1], pz = pts[pc * PD + 2];
@@ -77,7 +117,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
 
     // layer 0 (peeled: nothing else is live while the 30 sincos of the encoding run).  The encoded
     // point is parked in LDS for the skip layer instead of staying live through layers 1..4.
-    f32x4* park = reinterpret_cast<f32x4*>(ws.buf[0] + 2 * kMaxChunkFwd) + threadIdx.x;
+    f32x4* park = reinterpret_cast<f32x4*>(dynamic_lds<float>() + kStreamBufs * kMaxChunkFwd) + threadIdx.x;
     {
         float e[ES];
         pe_slots<PD, 10, ES>(px, py, pz, pw, h, e);
@@ -95,9 +135,11 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
 
     // trunk layers 1..7 and the (linear) feature layer as l == 8.  In training mode the output of
     // layer l-1 (the B operand of layer l's main part) is written to HBM chunk by chunk during layer l.
+    // Each layer's epilogue (ReLU -> next B operands, mask bits, next layer's bias) is folded into its last
+    // chunk (FwdEpi / LastChunk), so the accumulators arrive here already holding the bias of layer l.
+    init_bias<8>(acc, wpk + V::kFwdBias + 256, h);
 #pragma unroll 1
     for (int l = 1; l <= 8; ++l) {
-        init_bias<8>(acc, wpk + (l < 8 ? V::kFwdBias + 256 * l : V::kFwdBiasF), h);
         if (l == 5) {
             float e[ES];
 #pragma unroll
@@ -107,18 +149,28 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
             }
             mfma_part<ES, 8, 16, 8>(e, acc, ws);
         }
-        mfma_part<128, 8, 16, 8>(hreg, acc, ws,       // every chunk that can follow is 8 x 16 B / thread
-                                 save ? tile_ptr(save + (long)(kSaveAct + 256 * (l - 1)) * Ppad, wave_tile, 256, lane) : nullptr);
-        relu_to_regs<128>(acc, hreg, l < 8);
-        if (save && l < 8) *reinterpret_cast<u32x4*>(mask_ptr<PD>(save, P, l, wave_tile, lane)) = relu_bits<128>(hreg);
+        unsigned bits[4] = {0u, 0u, 0u, 0u};
+        // bias of layer l + 1 (l == 8: the accumulators are not used again; any valid table)
+        FwdEpi<TRAIN> epi{acc, hreg, wpk + (l < 7 ? V::kFwdBias + 256 * (l + 1) : V::kFwdBiasF), h,
+                   l < 8 ? 0.f : -__builtin_huge_valf(), bits, 0u, 0u, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        mfma_part_epi<128, 8, 16, 8>(hreg, acc, ws,       // every chunk that can follow is 8 x 16 B / thread
+                                     save ? tile_ptr(save + (long)(kSaveAct + 256 * (l - 1)) * Ppad, wave_tile, 256, lane) : nullptr,
+                                     epi);
+        if (save && l < 8) {
+            u32x4 m = {bits[0], bits[1], bits[2], bits[3]};
+            *reinterpret_cast<u32x4*>(mask_ptr<PD>(save, P, l, wave_tile, lane)) = m;
+        }
         if (l == 7) {
             // density head on the VALU: sigma = w_alpha . h8 + b  (half of the features per lane)
-            const float* wa = wpk + V::kFwdAlphaW;
+            const float* wa = wpk + V::kFwdAlphaW;          // lane-vector layout
 #pragma unroll
-            for (int i = 0; i < 128; ++i) {
-                const float w0 = wa[2 * i], w1 = wa[2 * i + 1];
-                sigma_part = fmaf(h ? w1 : w0, hreg[i], sigma_part);
-            }
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w = lane_vec(wa, t, q, h);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sigma_part = fmaf(w[j], hreg[16 * t + 4 * q + j], sigma_part);
+                }
         }
     }
 
@@ -191,18 +243,18 @@ extern "C" long long scnerf_mlp_grad_floats(long long n_samples) {
     return (long long)kGradPerSample * padded_samples(n_samples);
 }
 
-template <int PD>
+template <int PD, bool TRAIN>
 static int launch_fwd(const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
                       const float* wpacked, float* raw, float* save, long long n_samples, hipStream_t st) {
-    // weights (2 x 32 KB) + the parked encoding of the 256 threads
-    const size_t lds = (size_t)(2 * kMaxChunkFwd + Var<PD>::kES * kThreads) * sizeof(float);
+    // weights (3 x 32 KB) + the parked encoding of the 256 threads
+    const size_t lds = (size_t)(kStreamBufs * kMaxChunkFwd + Var<PD>::kES * kThreads) * sizeof(float);
     static bool lds_opt_in = false;          // > 64 KB of dynamic LDS needs the per-kernel opt-in
     if (!lds_opt_in) {
-        SCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<PD>),
+        SCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<PD, TRAIN>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_opt_in = true;
     }
-    hipLaunchKernelGGL(mlp_fwd_kernel<PD>, dim3(scn_ceil_div(n_samples, kSamplesPerBlock)), dim3(kThreads), lds,
+    hipLaunchKernelGGL((mlp_fwd_kernel<PD, TRAIN>), dim3(scn_ceil_div(n_samples, kSamplesPerBlock)), dim3(kThreads), lds,
                        st, pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, (long)n_samples);
     return scn_launch_status();
 }
@@ -213,7 +265,10 @@ extern "C" int scnerf_mlp_fwd(int pt_dims, const float* pts, const float* viewdi
     SCN_RETURN_IF(!pts || !viewdirs || !wpacked || !raw || samples_per_ray < 1 || vd_stride < 3 || n_samples < 0, SCN_EINVAL);
     SCN_RETURN_IF(pt_dims != 3 && pt_dims != 4, SCN_EINVAL);
     if (n_samples == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
     if (pt_dims == 3)
-        return launch_fwd<3>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, n_samples, (hipStream_t)stream);
-    return launch_fwd<4>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, n_samples, (hipStream_t)stream);
+        return save ? launch_fwd<3, true>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, n_samples, st)
+                    : launch_fwd<3, false>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, n_samples, st);
+    return save ? launch_fwd<4, true>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, n_samples, st)
+                : launch_fwd<4, false>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, n_samples, st);
 }

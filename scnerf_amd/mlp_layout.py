@@ -104,6 +104,21 @@ def _feat_step(step, half):
     return feat_of(step // 16, step % 16, half)
 
 
+def lane_vector_table(base: int, n_valid: int, ntiles: int) -> np.ndarray:
+    """Per-feature vectors (biases, the density head's weights) in the order a lane loads them: entry
+    ((4 t + q) * 2 + h) * 4 + j holds feature feat_of(t, 4 q + j, h) -- one 16-byte load per (tile, quarter)
+    with the lane half h as part of the address, no scalar loads + per-register selects."""
+    idx = np.full(ntiles * 16 * 2, -1, np.int32)
+    for t in range(ntiles):
+        for q in range(4):
+            for h in range(2):
+                for j in range(4):
+                    n = feat_of(t, 4 * q + j, h)
+                    if n < n_valid:
+                        idx[((4 * t + q) * 2 + h) * 4 + j] = base + n
+    return idx
+
+
 MASK_WORDS_PER_SAMPLE = 9 * 8     # lane-native ReLU bit masks behind the row sections
 GRAD_SECTIONS = [("dz%d" % l, W) for l in range(D)] + [("dfeat", W), ("dzv", W // 2)]
 GRAD_FLOATS_PER_SAMPLE = sum(w for _, w in GRAD_SECTIONS)      # 2432
@@ -155,7 +170,7 @@ class Layout:
                           + [Part("L0T", 128, self.e_tiles, self.e_cs)])
         self.fwd_stream = sum(p.floats for p in self.fwd_parts)
         self.bwd_stream = sum(p.floats for p in self.bwd_parts)
-        # tail sections of the packed forward buffer (half-pair layout [(16 t + r) * 2 + h])
+        # tail sections of the packed forward buffer (lane-vector layout, see lane_vector_table)
         self.fwd_bias = self.fwd_stream                 # 8 trunk layers x 256
         self.fwd_bias_f = self.fwd_bias + 8 * 256
         self.fwd_bias_v = self.fwd_bias_f + 256
@@ -225,15 +240,7 @@ class Layout:
             out.append(_part_index(p, s))
 
         def halfpair(bname, n_valid, ntiles):
-            base = po[bname]
-            idx = np.full(ntiles * 16 * 2, -1, np.int32)
-            for t in range(ntiles):
-                for r in range(16):
-                    for h in range(2):
-                        n = feat_of(t, r, h)
-                        if n < n_valid:
-                            idx[(16 * t + r) * 2 + h] = base + n
-            return idx
+            return lane_vector_table(po[bname], n_valid, ntiles)
 
         for l in range(D):
             out.append(halfpair("pts_linears.%d.bias" % l, W, 8))
@@ -291,12 +298,7 @@ class Layout:
                 l = int(p.name[1])
                 s = dense_t("pts_linears.%d.weight" % l, W, ident(W), _feat_step)
             out.append(_part_index(p, s))
-        idx = np.full(256, -1, np.int32)
-        for t in range(8):
-            for r in range(16):
-                for h in range(2):
-                    idx[(16 * t + r) * 2 + h] = po["alpha_linear.weight"] + feat_of(t, r, h)
-        out.append(idx)
+        out.append(lane_vector_table(po["alpha_linear.weight"], W, 8))
         idx = np.concatenate(out)
         assert idx.shape[0] == self.bwd_total
         return idx

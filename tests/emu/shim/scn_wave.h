@@ -74,6 +74,10 @@ inline int popcount64(unsigned long long m) { return __builtin_popcountll(m); }
 
 inline void block_sync() { simt::block_barrier(); }
 inline void sched_fence() {}
+inline float max_raw(float a, float b) { return a > b ? a : b; }
+inline unsigned shift_in_positive(unsigned bits, float v) { return bits + bits + (v > 0.f ? 1u : 0u); }
+template <int N> inline void sched_group_mfma() {}
+template <int N> inline void sched_group_valu() {}
 
 template <typename T>
 inline T* dynamic_lds() { return reinterpret_cast<T*>(simt::block_lds()); }
