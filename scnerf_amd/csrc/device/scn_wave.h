@@ -46,6 +46,9 @@ __device__ __forceinline__ void block_sync() { __syncthreads(); }
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // scheduling-group hints (LLVM AMDGPU sched_group_barrier): the next `n` MFMA / VALU instructions of the
 // region form one group; groups are emitted in the order the hints appear
+// tells the compiler a value is the same in every lane of the wave (lives in an SGPR; branches on it are real)
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // max without the canonicalising self-max the compiler adds in front of fmaxf under IEEE mode (v_max_f32
 // quiets signalling NaNs by itself): one instruction, and VALU instructions are not free next to fp32
 // MFMAs -- both run on the SIMD's fp32 lanes (tools/ubench/mfma_valu.hip: ~4.5 cycles per VALU op).
@@ -58,6 +61,15 @@ __device__ __forceinline__ float max_raw(float a, float b) {
 __device__ __forceinline__ unsigned shift_in_positive(unsigned bits, float v) {
     asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(v) : "vcc");
     return bits;
+}
+// v if bit `pos` of `bits` is set, else +0: sign-extended 1-bit field extract (0 / ~0) and one AND
+template <int POS>
+__device__ __forceinline__ float keep_if_bit(float v, unsigned bits) {
+    int m;
+    float r;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(bits), "n"(POS));
+    asm("v_and_b32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(m));
+    return r;
 }
 template <int N> __device__ __forceinline__ void sched_group_mfma() { __builtin_amdgcn_sched_group_barrier(0x008, N, 0); }
 template <int N> __device__ __forceinline__ void sched_group_valu() { __builtin_amdgcn_sched_group_barrier(0x002, N, 0); }

@@ -495,10 +495,19 @@ __device__ __forceinline__ u32x4 relu_bits(const float (&v)[N]) {
     return bits;
 }
 
-// v if the mask bit of element i is set, else +0 (bitwise AND with 0 / ~0: v_bfe_i32 + v_and_b32)
+// v if the mask bit of element i is set, else +0 (v_bfe_i32 + v_and_b32; i must be a compile-time constant
+// after unrolling)
 __device__ __forceinline__ float mask_select(float v, u32x4 bits, int i) {
-    const int m = -(int)((bits[i >> 5] >> (31 - (i & 31))) & 1u);
-    return __int_as_float(__float_as_int(v) & m);
+    const unsigned w = bits[i >> 5];
+    switch (31 - (i & 31)) {
+#define SCN_CASE(P) case P: return keep_if_bit<P>(v, w);
+        SCN_CASE(0) SCN_CASE(1) SCN_CASE(2) SCN_CASE(3) SCN_CASE(4) SCN_CASE(5) SCN_CASE(6) SCN_CASE(7)
+        SCN_CASE(8) SCN_CASE(9) SCN_CASE(10) SCN_CASE(11) SCN_CASE(12) SCN_CASE(13) SCN_CASE(14) SCN_CASE(15)
+        SCN_CASE(16) SCN_CASE(17) SCN_CASE(18) SCN_CASE(19) SCN_CASE(20) SCN_CASE(21) SCN_CASE(22) SCN_CASE(23)
+        SCN_CASE(24) SCN_CASE(25) SCN_CASE(26) SCN_CASE(27) SCN_CASE(28) SCN_CASE(29) SCN_CASE(30) SCN_CASE(31)
+#undef SCN_CASE
+    }
+    return v;
 }
 
 template <int PD>

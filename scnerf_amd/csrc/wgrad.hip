@@ -12,6 +12,8 @@
 // whole [BN x BK] output for a contiguous chunk of samples, staging 16 samples at a time through
 // double-buffered LDS; partial results go to a workspace and a second kernel reduces them in a
 // fixed order (deterministic; 64 MB per 256x256 layer at 256 chunks is ~25 us of HBM time).
+#include <type_traits>
+
 #include <scn_wave.h>
 
 #include "launch.h"
@@ -54,7 +56,9 @@ __device__ __forceinline__ int lds_piece_offset(int e, int width, int tiled) {
     return m * (width + 4) + c;
 }
 
-template <int WN, int WK>
+// FAST: both operands tile-native -- every staged piece exists (the sections are padded), so the loads are
+// unconditional; otherwise rows beyond P / columns beyond n_load of a row-major operand read as zero.
+template <int WN, int WK, bool FAST>
 __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
     constexpr int BN = 2 * WN * 32, BK = 2 * WK * 32;
     constexpr int LDA = BN + 4, LDB = BK + 4;              // padded LDS row strides
@@ -64,6 +68,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
     float* lds = dynamic_lds<float>();
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const int wn = wave >> 1, wk = wave & 1;
+    const int wk_uniform = uniform(wk);
     const int li = lane & 31, mh = lane >> 5;
     const long p_begin = (long)blockIdx.x * a.chunk;
     const long p_lim = a.Ppad;                              // tiles exist up to here
@@ -111,17 +116,24 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
         const float* Bs0 = a.B + p0 * a.ldb;
         const int rows = (int)min((long)kMS, a.P - p0);       // valid rows of a row-major operand
         const int rows_a = a.a_tiled ? kMS : rows, rows_b = a.b_tiled ? kMS : rows;
+        if constexpr (FAST) {
 #pragma unroll
-        for (int q = 0; q < A_F4; ++q) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (a_row[q] < rows_a) v = *reinterpret_cast<const f32x4*>(As0 + a_src[q]);
-            sa[q] = v;
-        }
+            for (int q = 0; q < A_F4; ++q) sa[q] = *reinterpret_cast<const f32x4*>(As0 + (q * kThreads + tid) * 4);
 #pragma unroll
-        for (int q = 0; q < B_F4; ++q) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (b_row[q] < rows_b) v = *reinterpret_cast<const f32x4*>(Bs0 + b_src[q]);
-            sb[q] = v;
+            for (int q = 0; q < B_F4; ++q) sb[q] = *reinterpret_cast<const f32x4*>(Bs0 + (q * kThreads + tid) * 4);
+        } else {
+#pragma unroll
+            for (int q = 0; q < A_F4; ++q) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (a_row[q] < rows_a) v = *reinterpret_cast<const f32x4*>(As0 + a_src[q]);
+                sa[q] = v;
+            }
+#pragma unroll
+            for (int q = 0; q < B_F4; ++q) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (b_row[q] < rows_b) v = *reinterpret_cast<const f32x4*>(Bs0 + b_src[q]);
+                sb[q] = v;
+            }
         }
     };
     auto commit = [&](int buf) {
@@ -137,6 +149,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
         commit(0);
     }
     block_sync();
+    // (unrolling the stage loop by two to make `buf` a compile-time constant spills: 632 B/lane of scratch)
     for (int st = 0; st < n_stage; ++st) {
         const int buf = st & 1;
         const bool more = st + 1 < n_stage;
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
             for (int i = 0; i < WN; ++i)
 #pragma unroll
                 for (int j = 0; j < WK; ++j) acc[i][j] = mfma_32x32x2(av[cur][i], bv[cur][j], acc[i][j]);
-            if (wk == 0) {
+            if (wk_uniform == 0) {       // wave-uniform: a real branch, not 2 x WN selects for every wave
 #pragma unroll
                 for (int i = 0; i < WN; ++i) bsum[i] += av[cur][i];
             }
@@ -284,18 +297,25 @@ __global__ __launch_bounds__(256) void vecmat_reduce_kernel(const float* __restr
     else if (k == 256 && dvsum) *dvsum = sum_partials(part + 256, 257, G);
 }
 
-template <int WN, int WK>
-int launch_wgrad(const WgradArgs& a, int G, hipStream_t stream) {
+template <int WN, int WK, bool FAST>
+int launch_wgrad_impl(const WgradArgs& a, int G, hipStream_t stream) {
     constexpr int BN = 2 * WN * 32, BK = 2 * WK * 32;
     const size_t lds = (size_t)2 * kMS * (BN + 4 + BK + 4) * sizeof(float);
     static bool opted_in = false;           // > 64 KB of dynamic LDS needs the per-kernel opt-in
     if (!opted_in && lds > 64 * 1024) {
-        SCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<WN, WK>),
+        SCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<WN, WK, FAST>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         opted_in = true;
     }
-    hipLaunchKernelGGL((wgrad_kernel<WN, WK>), dim3(G), dim3(kThreads), lds, stream, a);
+    hipLaunchKernelGGL((wgrad_kernel<WN, WK, FAST>), dim3(G), dim3(kThreads), lds, stream, a);
     return scn_launch_status();
+}
+
+template <int WN, int WK>
+int launch_wgrad(const WgradArgs& a, int G, hipStream_t stream) {
+    constexpr int BN = 2 * WN * 32, BK = 2 * WK * 32;
+    if (a.a_tiled && a.b_tiled && a.n_load == BN && a.k_load == BK) return launch_wgrad_impl<WN, WK, true>(a, G, stream);
+    return launch_wgrad_impl<WN, WK, false>(a, G, stream);
 }
 
 
