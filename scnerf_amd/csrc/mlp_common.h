@@ -238,52 +238,58 @@ __device__ __forceinline__ void store_tiles(const float (&regs)[N], float* tile)
 // CONT_OUT: fetch the next chunk's first pair from the next buffer (same part: same fragment geometry).
 template <int NSTEP, int NT, int CS, int B0, int N_F4, bool CONT_IN, bool CONT_OUT>
 __device__ __forceinline__ void mfma_chunk(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
-                                           const f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1], f32x4 (&ring)[4], int lane) {
+                                           const f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1], f32x4 (&ring)[8], int lane) {
     constexpr int G = CS / 4;
     constexpr int NF = G * NT;                 // fragments, order f = g * NT + t
     const f32x4* A = reinterpret_cast<const f32x4*>(WStream::buf(ws.cur)) + lane;
     if constexpr (NT % 2 == 0) {
-        // Two tiles are interleaved so that consecutive MFMAs never target the same accumulator
-        // (a 4-deep dependent chain on one accumulator issues measurably slower than 64 cycles).
-        constexpr int NP = NF / 2;             // fragment pairs (tiles t, t+1 of the same 4 steps)
-        static_assert(NP % 2 == 0 || !(CONT_IN || CONT_OUT), "ring parity across chunks");
+        // IW tiles are interleaved so that consecutive MFMAs never target the same accumulator: a dependent
+        // chain on one accumulator issues slower than 64 cycles (tools/ubench/mfma_dep.hip: 145 / 148 / 151 /
+        // 154 TFLOP/s with 1 / 2 / 4 / 8 independent chains).
+#ifndef SCN_IW
+#define SCN_IW 2      // (4-way measured: forward -0.3 %, dgrad +1.8 % -- no gain next to the LDS traffic; 2 kept)
+#endif
+        constexpr int IW = (NT % 4 == 0) ? SCN_IW : 2;
+        constexpr int NB = NF / IW;            // fragment bundles (tiles t .. t+IW-1 of the same 4 steps)
+        static_assert(NB % 2 == 0 || !(CONT_IN || CONT_OUT), "ring parity across chunks");
 #ifndef SCN_COMMIT_NUM
 #define SCN_COMMIT_NUM 2
 #define SCN_COMMIT_DEN 4
 #define SCN_SYNC_NUM 3
 #define SCN_SYNC_DEN 4
 #endif
-        constexpr int COMMIT_AT = (NP * SCN_COMMIT_NUM) / SCN_COMMIT_DEN;
-        constexpr int SYNC_AT = (NP * SCN_SYNC_NUM) / SCN_SYNC_DEN >= NP ? NP - 1 : (NP * SCN_SYNC_NUM) / SCN_SYNC_DEN;
+        constexpr int COMMIT_AT = (NB * SCN_COMMIT_NUM) / SCN_COMMIT_DEN;
+        constexpr int SYNC_AT = (NB * SCN_SYNC_NUM) / SCN_SYNC_DEN >= NB ? NB - 1 : (NB * SCN_SYNC_NUM) / SCN_SYNC_DEN;
         const f32x4* An = reinterpret_cast<const f32x4*>(WStream::buf(ws.next())) + lane;
         if constexpr (!CONT_IN) {
-            ring[0] = A[((0 % NT) * G + 0 / NT) * 64];
-            ring[1] = A[((1 % NT) * G + 1 / NT) * 64];
+#pragma unroll
+            for (int k = 0; k < IW; ++k) ring[k] = A[((k % NT) * G + k / NT) * 64];
         }
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
+        for (int p = 0; p < NB; ++p) {
             if (p == COMMIT_AT) stream_commit<N_F4>(ws, stage);
             if (p == SYNC_AT) {
 #ifndef SCN_ABLATE_NO_BARRIER      // (timing experiments only: tools/ablate.sh)
                 block_sync();
 #endif
             }
-            if (p + 1 < NP) {
-                const int f = 2 * p + 2;
-                ring[2 * ((p + 1) & 1) + 0] = A[((f % NT) * G + f / NT) * 64];
-                ring[2 * ((p + 1) & 1) + 1] = A[(((f + 1) % NT) * G + (f + 1) / NT) * 64];
-            } else if constexpr (CONT_OUT) {
-                ring[0] = An[((0 % NT) * G + 0 / NT) * 64];
-                ring[1] = An[((1 % NT) * G + 1 / NT) * 64];
-            }
-            sched_fence();      // keep the reads one pair (512 MFMA cycles) ahead of their use
-            const int f = 2 * p, g = f / NT, t = f % NT;
-            const f32x4 a0 = ring[2 * (p & 1)], a1 = ring[2 * (p & 1) + 1];
+            if (p + 1 < NB) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[t] = mfma_32x32x2(a0[j], b[B0 + 4 * g + j], acc[t]);
-                acc[t + 1] = mfma_32x32x2(a1[j], b[B0 + 4 * g + j], acc[t + 1]);
+                for (int k = 0; k < IW; ++k) {
+                    const int f = IW * (p + 1) + k;
+                    ring[IW * ((p + 1) & 1) + k] = A[((f % NT) * G + f / NT) * 64];
+                }
+            } else if constexpr (CONT_OUT) {
+#pragma unroll
+                for (int k = 0; k < IW; ++k) ring[k] = An[((k % NT) * G + k / NT) * 64];
             }
+            sched_fence();      // keep the reads one bundle ahead of their use
+            const int f = IW * p, g = f / NT, t = f % NT;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < IW; ++k)
+                    acc[t + k] = mfma_32x32x2(ring[IW * (p & 1) + k][j], b[B0 + 4 * g + j], acc[t + k]);
         }
     } else {
         static_assert(!CONT_IN && !CONT_OUT, "single-tile parts do not chain");
@@ -329,7 +335,7 @@ struct LastChunk {
     static constexpr int G = CS / 4, NPAIR = NT / 2, NQ = NPAIR * G;
     static constexpr int P = Q / G, g = Q % G;
     static __device__ __forceinline__ void run(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
-                                               const f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1], f32x4 (&ring)[4],
+                                               const f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1], f32x4 (&ring)[8],
                                                const f32x4* A, EPI& epi) {
         if constexpr (Q == NQ / 2) stream_commit<N_F4>(ws, stage);
         if constexpr (Q == (NQ * 3) / 4) {
@@ -383,7 +389,7 @@ struct LastChunk {
 
 template <int NSTEP, int NT, int CS, int B0, int N_F4, bool CONT_IN, class EPI>
 __device__ __forceinline__ void mfma_chunk_last(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
-                                                const f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1], f32x4 (&ring)[4],
+                                                const f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1], f32x4 (&ring)[8],
                                                 int lane, EPI& epi) {
     static_assert(NT % 2 == 0 && CS == 16, "tile-pair-major last chunk: 4 step groups");
     constexpr int G = CS / 4;
@@ -403,10 +409,10 @@ struct PartLoop {
 #ifdef SCN_NO_CHAIN
     static constexpr bool CHAIN = false;
 #else
-    static constexpr bool CHAIN = (NT % 2 == 0) && (((CS / 4) * NT / 2) % 2 == 0);
+    static constexpr bool CHAIN = (NT % 2 == 0) && (((CS / 4) * NT / ((NT % 4 == 0) ? SCN_IW : 2)) % 2 == 0);
 #endif
     static __device__ __forceinline__ void run(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
-                                               f32x4 (&ring)[4], int lane, float* save_tile, EPI& epi) {
+                                               f32x4 (&ring)[8], int lane, float* save_tile, EPI& epi) {
         f32x4 stage[N_F4 > 0 ? N_F4 : 1];
         stream_issue<N_F4>(ws, stage);
         sched_fence();      // the loads stay at the head of the chunk: half a chunk of MFMAs covers them
@@ -433,7 +439,7 @@ __device__ __forceinline__ void mfma_part(const float (&b)[NSTEP], f32x16 (&acc)
                                           float* save_tile = nullptr) {
     static_assert(NSTEP % CS == 0 && CS % 4 == 0, "chunking");
     static_assert((NT * CS * 64) % (4 * kThreads) == 0, "chunk must be whole 16-byte loads per thread");
-    f32x4 ring[4];
+    f32x4 ring[8];
     NoEpi none;
     PartLoop<NSTEP, NT, CS, NEXT_F4, 0, NoEpi>::run(b, acc, ws, ring, lane_id(), save_tile, none);
 }
@@ -442,7 +448,7 @@ template <int NSTEP, int NT, int CS, int NEXT_F4, class EPI>
 __device__ __forceinline__ void mfma_part_epi(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
                                               float* save_tile, EPI& epi) {
     static_assert(NSTEP % CS == 0 && CS % 4 == 0, "chunking");
-    f32x4 ring[4];
+    f32x4 ring[8];
     PartLoop<NSTEP, NT, CS, NEXT_F4, 0, EPI>::run(b, acc, ws, ring, lane_id(), save_tile, epi);
 }
 
