@@ -122,3 +122,82 @@ def sample_pdf(bins, weights, N_samples, det=False, _u=None):
     else:
         u = torch.rand(*(dots_sh + [N_samples]), device=bins.device)
     return _SamplePdf.apply(bins, weights.detach(), u)
+
+
+_IMAGE_KEYS = (("rgb", 3), ("fg_rgb", 3), ("fg_depth", 1), ("bg_rgb", 3), ("bg_depth", 1), ("bg_lambda", 1))
+
+
+def render_single_image(rank, world_size, models, ray_sampler, chunk_size, camera_model, camera_idx=None):
+    """(ddp_train_nerf.py:135-257) render every pixel of one image with the cascade of `models`, the rays
+    split evenly over the `world_size` processes; rank 0 returns one OrderedDict per cascade level with
+    [H, W(, 3)] CPU tensors (rgb, fg_rgb, fg_depth, bg_rgb, bg_depth, bg_lambda), the other ranks None.
+
+    Same sampling as the reference (level 0: evenly spaced depths without jitter; later levels: the
+    deterministic inverse-CDF samples merged by a sort).  MI355X differences: the per-chunk results stay on
+    the GPU and are packed (12 floats per ray) so that ONE gather per level moves them (the reference does
+    one CPU gather per key, after a `.cpu()` per key and chunk)."""
+    from collections import OrderedDict
+    import torch.distributed as dist
+    with torch.no_grad():
+        if camera_idx is not None:
+            ray_batch = ray_sampler.get_all(camera_model, camera_idx, None, rank)
+        else:
+            ray_batch = ray_sampler.get_all(camera_model, None, ray_sampler, rank)
+    n_pix = ray_batch['ray_d'].shape[0]
+    if (n_pix // world_size) * world_size != n_pix:
+        raise Exception('Number of pixels in the image is not divisible by the number of GPUs!\n\t# pixels: {}\n\t# GPUs: {}'
+                        .format(n_pix, world_size))
+    per = n_pix // world_size
+    device = torch.device("cuda", rank) if isinstance(rank, int) else torch.device(rank)
+    mine = {k: v[rank * per:(rank + 1) * per].to(device) for k, v in ray_batch.items() if torch.is_tensor(v)}
+    levels = models['cascade_level']
+    packed = [torch.empty((per, 12), dtype=torch.float32, device=device) for _ in range(levels)]
+    with torch.no_grad():
+        for s0 in range(0, per, chunk_size):
+            sl = slice(s0, min(per, s0 + chunk_size))
+            ray_o, ray_d, min_depth = mine['ray_o'][sl], mine['ray_d'][sl], mine['min_depth'][sl]
+            dots_sh = list(ray_d.shape[:-1])
+            ret = None
+            for m in range(levels):
+                net = models['net_{}'.format(m)]
+                N_samples = models['cascade_samples'][m]
+                if m == 0:
+                    fg_far_depth = intersect_sphere(ray_o, ray_d)
+                    step = (fg_far_depth - min_depth) / (N_samples - 1)
+                    fg_depth = torch.stack([min_depth + i * step for i in range(N_samples)], dim=-1)
+                    bg_depth = torch.linspace(0., 1., N_samples).view([1] * len(dots_sh) + [N_samples]) \
+                        .expand(dots_sh + [N_samples]).to(device)
+                else:
+                    fg_mid = .5 * (fg_depth[..., 1:] + fg_depth[..., :-1])
+                    fg_s = sample_pdf(bins=fg_mid, weights=ret['fg_weights'][..., 1:-1], N_samples=N_samples, det=True)
+                    fg_depth, _ = torch.sort(torch.cat((fg_depth, fg_s), dim=-1))
+                    bg_mid = .5 * (bg_depth[..., 1:] + bg_depth[..., :-1])
+                    bg_s = sample_pdf(bins=bg_mid, weights=ret['bg_weights'][..., 1:-1], N_samples=N_samples, det=True)
+                    bg_depth, _ = torch.sort(torch.cat((bg_depth, bg_s), dim=-1))
+                ret = net(ray_o, ray_d, fg_far_depth, fg_depth, bg_depth)
+                c = 0
+                for key, w in _IMAGE_KEYS:
+                    packed[m][sl, c:c + w] = ret[key].reshape(-1, w)
+                    c += w
+    out = None
+    for m in range(levels):
+        if world_size > 1:
+            gathered = [torch.empty_like(packed[m]) for _ in range(world_size)] if rank == 0 else None
+            if dist.get_backend() == "gloo":
+                src = packed[m].cpu()
+                gathered = [torch.empty_like(src) for _ in range(world_size)] if rank == 0 else None
+                dist.gather(src, gathered, dst=0)
+            else:
+                dist.gather(packed[m], gathered, dst=0)
+            full = torch.cat(gathered, 0) if rank == 0 else None
+        else:
+            full = packed[m]
+        if rank == 0 or world_size == 1:
+            if out is None:
+                out = [OrderedDict() for _ in range(levels)]
+            full = full.cpu()
+            c = 0
+            for key, w in _IMAGE_KEYS:
+                out[m][key] = full[:, c:c + w].reshape((ray_sampler.H, ray_sampler.W, -1)).squeeze()
+                c += w
+    return out if (rank == 0 or world_size == 1) else None

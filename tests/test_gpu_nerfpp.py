@@ -249,3 +249,37 @@ def test_create_nerf_models_optimizer_and_checkpoint(tmp_path):
     assert l2a == l2b
     for a, b in zip(models["net_0"].parameters(), models2["net_0"].parameters()):
         assert torch.equal(a, b)
+
+
+def test_render_single_image_matches_direct_evaluation():
+    """NeRF++ inference driver (ddp_train_nerf.py:135-257): chunked, deterministic cascade; equals evaluating
+    all rays of the image in one go, level by level."""
+    from collections import OrderedDict
+    from scnerf_amd.nerfplusplus import ddp_train_nerf as TR
+    Hh, Ww = 12, 20
+    o, d, near = synth.nerfpp_rays(Hh * Ww, seed=41)
+
+    class Sampler:
+        H, W = Hh, Ww
+
+        def get_all(self, camera_model, camera_idx, sampler, rank):
+            return OrderedDict(ray_o=o, ray_d=d, depth=torch.zeros(Hh * Ww), rgb=None, mask=None, min_depth=near,
+                               img_name="x")
+    models = OrderedDict(cascade_level=2, cascade_samples=[16, 24], net_0=make_net(781), net_1=make_net(782))
+    out = TR.render_single_image(0, 1, models, Sampler(), 100, None, camera_idx=None)        # 240 rays in chunks of 100
+    assert len(out) == 2 and out[1]["rgb"].shape == (Hh, Ww, 3) and out[1]["fg_depth"].shape == (Hh, Ww)
+    with torch.no_grad():
+        oc, dc, nc = o.cuda(), d.cuda(), near.cuda()
+        far = TR.intersect_sphere(oc, dc)
+        step = (far - nc) / 15
+        fg = torch.stack([nc + i * step for i in range(16)], dim=-1)
+        bg = torch.linspace(0., 1., 16).expand(Hh * Ww, 16).cuda()
+        r0 = models["net_0"](oc, dc, far, fg, bg)
+        fg1, _ = torch.sort(torch.cat((fg, TR.sample_pdf(.5 * (fg[..., 1:] + fg[..., :-1]), r0["fg_weights"][..., 1:-1], 24, det=True)), -1))
+        bg1, _ = torch.sort(torch.cat((bg, TR.sample_pdf(.5 * (bg[..., 1:] + bg[..., :-1]), r0["bg_weights"][..., 1:-1], 24, det=True)), -1))
+        r1 = models["net_1"](oc, dc, far, fg1, bg1)
+    np.testing.assert_array_equal(out[0]["rgb"].numpy().reshape(-1, 3), r0["rgb"].cpu().numpy())
+    np.testing.assert_array_equal(out[1]["rgb"].numpy().reshape(-1, 3), r1["rgb"].cpu().numpy())
+    np.testing.assert_array_equal(out[1]["bg_lambda"].numpy().reshape(-1), r1["bg_lambda"].cpu().numpy())
+    with pytest.raises(Exception, match="not divisible"):
+        TR.render_single_image(0, 7, models, Sampler(), 100, None)
