@@ -49,6 +49,14 @@ __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0
 // tells the compiler a value is the same in every lane of the wave (lives in an SGPR; branches on it are real)
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+template <typename T>
+__device__ __forceinline__ const T* uniform_ptr(const T* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
+}
+
 // max without the canonicalising self-max the compiler adds in front of fmaxf under IEEE mode (v_max_f32
 // quiets signalling NaNs by itself): one instruction, and VALU instructions are not free next to fp32
 // MFMAs -- both run on the SIMD's fp32 lanes (tools/ubench/mfma_valu.hip: ~4.5 cycles per VALU op).
