@@ -213,14 +213,8 @@ extern "C" int scnerf_mlp_bwd(int pt_dims, const float* d_raw, const float* pts,
     SCN_RETURN_IF(samples_per_ray < 1 || vd_stride < 3 || n_samples < 0 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
     if (n_samples == 0) return 0;
     const size_t lds = (size_t)kStreamBufs * kMaxChunkBwd * sizeof(float);      // 96 KB: needs the opt-in
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {
-        SCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<3>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<4>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_opt_in = true;
-    }
+    SCN_LDS_OPT_IN(mlp_bwd_kernel<3>, lds);
+    SCN_LDS_OPT_IN(mlp_bwd_kernel<4>, lds);
     const dim3 grid(scn_ceil_div(n_samples, kSamplesPerBlock));
     if (pt_dims == 3)
         hipLaunchKernelGGL(mlp_bwd_kernel<3>, grid, dim3(kThreads), lds, (hipStream_t)stream, d_raw, pts, viewdirs,

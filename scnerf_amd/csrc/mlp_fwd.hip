@@ -248,12 +248,7 @@ static int launch_fwd(const float* pts, const float* viewdirs, int vd_stride, in
                       const float* wpacked, float* raw, float* save, long long n_samples, hipStream_t st) {
     // weights (3 x 32 KB) + the parked encoding of the 256 threads
     const size_t lds = (size_t)(kStreamBufs * kMaxChunkFwd + Var<PD>::kES * kThreads) * sizeof(float);
-    static bool lds_opt_in = false;          // > 64 KB of dynamic LDS needs the per-kernel opt-in
-    if (!lds_opt_in) {
-        SCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<PD, TRAIN>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_opt_in = true;
-    }
+    SCN_LDS_OPT_IN((mlp_fwd_kernel<PD, TRAIN>), lds);
     hipLaunchKernelGGL((mlp_fwd_kernel<PD, TRAIN>), dim3(scn_ceil_div(n_samples, kSamplesPerBlock)), dim3(kThreads), lds,
                        st, pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, (long)n_samples);
     return scn_launch_status();

@@ -301,12 +301,7 @@ template <int WN, int WK, bool FAST>
 int launch_wgrad_impl(const WgradArgs& a, int G, hipStream_t stream) {
     constexpr int BN = 2 * WN * 32, BK = 2 * WK * 32;
     const size_t lds = (size_t)2 * kMS * (BN + 4 + BK + 4) * sizeof(float);
-    static bool opted_in = false;           // > 64 KB of dynamic LDS needs the per-kernel opt-in
-    if (!opted_in && lds > 64 * 1024) {
-        SCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<WN, WK, FAST>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        opted_in = true;
-    }
+    if (lds > 64 * 1024) SCN_LDS_OPT_IN((wgrad_kernel<WN, WK, FAST>), lds);
     hipLaunchKernelGGL((wgrad_kernel<WN, WK, FAST>), dim3(G), dim3(kThreads), lds, stream, a);
     return scn_launch_status();
 }

@@ -39,6 +39,7 @@ inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::m
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 enum hipFuncAttribute_emu { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...)                              \
