@@ -297,6 +297,34 @@ __global__ __launch_bounds__(256) void vecmat_reduce_kernel(const float* __restr
     else if (k == 256 && dvsum) *dvsum = sum_partials(part + 256, 257, G);
 }
 
+// ---- all reductions of one network pass in ONE launch -----------------------------------------------
+// (13 dependent ~20 us launches between the GEMMs kept them from overlapping at their tails)
+struct ReduceJob {
+    const float* part_w; const float* part_b;
+    float* dW; float* db;
+    int G, BN, BK, n_out, k_out, ldo, col0;
+    int block0;                 // first block of this job in the merged grid
+};
+constexpr int kMaxJobs = 16;
+struct ReduceJobs { ReduceJob j[kMaxJobs]; int n; };
+
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReduceJobs jobs) {
+    int q = 0;
+#pragma unroll 1
+    for (int i = 1; i < jobs.n; ++i)
+        if ((int)blockIdx.x >= jobs.j[i].block0) q = i;
+    const ReduceJob& J = jobs.j[q];
+    const long idx = (long)(blockIdx.x - J.block0) * blockDim.x + threadIdx.x;
+    const long nw = (long)J.n_out * J.k_out;
+    if (idx < nw) {
+        const int n = (int)(idx / J.k_out), k = (int)(idx % J.k_out);
+        J.dW[(long)n * J.ldo + J.col0 + k] = sum_partials(J.part_w + (long)n * J.BK + k, (long)J.BN * J.BK, J.G);
+        return;
+    }
+    const long j = idx - nw;
+    if (J.db && j < J.n_out) J.db[j] = sum_partials(J.part_b + j, J.BN, J.G);
+}
+
 template <int WN, int WK, bool FAST>
 int launch_wgrad_impl(const WgradArgs& a, int G, hipStream_t stream) {
     constexpr int BN = 2 * WN * 32, BK = 2 * WK * 32;
@@ -334,9 +362,11 @@ extern "C" long long scnerf_wgrad_workspace_floats(int n_load, int k_load, int n
     return (long long)n_chunks * ((long long)s.BN * s.BK + s.BN);
 }
 
-extern "C" int scnerf_wgrad(const float* dz, int lda, int n_load, int n_out, int dz_tiled, const float* x,
-                            int ldb, int k_load, int k_out, int x_tiled, long long n_samples, int n_chunks,
-                            float* workspace, float* dW, int ldo, int col0, float* db, void* stream) {
+namespace {
+// GEMM into partials at `workspace`; fills `job` (the reduction that finishes it) and returns the floats used
+int wgrad_gemm(const float* dz, int lda, int n_load, int n_out, int dz_tiled, const float* x, int ldb, int k_load,
+               int k_out, int x_tiled, long long n_samples, int n_chunks, float* workspace, float* dW, int ldo,
+               int col0, float* db, hipStream_t st, ReduceJob* job, long long* used) {
     SCN_RETURN_IF(!dz || !x || !workspace || !dW || n_samples < 0 || n_chunks < 1, SCN_EINVAL);
     SCN_RETURN_IF(lda % 4 || ldb % 4 || n_load % 4 || k_load % 4 || n_out > n_load || k_out > k_load, SCN_EINVAL);
     SCN_RETURN_IF(((uintptr_t)dz | (uintptr_t)x) & 15, SCN_EINVAL);
@@ -356,7 +386,6 @@ extern "C" int scnerf_wgrad(const float* dz, int lda, int n_load, int n_out, int
     const int G = n_chunks;
     a.part_w = workspace;
     a.part_b = a.part_w + (long)G * s.BN * s.BK;
-    hipStream_t st = (hipStream_t)stream;
     int rc;
     if (s.BN == 256 && s.BK == 256) rc = launch_wgrad<4, 4>(a, G, st);
     else if (s.BN == 256 && s.BK == 128) rc = launch_wgrad<4, 2>(a, G, st);
@@ -365,9 +394,26 @@ extern "C" int scnerf_wgrad(const float* dz, int lda, int n_load, int n_out, int
     else if (s.BN == 128 && s.BK == 64) rc = launch_wgrad<2, 1>(a, G, st);
     else rc = launch_wgrad<1, 2>(a, G, st);
     SCN_RETURN_IF(rc != 0, rc);
+    job->part_w = a.part_w; job->part_b = a.part_b; job->dW = dW; job->db = db;
+    job->G = G; job->BN = s.BN; job->BK = s.BK; job->n_out = n_out; job->k_out = k_out; job->ldo = ldo; job->col0 = col0;
+    job->block0 = 0;
+    *used = (long long)G * ((long long)s.BN * s.BK + s.BN);
+    return 0;
+}
+}  // namespace
+
+extern "C" int scnerf_wgrad(const float* dz, int lda, int n_load, int n_out, int dz_tiled, const float* x,
+                            int ldb, int k_load, int k_out, int x_tiled, long long n_samples, int n_chunks,
+                            float* workspace, float* dW, int ldo, int col0, float* db, void* stream) {
+    ReduceJob j;
+    long long used;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = wgrad_gemm(dz, lda, n_load, n_out, dz_tiled, x, ldb, k_load, k_out, x_tiled, n_samples, n_chunks,
+                              workspace, dW, ldo, col0, db, st, &j, &used);
+    SCN_RETURN_IF(rc != 0, rc);
     const long total = (long)n_out * k_out + (db ? n_out : 0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(scn_ceil_div(total, 256)), dim3(256), 0, st, a.part_w,
-                       a.part_b, G, s.BN, s.BK, n_out, k_out, dW, ldo, col0, db);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(scn_ceil_div(total, 256)), dim3(256), 0, st, j.part_w, j.part_b,
+                       j.G, j.BN, j.BK, n_out, k_out, dW, ldo, col0, db);
     return scn_launch_status();
 }
 
@@ -400,31 +446,48 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
     auto dz = [&](int l) { return G(kGradDz + 256 * l); };
     constexpr int EW = V::kEW, IN = V::kInCh, SK = V::kSkipLd;
     int rc;
-#define SCN_WG(...)                          \
-    rc = scnerf_wgrad(__VA_ARGS__, stream);  \
-    if (rc != 0) return rc;
+    ReduceJobs jobs;
+    jobs.n = 0;
+    float* ws = workspace + 257LL * n_chunks;          // [0, 257 G): the vecmat partials
+    hipStream_t st = (hipStream_t)stream;
+#define SCN_WG(...)                                                                            \
+    {                                                                                          \
+        long long used__ = 0;                                                                  \
+        rc = wgrad_gemm(__VA_ARGS__, st, &jobs.j[jobs.n], &used__);                            \
+        if (rc != 0) return rc;                                                                \
+        ws += used__;                                                                          \
+        ++jobs.n;                                                                              \
+    }
     // (dz, lda, n_load, n_out, tiled,  x, ldb, k_load, k_out, tiled,  P, chunks, ws, dW, ldo, col0, db)
     // layer 0: X = encoded points (row-major, IN valid of EW columns)
-    SCN_WG(dz(0), 256, 256, 256, 1, S(kSaveEpts), EW, EW, IN, 0, P, n_chunks, workspace, g + V::kW0, IN, 0, g + V::kB0)
+    SCN_WG(dz(0), 256, 256, 256, 1, S(kSaveEpts), EW, EW, IN, 0, P, n_chunks, ws, g + V::kW0, IN, 0, g + V::kB0)
     for (int l = 1; l <= 7; ++l) {
         if (l == 5) {
-            SCN_WG(dz(5), 256, 256, 256, 1, S(kSaveEpts), EW, EW, IN, 0, P, n_chunks, workspace, g + V::trunk_w(5), SK, 0, nullptr)
-            SCN_WG(dz(5), 256, 256, 256, 1, act(4), 256, 256, 256, 1, P, n_chunks, workspace, g + V::trunk_w(5), SK, IN, g + V::trunk_b(5))
+            SCN_WG(dz(5), 256, 256, 256, 1, S(kSaveEpts), EW, EW, IN, 0, P, n_chunks, ws, g + V::trunk_w(5), SK, 0, nullptr)
+            SCN_WG(dz(5), 256, 256, 256, 1, act(4), 256, 256, 256, 1, P, n_chunks, ws, g + V::trunk_w(5), SK, IN, g + V::trunk_b(5))
         } else {
-            SCN_WG(dz(l), 256, 256, 256, 1, act(l - 1), 256, 256, 256, 1, P, n_chunks, workspace, g + V::trunk_w(l), 256, 0, g + V::trunk_b(l))
+            SCN_WG(dz(l), 256, 256, 256, 1, act(l - 1), 256, 256, 256, 1, P, n_chunks, ws, g + V::trunk_w(l), 256, 0, g + V::trunk_b(l))
         }
     }
     // feature_linear; alpha_linear (one output row) = d sigma^T . act7 with d sigma = d_raw[:, 3]
-    SCN_WG(G(kGradDfeat), 256, 256, 256, 1, act(7), 256, 256, 256, 1, P, n_chunks, workspace, g + V::kWF, 256, 0, g + V::kBF)
+    SCN_WG(G(kGradDfeat), 256, 256, 256, 1, act(7), 256, 256, 256, 1, P, n_chunks, ws, g + V::kWF, 256, 0, g + V::kBF)
     rc = scnerf_vecmat(act(7), d_raw + 3, 4, P, n_chunks, workspace, g + V::kWA, g + V::kBA, stream);
     if (rc != 0) return rc;
     // views layer: [feature | encoded direction]
-    SCN_WG(G(kGradDzv), 128, 128, 128, 1, S(kSaveFeat), 256, 256, 256, 1, P, n_chunks, workspace, g + V::kWV, 283, 0, g + V::kBV)
-    SCN_WG(G(kGradDzv), 128, 128, 128, 1, S(kSaveEviews), 32, 32, 27, 0, P, n_chunks, workspace, g + V::kWV, 283, 256, nullptr)
+    SCN_WG(G(kGradDzv), 128, 128, 128, 1, S(kSaveFeat), 256, 256, 256, 1, P, n_chunks, ws, g + V::kWV, 283, 0, g + V::kBV)
+    SCN_WG(G(kGradDzv), 128, 128, 128, 1, S(kSaveEviews), 32, 32, 27, 0, P, n_chunks, ws, g + V::kWV, 283, 256, nullptr)
     // rgb_linear: dZ = d_raw[:, 0:3] (row-major), X = hidden of the views layer
-    SCN_WG(d_raw, 4, 4, 3, 0, S(kSaveHv), 128, 128, 128, 1, P, n_chunks, workspace, g + V::kWRGB, 128, 0, g + V::kBRGB)
+    SCN_WG(d_raw, 4, 4, 3, 0, S(kSaveHv), 128, 128, 128, 1, P, n_chunks, ws, g + V::kWRGB, 128, 0, g + V::kBRGB)
 #undef SCN_WG
-    return 0;
+    // one launch finishes all twelve GEMMs (fixed-order sums: deterministic)
+    int blocks = 0;
+    for (int i = 0; i < jobs.n; ++i) {
+        jobs.j[i].block0 = blocks;
+        const long total = (long)jobs.j[i].n_out * jobs.j[i].k_out + (jobs.j[i].db ? jobs.j[i].n_out : 0);
+        blocks += (int)scn_ceil_div(total, 256);
+    }
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), 0, st, jobs);
+    return scn_launch_status();
 }
 }  // namespace
 
@@ -438,5 +501,9 @@ extern "C" int scnerf_nerf_wgrad(int pt_dims, const float* save, const float* gr
 }
 
 extern "C" long long scnerf_nerf_wgrad_workspace_floats(int n_chunks) {
-    return scnerf_wgrad_workspace_floats(256, 256, n_chunks);
+    // every GEMM keeps its partials until the single reduction launch: 9 x (256 x 256), 2 x (256 x 128 | 64),
+    // (128 x 256), (128 x 64), (64 x 128) blocks + the vecmat partials
+    const long long G = n_chunks;
+    auto blk = [&](long long bn, long long bk) { return G * (bn * bk + bn); };
+    return 257 * G + 9 * blk(256, 256) + 2 * blk(256, 128) + blk(128, 256) + blk(128, 64) + blk(64, 128);
 }
