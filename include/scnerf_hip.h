@@ -213,9 +213,11 @@ int scnerf_vecmat(const float* x_tiled256, const float* vec, int vec_stride, lon
  * scnerf_nerf_wgrad_workspace_floats(n_chunks) floats. */
 int scnerf_nerf_param_count(int pt_dims);
 long long scnerf_nerf_wgrad_workspace_floats(int n_chunks);
+ /* accumulate != 0: flat_grad += the gradients (autograd's accumulation into an attached flat .grad
+ * buffer without 48 separate add kernels); 0: overwrite. */
 int scnerf_nerf_wgrad(int pt_dims, const float* save, const float* grads, const float* d_raw,
                       long long n_samples, int n_chunks, float* workspace, float* flat_grad,
-                      void* stream);
+                      int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ PRD loss --------- */
 

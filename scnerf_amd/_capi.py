@@ -57,7 +57,7 @@ PROTOTYPES = {
     "scnerf_mlp_fwd": [I, P, P, I, I, P, P, P, LL, P],
     "scnerf_mlp_bwd": [I, P, P, P, I, I, P, P, P, P, P, LL, P],
     "scnerf_nerf_param_count": [I],
-    "scnerf_nerf_wgrad": [I, P, P, P, LL, I, P, P, P],
+    "scnerf_nerf_wgrad": [I, P, P, P, LL, I, P, P, I, P],
     "scnerf_wgrad": [P, I, I, I, I, P, I, I, I, I, LL, I, P, P, I, I, P, P],
     "scnerf_vecmat": [P, P, I, LL, I, P, P, P, P],
 }

@@ -289,12 +289,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(
     if (db && j < n_out) db[j] = sum_partials(part_b + j, BN, G);
 }
 
-// dv[k] = sum_g part[g][k] (k < 256), *dvsum = sum_g part[g][256]
+// dv[k] (+)= sum_g part[g][k] (k < 256), *dvsum (+)= sum_g part[g][256]
 __global__ __launch_bounds__(256) void vecmat_reduce_kernel(const float* __restrict__ part, int G,
-                                                            float* __restrict__ dv, float* __restrict__ dvsum) {
+                                                            float* __restrict__ dv, float* __restrict__ dvsum,
+                                                            int accumulate) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < 256) dv[k] = sum_partials(part + k, 257, G);
-    else if (k == 256 && dvsum) *dvsum = sum_partials(part + 256, 257, G);
+    if (k < 256) {
+        const float v = sum_partials(part + k, 257, G);
+        dv[k] = accumulate ? dv[k] + v : v;
+    } else if (k == 256 && dvsum) {
+        const float v = sum_partials(part + 256, 257, G);
+        *dvsum = accumulate ? *dvsum + v : v;
+    }
 }
 
 // ---- all reductions of one network pass in ONE launch -----------------------------------------------
@@ -306,7 +312,7 @@ struct ReduceJob {
     int block0;                 // first block of this job in the merged grid
 };
 constexpr int kMaxJobs = 16;
-struct ReduceJobs { ReduceJob j[kMaxJobs]; int n; };
+struct ReduceJobs { ReduceJob j[kMaxJobs]; int n; int accumulate; };
 
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReduceJobs jobs) {
     int q = 0;
@@ -318,11 +324,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReduceJobs jobs
     const long nw = (long)J.n_out * J.k_out;
     if (idx < nw) {
         const int n = (int)(idx / J.k_out), k = (int)(idx % J.k_out);
-        J.dW[(long)n * J.ldo + J.col0 + k] = sum_partials(J.part_w + (long)n * J.BK + k, (long)J.BN * J.BK, J.G);
+        float* o = J.dW + (long)n * J.ldo + J.col0 + k;
+        const float v = sum_partials(J.part_w + (long)n * J.BK + k, (long)J.BN * J.BK, J.G);
+        *o = jobs.accumulate ? *o + v : v;
         return;
     }
     const long j = idx - nw;
-    if (J.db && j < J.n_out) J.db[j] = sum_partials(J.part_b + j, J.BN, J.G);
+    if (J.db && j < J.n_out) {
+        const float v = sum_partials(J.part_b + j, J.BN, J.G);
+        J.db[j] = jobs.accumulate ? J.db[j] + v : v;
+    }
 }
 
 template <int WN, int WK, bool FAST>
@@ -417,15 +428,22 @@ extern "C" int scnerf_wgrad(const float* dz, int lda, int n_load, int n_out, int
     return scn_launch_status();
 }
 
-extern "C" int scnerf_vecmat(const float* x_tiled256, const float* vec, int vec_stride, long long n_samples,
-                             int n_chunks, float* workspace, float* dv, float* dvsum, void* stream) {
+namespace {
+int vecmat_impl(const float* x_tiled256, const float* vec, int vec_stride, long long n_samples, int n_chunks,
+                float* workspace, float* dv, float* dvsum, int accumulate, void* stream) {
     SCN_RETURN_IF(!x_tiled256 || !vec || !workspace || !dv || n_samples < 0 || n_chunks < 1 || vec_stride < 1, SCN_EINVAL);
     const long n_tiles = scn::mlp::padded_samples((long)n_samples) / 32;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(vecmat_kernel, dim3(n_chunks), dim3(kThreads), 0, st, x_tiled256, vec, vec_stride,
                        (long)n_samples, n_tiles, workspace);
-    hipLaunchKernelGGL(vecmat_reduce_kernel, dim3(2), dim3(256), 0, st, workspace, n_chunks, dv, dvsum);
+    hipLaunchKernelGGL(vecmat_reduce_kernel, dim3(2), dim3(256), 0, st, workspace, n_chunks, dv, dvsum, accumulate);
     return scn_launch_status();
+}
+}  // namespace
+
+extern "C" int scnerf_vecmat(const float* x_tiled256, const float* vec, int vec_stride, long long n_samples,
+                             int n_chunks, float* workspace, float* dv, float* dvsum, void* stream) {
+    return vecmat_impl(x_tiled256, vec, vec_stride, n_samples, n_chunks, workspace, dv, dvsum, 0, stream);
 }
 
 // ---- all weight gradients of one network (D=8, W=256, skip 4, view-dependent head; 3-D or 4-D point) ----
@@ -436,7 +454,7 @@ extern "C" int scnerf_nerf_param_count(int pt_dims) {
 namespace {
 template <int PD>
 int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long long P, int n_chunks,
-               float* workspace, float* g, void* stream) {
+               float* workspace, float* g, int accumulate, void* stream) {
     using namespace scn::mlp;
     using V = Var<PD>;
     const long long Ppad = scn::mlp::padded_samples(P);
@@ -448,6 +466,7 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
     int rc;
     ReduceJobs jobs;
     jobs.n = 0;
+    jobs.accumulate = accumulate;
     float* ws = workspace + 257LL * n_chunks;          // [0, 257 G): the vecmat partials
     hipStream_t st = (hipStream_t)stream;
 #define SCN_WG(...)                                                                            \
@@ -471,7 +490,7 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
     }
     // feature_linear; alpha_linear (one output row) = d sigma^T . act7 with d sigma = d_raw[:, 3]
     SCN_WG(G(kGradDfeat), 256, 256, 256, 1, act(7), 256, 256, 256, 1, P, n_chunks, ws, g + V::kWF, 256, 0, g + V::kBF)
-    rc = scnerf_vecmat(act(7), d_raw + 3, 4, P, n_chunks, workspace, g + V::kWA, g + V::kBA, stream);
+    rc = vecmat_impl(act(7), d_raw + 3, 4, P, n_chunks, workspace, g + V::kWA, g + V::kBA, accumulate, stream);
     if (rc != 0) return rc;
     // views layer: [feature | encoded direction]
     SCN_WG(G(kGradDzv), 128, 128, 128, 1, S(kSaveFeat), 256, 256, 256, 1, P, n_chunks, ws, g + V::kWV, 283, 0, g + V::kBV)
@@ -493,11 +512,11 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
 
 extern "C" int scnerf_nerf_wgrad(int pt_dims, const float* save, const float* grads, const float* d_raw,
                                  long long n_samples, int n_chunks, float* workspace, float* flat_grad,
-                                 void* stream) {
+                                 int accumulate, void* stream) {
     SCN_RETURN_IF(!save || !grads || !d_raw || !workspace || !flat_grad || n_samples < 1 || n_chunks < 1, SCN_EINVAL);
     SCN_RETURN_IF(pt_dims != 3 && pt_dims != 4, SCN_EINVAL);
-    if (pt_dims == 3) return nerf_wgrad<3>(save, grads, d_raw, n_samples, n_chunks, workspace, flat_grad, stream);
-    return nerf_wgrad<4>(save, grads, d_raw, n_samples, n_chunks, workspace, flat_grad, stream);
+    if (pt_dims == 3) return nerf_wgrad<3>(save, grads, d_raw, n_samples, n_chunks, workspace, flat_grad, accumulate, stream);
+    return nerf_wgrad<4>(save, grads, d_raw, n_samples, n_chunks, workspace, flat_grad, accumulate, stream);
 }
 
 extern "C" long long scnerf_nerf_wgrad_workspace_floats(int n_chunks) {

@@ -104,13 +104,19 @@ class RenderRaysFunction(torch.autograd.Function):
 
     @staticmethod
     def _stage_backward(stage, rays, spr, wbk, white_bkgd, g_rgb, g_disp, g_acc, g_depth, g_raw, d_rays,
-                        accumulate):
+                        accumulate, into=None):
+        """`into`: the network's attached flat .grad buffer -- the weight gradients are ADDED to it and
+        None is returned (nothing for autograd to accumulate); otherwise a fresh flat gradient."""
         z, pts, raw, noise, save = stage
         n = z.shape[0]
         d_raw, d_rd = ops.composite_bwd(raw, z, rays, noise, white_bkgd, _c(g_rgb), _c(g_disp), _c(g_acc),
                                         _c(g_depth), _c(g_raw))
         grads, d_pts, d_views = ops.mlp_bwd(d_raw, pts, rays[:, 8:11], spr, wbk, save)
-        flat_grad = ops.nerf_wgrad(save, grads, d_raw, n * spr)
+        if into is not None:
+            ops.nerf_wgrad(save, grads, d_raw, n * spr, flat_grad=into, accumulate=True)
+            flat_grad = None
+        else:
+            flat_grad = ops.nerf_wgrad(save, grads, d_raw, n * spr)
         ops.ray_reduce(d_pts, d_views, z, d_rd, d_rays, accumulate)
         return flat_grad
 
@@ -123,17 +129,25 @@ class RenderRaysFunction(torch.autograd.Function):
         d_rays = torch.zeros_like(rays)
         fg_c = fg_f = None
         wrote = False
+        # networks whose .grad tensors are views of one flat buffer take their weight gradients by direct
+        # accumulation (what AccumulateGrad would do with 24 returned tensors, in one launch)
+        n_pc = ctx.n_params_c
+        need = ctx.needs_input_grad[8:]
+        into_c = ctx.net_c.attached_flat_grad() if all(need[:n_pc]) else None
+        fine_net = ctx.net_f if ctx.net_f is not None else ctx.net_c
+        into_f = into_c if ctx.net_f is None else (ctx.net_f.attached_flat_grad() if all(need[n_pc:]) else None)
         if sf > 0:
             if any(g is not None for g in (g_rgb, g_disp, g_acc, g_depth, g_raw)):
                 fg_f = RenderRaysFunction._stage_backward(ctx.fine, rays, sc + sf, ctx.wb_f, cfg.white_bkgd,
-                                                          g_rgb, g_disp, g_acc, g_depth, g_raw, d_rays, wrote)
+                                                          g_rgb, g_disp, g_acc, g_depth, g_raw, d_rays, wrote,
+                                                          into=into_f)
                 wrote = True
             coarse_g = (g_rgb0, g_disp0, g_acc0, g_depth0, None)
         else:
             coarse_g = (g_rgb, g_disp, g_acc, g_depth, g_raw)
         if any(g is not None for g in coarse_g):
             fg_c = RenderRaysFunction._stage_backward(ctx.coarse, rays, sc, ctx.wb_c, cfg.white_bkgd,
-                                                      *coarse_g, d_rays, wrote)
+                                                      *coarse_g, d_rays, wrote, into=into_c)
         if sf > 0 and ctx.net_f is None and fg_f is not None:
             # one network serves both stages (reference :279): its gradient is the sum
             fg_c = fg_f if fg_c is None else fg_c + fg_f

@@ -261,8 +261,9 @@ _wgrad_ws = {}
 
 
 def nerf_wgrad(save: Tensor, grads: Tensor, d_raw: Tensor, P: int, flat_grad: Optional[Tensor] = None,
-               pd: int = 3) -> Tensor:
-    """All parameter gradients of one network -> flat buffer (mlp_layout.Layout parameter order)."""
+               pd: int = 3, accumulate: bool = False) -> Tensor:
+    """All parameter gradients of one network -> flat buffer (mlp_layout.Layout parameter order);
+    `accumulate`: add to `flat_grad` instead of overwriting it."""
     lib = _capi.load()
     chunks = wgrad_chunks(P)
     key = (chunks, str(save.device))
@@ -271,10 +272,14 @@ def nerf_wgrad(save: Tensor, grads: Tensor, d_raw: Tensor, P: int, flat_grad: Op
                                      device=save.device)
     if flat_grad is None:
         flat_grad = torch.empty(ML.layout(pd).n_params, dtype=torch.float32, device=save.device)
+    elif flat_grad.numel() != ML.layout(pd).n_params or flat_grad.dtype != torch.float32 or not flat_grad.is_contiguous():
+        raise ValueError("flat_grad must be a contiguous fp32 buffer of %d elements" % ML.layout(pd).n_params)
     with PROFILE.region("wgrad(12 GEMMs + reduces)%s/P=%d" % ("" if pd == 3 else "/pd4", P),
                         2 * _MAC_PER_SAMPLE[pd] * P, group=True):
+        if accumulate and flat_grad is None:
+            raise ValueError("accumulate needs the buffer to add to")
         st = lib.scnerf_nerf_wgrad(pd, _p(save), _p(grads), _p(d_raw), P, chunks, _p(_wgrad_ws[key]),
-                                   _p(flat_grad), _stream())
+                                   _p(flat_grad), int(bool(accumulate)), _stream())
     _capi.check(st, "scnerf_nerf_wgrad")
     return flat_grad
 

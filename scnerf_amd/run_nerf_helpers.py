@@ -132,6 +132,23 @@ class NeRF(nn.Module):
             self._flat = flat
         return flat
 
+    def attached_flat_grad(self) -> Optional[torch.Tensor]:
+        """The flat gradient buffer when every parameter's .grad is a view of ONE contiguous fp32 buffer in
+        parameter order (FusedAdam / FlatGradAllReduce attach them so), else None.  The backward then adds
+        the weight gradients straight into it instead of returning 24 tensors for autograd to accumulate."""
+        params = [p for _, p in self.named_parameters()]
+        g0 = params[0].grad
+        if g0 is None or g0.dtype != torch.float32 or not g0.is_cuda:
+            return None
+        base, off = g0.data_ptr(), 0
+        for p in params:
+            g = p.grad
+            if g is None or not p.requires_grad or g.dtype != torch.float32 or not g.is_contiguous() \
+                    or g.data_ptr() != base + 4 * off:
+                return None
+            off += p.numel()
+        return torch.as_strided(g0, (off,), (1,))
+
     def forward(self, x):
         raise NotImplementedError(
             "scnerf_amd.NeRF is evaluated by the fused HIP kernels through render_rays / "

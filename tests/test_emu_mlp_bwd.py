@@ -106,7 +106,10 @@ def test_full_network_weight_gradients_match_autograd(pd):
     ws = np.full(H.lib().scnerf_nerf_wgrad_workspace_floats(chunks), np.nan, np.float32)
     flat = np.full(lay.n_params, np.nan, np.float32)
     assert H.lib().scnerf_nerf_param_count(pd) == lay.n_params
-    H.call("scnerf_nerf_wgrad", pd, save, grads, d_raw.numpy(), P, chunks, ws, flat, None)
+    H.call("scnerf_nerf_wgrad", pd, save, grads, d_raw.numpy(), P, chunks, ws, flat, 0, None)
+    twice = flat.copy()
+    H.call("scnerf_nerf_wgrad", pd, save, grads, d_raw.numpy(), P, chunks, ws, twice, 1, None)     # accumulate
+    np.testing.assert_allclose(twice, 2.0 * flat, rtol=1e-6, atol=1e-30)
     out = O.query_network(p, pts.reshape(n_rays, spr, pd), vd).reshape(P, 4)
     (out * d_raw).sum().backward()
     assert not np.isnan(flat).any()

@@ -244,3 +244,35 @@ def test_headline_size_against_oracle(R):
     # fine-sample indices: bit-exact whenever the two sides see the same cdf; count rows that differ
     z_same = float((ret["z_std"].cpu() - o32["z_std"]).abs().max())
     assert z_same < 1e-3
+
+
+def test_weight_gradients_accumulate_into_attached_flat_buffers(R):
+    """With every .grad a view of one flat buffer (FusedAdam / FlatGradAllReduce attach them so) the backward
+    adds the weight gradients straight into that buffer; the result equals the ordinary autograd
+    accumulation, also over two backward passes (gradient accumulation) and with a pre-filled buffer."""
+    from scnerf_amd.parallel import FlatGradAllReduce
+    n, sc, sf = 64, 64, 128
+    rays = synth.ray_batch(n, seed=1).cuda()
+    target = synth.target_rgb(n, seed=2).cuda()
+    rnd = {k: v.cuda() for k, v in synth.render_randoms(n, sc, sf, seed=3).items()}
+    query = make_query(R)
+
+    def run(attach):
+        net_c, net_f = make_net(R, 0), make_net(R, 1)
+        red = FlatGradAllReduce([net_c, net_f], 1) if attach else None
+        if attach:
+            assert net_c.attached_flat_grad() is not None and net_f.attached_flat_grad() is not None
+            red.flat.fill_(0.25)                              # whatever is there must be added to, not replaced
+        else:
+            assert net_c.attached_flat_grad() is None
+        for _ in range(2):
+            ret = R["render"].batchify_rays(rays, chunk=1 << 15, network_fn=net_c, network_query_fn=query, N_samples=sc,
+                                         perturb=1.0, N_importance=sf, network_fine=net_f, raw_noise_std=1.0, _randoms=rnd)
+            loss = torch.mean((ret["rgb_map"] - target) ** 2) + torch.mean((ret["rgb0"] - target) ** 2)
+            loss.backward()
+        return [p.grad.clone() for m in (net_c, net_f) for p in m.parameters()]
+    plain = run(False)
+    attached = run(True)
+    for a, b in zip(plain, attached):
+        scale = float(a.abs().max()) + 1e-12
+        assert float((b - 0.25 - a).abs().max()) <= 2e-6 * scale + 1e-7
