@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_int, c_int64, c_longlong, c_void_p, c_float, c_double
+from ctypes import c_int, c_longlong, c_void_p, c_float, c_double
 
 D = c_double
 

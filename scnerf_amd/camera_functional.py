@@ -1,8 +1,6 @@
 """autograd nodes over the camera kernels (scnerf_amd/csrc/camera_rays.hip)."""
 from __future__ import annotations
 
-from typing import Optional
-
 import torch
 
 from . import ops

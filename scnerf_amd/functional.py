@@ -134,7 +134,6 @@ class RenderRaysFunction(torch.autograd.Function):
         n_pc = ctx.n_params_c
         need = ctx.needs_input_grad[8:]
         into_c = ctx.net_c.attached_flat_grad() if all(need[:n_pc]) else None
-        fine_net = ctx.net_f if ctx.net_f is not None else ctx.net_c
         into_f = into_c if ctx.net_f is None else (ctx.net_f.attached_flat_grad() if all(need[n_pc:]) else None)
         if sf > 0:
             if any(g is not None for g in (g_rgb, g_disp, g_acc, g_depth, g_raw)):

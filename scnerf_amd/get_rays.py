@@ -4,7 +4,6 @@ warps of NeRF/render.py:357-396; the arithmetic runs in the HIP ray-generator ke
 from __future__ import annotations
 
 import numpy as np
-import torch
 
 
 def _cf():

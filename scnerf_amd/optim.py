@@ -18,7 +18,6 @@ from typing import Iterable, List
 import torch
 
 from . import _capi
-from . import ops
 
 
 def decayed_lr(lrate: float, lrate_decay: float, global_step: int) -> float:
