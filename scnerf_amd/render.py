@@ -18,7 +18,7 @@ import torch.nn as nn
 from . import ops
 from .functional import RawToOutputsFunction, RenderConfig, RenderRaysFunction, host_linspace
 from .get_rays import (get_rays_full_image_no_camera, get_rays_full_image_use_camera,  # noqa: F401  (the
-                       get_rays_kps_no_camera, get_rays_kps_use_camera, ndc_rays, ndc_rays_camera)  # reference's render module re-exports these, render.py:7-12)
+                       get_rays_kps_no_camera, get_rays_kps_use_camera, ndc_rays, ndc_rays_camera)  # reference's render module imports these too, render.py:9-14)
 from .run_nerf_helpers import NeRF
 
 to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)
