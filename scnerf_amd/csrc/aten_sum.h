@@ -15,54 +15,70 @@ __device__ inline int ceil_log2_aten(long x) {
     return l;
 }
 
-// four interleaved cascade accumulators over `size` groups; elem(i, k) = k-th of group i
-template <typename Elem>
-__device__ inline void multi_row_sum4(float out[4], Elem elem, long size) {
-    const int level_power = max(4, ceil_log2_aten(size) / 4);
-    const long level_step = 1L << level_power;
-    const long level_mask = level_step - 1;
-    float acc[4][4];
-    for (int j = 0; j < 4; ++j)
-        for (int k = 0; k < 4; ++k) acc[j][k] = 0.f;
-    long i = 0;
-    for (; i + level_step <= size;) {
-        for (long j = 0; j < level_step; ++j, ++i)
-            for (int k = 0; k < 4; ++k) acc[0][k] += elem(i, k);
-        for (int j = 1; j < 4; ++j) {
-            for (int k = 0; k < 4; ++k) {
-                acc[j][k] += acc[j - 1][k];
-                acc[j - 1][k] = 0.f;
+// One "vector lane" of the ATen sum: elements w[i * stride], i < size.  Four interleaved partial sums
+// (ILP 4), each a cascade of four levels: level 0 takes level_step groups, then folds upwards (level j is
+// folded into j+1 whenever the group counter reaches a multiple of level_step^(j+1)); the tail groups go to
+// level 0; levels are added 1, 2, 3 into 0; then the ungrouped tail, then p0 += p1 += p2 += p3.
+// Written with named scalars and rolled loops: as private arrays with run-time level indices this cost the
+// samplers 248 VGPRs plus scratch (one wave per SIMD).
+__device__ inline float aten_lane_sum(const float* w, int stride, int size) {
+    const int size_ilp = size >> 2;
+    const int level_power = max(4, ceil_log2_aten(size_ilp) / 4);
+    const int level_step = 1 << level_power;
+    const int level_mask = level_step - 1;
+    float a00 = 0.f, a01 = 0.f, a02 = 0.f, a03 = 0.f;      // level 0, ILP slot 0..3
+    float a10 = 0.f, a11 = 0.f, a12 = 0.f, a13 = 0.f;
+    float a20 = 0.f, a21 = 0.f, a22 = 0.f, a23 = 0.f;
+    float a30 = 0.f, a31 = 0.f, a32 = 0.f, a33 = 0.f;
+    int i = 0;
+#pragma unroll 1
+    while (i + level_step <= size_ilp) {
+#pragma unroll 1
+        for (int j = 0; j < level_step; ++j, ++i) {
+            a00 += w[(i * 4 + 0) * stride];
+            a01 += w[(i * 4 + 1) * stride];
+            a02 += w[(i * 4 + 2) * stride];
+            a03 += w[(i * 4 + 3) * stride];
+        }
+        a10 += a00; a11 += a01; a12 += a02; a13 += a03;
+        a00 = a01 = a02 = a03 = 0.f;
+        if ((i & (level_mask << level_power)) == 0) {
+            a20 += a10; a21 += a11; a22 += a12; a23 += a13;
+            a10 = a11 = a12 = a13 = 0.f;
+            if ((i & (level_mask << (2 * level_power))) == 0) {
+                a30 += a20; a31 += a21; a32 += a22; a33 += a23;
+                a20 = a21 = a22 = a23 = 0.f;
             }
-            const long mask = level_mask << (j * level_power);
-            if ((i & mask) != 0) break;
         }
     }
-    for (; i < size; ++i)
-        for (int k = 0; k < 4; ++k) acc[0][k] += elem(i, k);
-    for (int j = 1; j < 4; ++j)
-        for (int k = 0; k < 4; ++k) acc[0][k] += acc[j][k];
-    for (int k = 0; k < 4; ++k) out[k] = acc[0][k];
+#pragma unroll 1
+    for (; i < size_ilp; ++i) {
+        a00 += w[(i * 4 + 0) * stride];
+        a01 += w[(i * 4 + 1) * stride];
+        a02 += w[(i * 4 + 2) * stride];
+        a03 += w[(i * 4 + 3) * stride];
+    }
+    a00 += a10; a01 += a11; a02 += a12; a03 += a13;
+    a00 += a20; a01 += a21; a02 += a22; a03 += a23;
+    a00 += a30; a01 += a31; a02 += a32; a03 += a33;
+#pragma unroll 1
+    for (int k = size_ilp * 4; k < size; ++k) a00 += w[k * stride];
+    a00 += a01;
+    a00 += a02;
+    a00 += a03;
+    return a00;
 }
 
-template <typename Load>
-__device__ inline float row_sum_ilp4(Load load, long size) {
-    const long size_ilp = size / 4;
-    float p[4];
-    multi_row_sum4(p, [&](long i, int k) { return load(i * 4 + k); }, size_ilp);
-    for (long i = size_ilp * 4; i < size; ++i) p[0] += load(i);
-    for (int k = 1; k < 4; ++k) p[0] += p[k];
-    return p[0];
-}
-
+// torch.sum over a contiguous float row of m elements (m < 8: one lane over the row; else 8 vector lanes
+// over the strided elements, the row tail, then the lanes in order)
 __device__ inline float aten_rowsum(const float* w, int m) {
-    constexpr int V = 8;
-    if (m < V) return row_sum_ilp4([&](long i) { return w[i]; }, m);
-    const int nv = m / V;
-    float lanes[V];
-    for (int v = 0; v < V; ++v) lanes[v] = row_sum_ilp4([&](long i) { return w[i * V + v]; }, nv);
+    if (m < 8) return aten_lane_sum(w, 1, m);
+    const int nv = m >> 3;
     float acc = 0.f;
-    for (int k = nv * V; k < m; ++k) acc += w[k];
-    for (int v = 0; v < V; ++v) acc += lanes[v];
+#pragma unroll 1
+    for (int k = nv * 8; k < m; ++k) acc += w[k];
+#pragma unroll 1
+    for (int v = 0; v < 8; ++v) acc += aten_lane_sum(w + v, 8, nv);
     return acc;
 }
 

@@ -30,6 +30,7 @@ __device__ void build_cdf(const float* w_in, int nb, float* s_w, float* s_cdf, i
         const float tot = aten_rowsum(s_w, m);
         double run = 0.0;
         s_cdf[0] = 0.f;
+#pragma unroll 1
         for (int k = 0; k < m; ++k) {
             const float pdf = s_w[k] / tot;
             run += (double)pdf;
@@ -44,6 +45,7 @@ __device__ void search_right(const float* s_cdf, int nb, const float* s_u, int n
                              int lane, bool side_left) {
     if (nb <= kWave) {
         const float c = lane < nb ? s_cdf[lane] : 0.f;
+#pragma unroll 1      // (fully unrolled these loops cost 248 VGPRs + scratch: one wave per SIMD)
         for (int j = 0; j < ns; ++j) {
             const float uq = s_u[j];  // LDS broadcast
             const bool le = side_left ? (c < uq) : (c <= uq);
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(256) void fine_sample_kernel(
     for (int e = lane; e < tot; e += kWave) {
         const float v = s_all[e];
         int rank = 0;
+#pragma unroll 4
         for (int j = 0; j < tot; ++j) rank += total_less(s_all[j], j, v, e) ? 1 : 0;
         s_sorted[rank] = v;
     }

@@ -36,7 +36,8 @@ def test_sample_pdf_golden_bit_exact(golden, tag):
     np.testing.assert_array_equal(samples, g[tag + "/samples"])
 
 
-@pytest.mark.parametrize("nb,ns", [(3, 1), (9, 5), (31, 64), (63, 128), (64, 200), (127, 96), (200, 33)])
+@pytest.mark.parametrize("nb,ns", [(3, 1), (9, 5), (31, 64), (63, 128), (64, 200), (127, 96), (200, 33),
+                                   (601, 40), (1100, 16)])      # >= 512 weights: the row sum's cascade levels engage
 def test_sample_pdf_vs_oracle_shapes(nb, ns):
     g = torch.Generator().manual_seed(nb * 1000 + ns)
     n = 7          # ragged against the 4-rays-per-block tiling
