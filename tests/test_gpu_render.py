@@ -276,3 +276,62 @@ def test_weight_gradients_accumulate_into_attached_flat_buffers(R):
     for a, b in zip(plain, attached):
         scale = float(a.abs().max()) + 1e-12
         assert float((b - 0.25 - a).abs().max()) <= 2e-6 * scale + 1e-7
+
+
+def test_headline_size_invariants(R):
+    """Size-independent properties at the BASELINE size (4096 x (64 + 128)), no oracle needed:
+    sorted merged depths that contain the coarse depths, weights that partition at most unity, colours in
+    [0, 1], ray independence (a permuted / split batch renders bit-identically), chunking invariance, and the
+    gradient of a sum of per-ray losses being the sum of the per-half gradients."""
+    from scnerf_amd import ops
+    from scnerf_amd.functional import host_linspace
+    n, sc, sf = 4096, 64, 128
+    net_c, net_f = make_net(R, 0), make_net(R, 1)
+    query = make_query(R)
+    rays = synth.ray_batch(n, seed=11).cuda()
+    rnd = {k: v.cuda() for k, v in synth.render_randoms(n, sc, sf, seed=13).items()}
+    kw = dict(network_fn=net_c, network_query_fn=query, N_samples=sc, perturb=1.0, N_importance=sf,
+              network_fine=net_f, raw_noise_std=1.0)
+    with torch.no_grad():
+        full = R["render"].batchify_rays(rays, chunk=1 << 15, retraw=True, _randoms=rnd, **kw)
+        # sampling invariants straight from the kernels
+        z_c, _ = ops.coarse_sample(rays, host_linspace(sc, rays.device), rnd["t_rand"], False)
+        raw_c = torch.zeros(n, sc, 4, device="cuda")
+        raw_c[..., 3] = torch.rand(n, sc, device="cuda") * 5
+        _, _, acc_c, w_c, _ = ops.composite_fwd(raw_c, z_c, rays, None, False)
+        z_f, pts_f, z_s, z_std, _, _ = ops.fine_sample(rays, z_c, w_c, rnd["u"])
+    assert bool((z_c[:, 1:] >= z_c[:, :-1]).all()) and bool((z_f[:, 1:] >= z_f[:, :-1]).all())
+    assert z_f.shape == (n, sc + sf)
+    # every coarse depth and every new sample is in the merged set (sort of the concatenation)
+    ref_sorted = torch.sort(torch.cat([z_c, z_s], -1), -1)[0]
+    assert torch.equal(z_f, ref_sorted)
+    assert bool((w_c >= 0).all()) and float(w_c.sum(-1).max()) <= 1.0 + 1e-5 and float(acc_c.max()) <= 1.0 + 1e-5
+    for k in ("rgb_map", "rgb0"):
+        assert float(full[k].min()) >= 0.0 and float(full[k].max()) <= 1.0
+    assert torch.isfinite(full["disp_map"]).all() and torch.isfinite(full["raw"]).all()
+
+    # ray independence: a permutation of the batch permutes the outputs, bit for bit; so does chunking
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(5)).cuda()
+    with torch.no_grad():
+        permuted = R["render"].batchify_rays(rays[perm], chunk=1 << 15, _randoms={k: v[perm] for k, v in rnd.items()}, **kw)
+        # (sub-batches rather than batchify's own chunks: the `_randoms` test hook is not sliced per chunk)
+        chunked = torch.cat([R["render"].batchify_rays(rays[a:a + 1000], chunk=1 << 15,
+                                                       _randoms={k: v[a:a + 1000] for k, v in rnd.items()}, **kw)["rgb_map"]
+                             for a in range(0, n, 1000)], 0)
+    assert torch.equal(permuted["rgb_map"], full["rgb_map"][perm])
+    assert torch.equal(permuted["disp_map"], full["disp_map"][perm])
+    assert torch.equal(chunked, full["rgb_map"])
+
+    # additivity of the backward over rays: grad(sum over all rays) == grad(first half) + grad(second half)
+    target = synth.target_rgb(n, seed=17).cuda()
+
+    def grads(lo, hi):
+        for m in (net_c, net_f):
+            for p in m.parameters():
+                p.grad = None
+        ret = R["render"].batchify_rays(rays[lo:hi], chunk=1 << 15, _randoms={k: v[lo:hi] for k, v in rnd.items()}, **kw)
+        (((ret["rgb_map"] - target[lo:hi]) ** 2).sum() + ((ret["rgb0"] - target[lo:hi]) ** 2).sum()).backward()
+        return torch.cat([p.grad.reshape(-1) for m in (net_c, net_f) for p in m.parameters()])
+    g_all, g_a, g_b = grads(0, n), grads(0, n // 2), grads(n // 2, n)
+    scale = float(g_all.abs().max())
+    assert float((g_all - (g_a + g_b)).abs().max()) <= 2e-5 * scale
