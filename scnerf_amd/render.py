@@ -109,7 +109,10 @@ def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
     """Render rays in chunks (reference :398-413), including its in-place saturation of the colour
     outputs at 1 -- which also zeroes the gradient of saturated pixels."""
     all_ret = {}
+    randoms = kwargs.pop("_randoms", None)            # (tests only) injected draws follow their rays
     for i in range(0, rays_flat.shape[0], chunk):
+        if randoms is not None:
+            kwargs["_randoms"] = {k: v[i:i + chunk] for k, v in randoms.items()}
         ret = render_rays(rays_flat[i:i + chunk], **kwargs)
         for key in ["rgb0", "rgb1", "rgb_map"]:
             if key in ret.keys():
