@@ -314,8 +314,7 @@ def test_headline_size_invariants(R):
     perm = torch.randperm(n, generator=torch.Generator().manual_seed(5)).cuda()
     with torch.no_grad():
         permuted = R["render"].batchify_rays(rays[perm], chunk=1 << 15, _randoms={k: v[perm] for k, v in rnd.items()}, **kw)
-        # (sub-batches rather than batchify's own chunks: the `_randoms` test hook is not sliced per chunk)
-        chunked = torch.cat([R["render"].batchify_rays(rays[a:a + 1000], chunk=1 << 15,
+        chunked = torch.cat([R["render"].batchify_rays(rays[a:a + 1000], chunk=384,      # sub-batches AND chunks
                                                        _randoms={k: v[a:a + 1000] for k, v in rnd.items()}, **kw)["rgb_map"]
                              for a in range(0, n, 1000)], 0)
     assert torch.equal(permuted["rgb_map"], full["rgb_map"][perm])
