@@ -289,7 +289,9 @@ int scnerf_npp_points_bwd(const float* ray_o, const float* ray_d, const float* f
  * scaled by |ray_d| with the last reaching fg_z_max, T = cumprod(1 - alpha + 1e-6), bg_lambda = T behind
  * the last sample; background over the flipped inverse radii with a 1e10 last interval; bg_rgb /
  * bg_depth already scaled by bg_lambda; rgb = fg_rgb + bg_rgb.  raw_bg / bg_weights are in the flipped
- * (network) order, bg_z in the caller's ascending order.  _bwd: any incoming gradient may be NULL;
+ * (network) order, bg_z in the caller's ascending order.  (sb = 1: the single sample is kept; the reference's
+ * slicing, :123-124, yields an empty transmittance there and drops the background -- unused: sb >= 2.)
+ * _bwd: any incoming gradient may be NULL;
  * returns d raw of both networks, d fg_z, d fg_z_max, d |ray_d|. */
 int scnerf_npp_composite_fwd(const float* raw_fg, const float* raw_bg, const float* fg_z, const float* fg_z_max,
                              const float* bg_z, const float* ray_d, float* rgb, float* fg_weights,

@@ -246,3 +246,42 @@ def test_pixel_centre_ray_generator_golden(tag):
     close(out["dgd"], G[k + "g_ray_d_noise"], 1e-4, "ray_d_noise")
     if aliased:
         close(out["dd"] * np.float32(1e-1), G[k + "g_distortion_noise"], 1e-4, "distortion_noise")
+
+
+def test_empty_and_single_ray_edge_cases():
+    """n = 0 is a no-op for every NeRF++ entry point; one ray with a single foreground / background sample
+    still composites (the only interval is the one up to fg_z_max / the HUGE background tail)."""
+    import ctypes
+    z = np.zeros(0, np.float32)
+    zi = np.zeros(0, np.int32)
+    H.call("scnerf_npp_intersect_fwd", z, z, z, None, 0, None)
+    H.call("scnerf_npp_intersect_bwd", z, z, z, z, z, 0, None)
+    H.call("scnerf_npp_perturb_fwd", z, z, z, 0, 5, None)
+    H.call("scnerf_npp_perturb_bwd", z, z, z, 0, 5, None)
+    H.call("scnerf_npp_sample_pdf", z, z, z, z, zi, z, 0, 7, 3, None)
+    H.call("scnerf_npp_sample_pdf_bwd", z, zi, z, z, 0, 7, 3, None)
+    H.call("scnerf_npp_points_fwd", z, z, z, z, z, z, z, None, 0, 4, 4, None)
+    H.call("scnerf_npp_points_bwd", z, z, z, z, z, z, z, z, None, None, z, z, z, 0, 4, 4, None)
+    H.call("scnerf_npp_composite_fwd", z, z, z, z, z, z, z, z, z, z, z, z, z, z, 0, 4, 4, None)
+    H.call("scnerf_npp_composite_bwd", z, z, z, z, z, z, None, None, None, None, None, None, None, None, z, z, z, z, z,
+           0, 4, 4, None)
+    # invalid sizes are argument errors, not launches
+    with pytest.raises(AssertionError, match="-22"):
+        H.call("scnerf_npp_composite_fwd", z, z, z, z, z, z, z, z, z, z, z, z, z, z, 1, 0, 4, None)
+
+    raw_fg = torch.tensor([[[0.3, -0.2, 1.1, 2.0]]])
+    # (two background samples: with ONE the reference's `cumprod(...)[..., :-1]` + `ones_like(T[..., 0:1])`
+    # slicing, ddp_model.py:123-124, leaves an empty transmittance and silently drops the background;
+    # the kernel keeps the single sample -- no reference configuration uses fewer than 2)
+    raw_bg = torch.tensor([[[-0.5, 0.7, 0.1, -1.5], [0.2, 0.1, -0.3, 0.8]]])
+    fg_z, z_max, bg_z, rd = torch.tensor([[0.4]]), torch.tensor([0.9]), torch.tensor([[0.25, 0.6]]), torch.tensor([[0.2, -0.1, 1.0]])
+    ref = _oracle_composite(raw_fg, raw_bg, fg_z, z_max, bg_z, rd)
+    shapes = {"rgb": (1, 3), "fg_weights": (1, 1), "bg_weights": (1, 2), "fg_rgb": (1, 3), "fg_depth": (1,),
+              "bg_rgb": (1, 3), "bg_depth": (1,), "bg_lambda": (1,)}
+    out = {k: np.full(shapes[k], np.nan, np.float32) for k in KEYS}
+    H.call("scnerf_npp_composite_fwd", raw_fg.numpy(), raw_bg.numpy(), fg_z.numpy(), z_max.numpy(), bg_z.numpy(),
+           rd.numpy(), *[out[k] for k in KEYS], 1, 1, 2, None)
+    for k in KEYS:
+        np.testing.assert_allclose(out[k], ref[k].numpy(), rtol=2e-6, atol=1e-8, err_msg=k)
+    # the last background sample closes the ray: its alpha is that of the HUGE interval, 1 for any sigma > 0
+    assert out["bg_weights"].sum() == pytest.approx(1.0, abs=1e-5)
