@@ -105,6 +105,18 @@ def load() -> ctypes.CDLL:
     return _lib
 
 
+def on_device(t) -> bool:
+    """True when tensor `t` lives in the memory the loaded library computes on (the GPU's HBM).  Every
+    residency check of the host layer goes through here."""
+    return bool(t.is_cuda)
+
+
+def current_stream():
+    """The raw hipStream_t of torch's current stream (kernels are enqueued there)."""
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
 def check(status: int, what: str):
     if status != 0:
         raise RuntimeError("%s failed with status %d" % (what, status))

@@ -42,7 +42,7 @@ class CameraRaysFunction(torch.autograd.Function):
 def camera_rays(H, W, camera_model, kps_list, idx_in_camera_param=None, extrinsic=None):
     """Shared implementation of get_rays_kps_use_camera / get_rays_full_image_use_camera."""
     dev = camera_model.intrinsics_initial.device
-    if not camera_model.intrinsics_initial.is_cuda:
+    if not ops._capi.on_device(camera_model.intrinsics_initial):
         raise RuntimeError("the camera model must be on the GPU (scnerf_amd has no CPU path)")
     n = H * W if kps_list is None else int(kps_list.shape[0])
     kps = None
@@ -84,7 +84,7 @@ def camera_rays(H, W, camera_model, kps_list, idx_in_camera_param=None, extrinsi
 
 def pinhole_rays(H, W, focal, extrinsic, kps_list):
     """get_rays_{kps,full_image}_no_camera: fixed pose, no gradients (reference get_rays.py:5-23, :75-90)."""
-    if not extrinsic.is_cuda:
+    if not ops._capi.on_device(extrinsic):
         raise RuntimeError("extrinsic must be on the GPU")
     c2w = torch.zeros((4, 4), device=extrinsic.device)
     c2w[:extrinsic.shape[0], :extrinsic.shape[1]] = extrinsic.detach().float()

@@ -2,16 +2,60 @@
 same class names, constructor arguments, parameter names / shapes / requires_grad flags and public
 methods, so `run_nerf.py` (hasattr probes, requires_grad_ curriculum toggles, checkpoints) works
 unchanged.  Ray generation itself does not go through these methods: `get_rays_*` hands the raw
-parameter tensors to the fused HIP kernel."""
+parameter tensors to the fused HIP kernel.
+
+Star-import surface.  `run_nerf.py` obtains `torch`, `np`, `nn`, `wandb`, `Image`, `sys` and every helper
+of camera_utils only through `from model.camera_model import *` (/root/reference NeRF/run_nerf.py:58,
+model/camera_model.py:1-9), so this module re-exports exactly those names (`__all__` below).  Where the
+`wandb` package is not installed an offline stand-in with the three entry points the scripts use
+(`init`, `log`, `Image`) takes its place; it keeps what was logged in `wandb.history`."""
 from __future__ import annotations
+
+import sys
+import types
 
 import numpy as np
 import torch
 import torch.nn as nn
+from PIL import Image
 
 from .camera_functional import UpsampleGridFunction
+from .camera_utils import *                                     # noqa: F401,F403  (re-exported, as the reference does)
+from .camera_utils import __all__ as _camera_utils_all
 from .camera_utils import (get_44_rotation_matrix_from_33_rotation_matrix, intrinsic_param_to_K,
-                           ortho2rotation, rotation2orth)
+                           ortho2rotation, rotation2orth, to_pil_normalize)
+
+
+def _offline_wandb():
+    """Stand-in for the wandb package (logging is out of scope; the training script must still run)."""
+    m = types.ModuleType("wandb")
+    m.__doc__ = "offline stand-in created by scnerf_amd.camera_model (wandb is not installed)"
+    m.history, m.run = [], None
+
+    class _Image:
+        def __init__(self, data, caption=None):
+            self.image, self.caption = data, caption
+
+    def init(*args, **kwargs):
+        m.run = types.SimpleNamespace(name=kwargs.get("name"), project=kwargs.get("project"))
+        return m.run
+
+    def log(data, step=None, **kwargs):
+        m.history.append((step, dict(data)))
+        del m.history[:-64]                                        # bounded: the loop logs every iteration
+
+    m.Image, m.init, m.log, m.finish = _Image, init, log, lambda *a, **k: None
+    return m
+
+
+try:
+    import wandb
+except ImportError:
+    wandb = _offline_wandb()
+
+__all__ = sorted(set(_camera_utils_all) | {
+    "torch", "nn", "np", "Image", "wandb", "sys", "CameraModel", "PinholeModelRotNoiseLearning10kRayoRayd",
+    "PinholeModelRotNoiseLearning10kRayoRaydDistortion"})
 
 
 class CameraModel(nn.Module):
@@ -41,15 +85,35 @@ class CameraModel(nn.Module):
         raise Exception("function get_extrinsic not implemented!")
 
     def log_noises(self, gt_intrinsic, gt_extrinsic):
-        """Scalar summaries of the learnt residuals (reference :54-117 sends them to wandb; here they
-        are returned so any logger can take them)."""
-        out = {"camera/intrinsic_noise_mean": self.get_intrinsic().abs().mean().item()}
-        for name in ("intrinsics_noise", "extrinsics_noise", "ray_o_noise", "ray_d_noise", "distortion_noise"):
-            if hasattr(self, name):
-                t = getattr(self, name)
-                out["camera/%s_abs_mean" % name] = t.abs().mean().item()
-                out["camera/%s_std" % name] = t.std().item()
-        return out
+        """(scalars, images) for the logger, keys and values as the reference (:54-117): the current
+        intrinsics and their absolute errors against `gt_intrinsic`, extrinsic statistics and mean absolute
+        error against `gt_extrinsic`, statistics + a normalised picture of each upsampled ray-noise field, and
+        the distortion coefficients where the model has them.  Values stay 0-dim tensors like there
+        (wandb accepts them); `run_nerf.py:607-613` unpacks the pair.  (The reference stores the *mean* under
+        "camera/intrinsic_noise_std" as well, :58-61 -- reproduced.)"""
+        scalars, images = {}, {}
+        K = self.get_intrinsic()
+        scalars["camera/intrinsic_noise_mean"] = K.abs().mean()
+        scalars["camera/intrinsic_noise_std"] = K.abs().mean()
+        for name, (r, c) in (("fx", (0, 0)), ("fy", (1, 1)), ("cx", (0, 2)), ("cy", (1, 2))):
+            scalars["camera/" + name] = K[r][c]
+        for name, (r, c) in (("fx", (0, 0)), ("fy", (1, 1)), ("cx", (0, 2)), ("cy", (1, 2))):
+            scalars["camera/%s_err" % name] = (K[r][c] - gt_intrinsic[r][c]).abs()
+        if hasattr(self, "extrinsics_noise"):
+            E = self.get_extrinsic()
+            scalars["camera/extrinsic_noise_mean"] = E.abs().mean()
+            scalars["camera/extrinsic_noise_std"] = E.abs().std()
+            scalars["camera/extrinisic_err"] = (E - gt_extrinsic).abs().mean()      # (sic) the reference's key
+        for tag, getter in (("ray_o_noise", self.get_ray_o_noise), ("ray_d_noise", self.get_ray_d_noise)):
+            if hasattr(self, tag):
+                field = getter()
+                scalars["camera/%s_mean" % tag] = field.abs().mean()
+                scalars["camera/%s_std" % tag] = field.abs().std()
+                images["camera/" + tag] = to_pil_normalize(field.reshape(self.H, self.W, 3))
+        if hasattr(self, "distortion_noise"):
+            k1, k2 = self.get_distortion()
+            scalars["camera/k1"], scalars["camera/k2"] = k1, k2
+        return scalars, images
 
 
 class _PinholeRotNoise(CameraModel):

@@ -7,8 +7,9 @@
     import scnerf_amd.dropin; scnerf_amd.dropin.install()     # before run_nerf.py's imports
 """
 import importlib
+import importlib.abc
+import importlib.machinery
 import sys
-import types
 
 _MAP = {
     "render": "scnerf_amd.render",
@@ -20,6 +21,8 @@ _MAP = {
     "model.camera_model": "scnerf_amd.camera_model",
     "model.camera_utils": "scnerf_amd.camera_utils",
     "model.ray_dist_loss": "scnerf_amd.ray_dist_loss",
+    # model/prd_evaluation.py:2 imports it as a top-level module (load_llff.py:6 puts ../model on sys.path)
+    "ray_dist_loss": "scnerf_amd.ray_dist_loss",
 }
 
 
@@ -35,38 +38,47 @@ _MAP_NERFPP = {
 }
 
 
+class _ModelPackageFallback(importlib.abc.MetaPathFinder):
+    """LAST meta-path entry: if no real `model` package is importable (the reference tree is not on
+    sys.path), `import model.<mirrored module>` still has to succeed, so an empty package named `model`
+    is synthesised.  When the reference's model/ directory IS importable it wins, and its un-mirrored
+    modules (`model.reprojection`, `model.lookup`: matchers, host-side) keep resolving from there while the
+    mirrored ones come out of sys.modules."""
+
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname != "model":
+            return None
+        spec = importlib.machinery.ModuleSpec("model", None, is_package=True)
+        spec.submodule_search_locations = []
+        return spec
+
+
+def _register(mapping):
+    for alias, target in mapping.items():
+        sys.modules[alias] = importlib.import_module(target)
+    stale = sys.modules.get("model")
+    if stale is not None and not getattr(stale, "__file__", None) and not list(getattr(stale, "__path__", [])):
+        del sys.modules["model"]                    # an empty stand-in from an earlier install(): re-resolve
+    if not any(isinstance(f, _ModelPackageFallback) for f in sys.meta_path):
+        sys.meta_path.append(_ModelPackageFallback())
+    return sorted(mapping)
+
+
 def install_nerfplusplus():
     """As install(), for the module names nerfplusplus/ddp_train_nerf.py imports; its own per-ray helpers
     (intersect_sphere, perturb_samples, sample_pdf) live in scnerf_amd.nerfplusplus.ddp_train_nerf and
     `create_nerf` in scnerf_amd.nerfplusplus.create_nerf (same names / signatures).  The reference's
     render_ray_from_camera is only one function of nerf_sample_ray_split.py: the remaining names of that
     module (RaySamplerSingleImage ...) are host-side data handling and stay the reference's."""
-    for alias, target in _MAP_NERFPP.items():
-        if alias == "nerf_sample_ray_split":
-            continue                      # patched function-wise below when the reference module is importable
-        sys.modules[alias] = importlib.import_module(target)
-    if "model" not in sys.modules or not hasattr(sys.modules["model"], "__path__"):
-        pkg = types.ModuleType("model")
-        pkg.__path__ = []
-        sys.modules["model"] = pkg
-    for name in ("camera_model", "camera_utils", "ray_dist_loss"):
-        setattr(sys.modules["model"], name, sys.modules["model." + name])
+    names = _register({k: v for k, v in _MAP_NERFPP.items() if k != "nerf_sample_ray_split"})
     try:
-        ref = importlib.import_module("nerf_sample_ray_split")
+        ref = importlib.import_module("nerf_sample_ray_split")    # patched function-wise when importable
         ref.render_ray_from_camera = importlib.import_module(_MAP_NERFPP["nerf_sample_ray_split"]).render_ray_from_camera
     except Exception:
         sys.modules["nerf_sample_ray_split"] = importlib.import_module(_MAP_NERFPP["nerf_sample_ray_split"])
-    return sorted(_MAP_NERFPP)
+    return sorted(names + ["nerf_sample_ray_split"])
 
 
 def install():
-    for alias, target in _MAP.items():
-        sys.modules[alias] = importlib.import_module(target)
-    if "model" not in sys.modules or not hasattr(sys.modules["model"], "__path__"):
-        pkg = types.ModuleType("model")
-        pkg.__path__ = []
-        sys.modules["model"] = pkg
-    sys.modules["model"].camera_model = sys.modules["model.camera_model"]
-    sys.modules["model"].camera_utils = sys.modules["model.camera_utils"]
-    sys.modules["model"].ray_dist_loss = sys.modules["model.ray_dist_loss"]
-    return sorted(_MAP)
+    """Registers the mirrors under the reference's module names (see the module docstring)."""
+    return _register(_MAP)

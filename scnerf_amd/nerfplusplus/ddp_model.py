@@ -151,7 +151,7 @@ class NerfNet(nn.Module):
         self.bg_net.require_standard()
         if self.fg_net.pt_dims != 3 or self.bg_net.pt_dims != 4:
             raise NotImplementedError("foreground / background nets must take 3-D / 4-D points")
-        if not ray_o.is_cuda:
+        if not _capi.on_device(ray_o):
             raise RuntimeError("NerfNet inputs must be on the GPU: scnerf_amd has no CPU path")
         fg_params = [p for _, p in self.fg_net.named_parameters()]
         bg_params = [p for _, p in self.bg_net.named_parameters()]

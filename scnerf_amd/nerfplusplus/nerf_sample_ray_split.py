@@ -65,7 +65,7 @@ def render_ray_from_camera(camera_model, camera_idx, select_inds, rank, extrinsi
     exactly like the reference (:196-257; `depth` is c2w.T[2, 3] broadcast, :256)."""
     W, H = camera_model.W, camera_model.H
     dev = camera_model.intrinsics_initial.device
-    if not camera_model.intrinsics_initial.is_cuda:
+    if not _capi.on_device(camera_model.intrinsics_initial):
         raise RuntimeError("the camera model must be on the GPU (scnerf_amd has no CPU path)")
     ext = None
     if camera_idx is None:

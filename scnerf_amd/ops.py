@@ -64,11 +64,11 @@ def _p(t: Optional[Tensor]):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _capi.current_stream()
 
 
 def _chk(t: Tensor, dtype, name):
-    if not t.is_cuda:
+    if not _capi.on_device(t):
         raise RuntimeError("%s must live on the GPU (scnerf_amd has no CPU path)" % name)
     if t.dtype != dtype:
         raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
@@ -195,7 +195,7 @@ def pack_weights(flat_params: Tensor, kind: str = "fwd", out: Optional[Tensor] =
 def _vd(viewdirs: Tensor):
     """(pointer, row stride) of a [n,3] fp32 view-direction tensor that may be a column slice
     of the packed ray batch (ray_batch[:, 8:11])."""
-    if viewdirs.dtype != torch.float32 or not viewdirs.is_cuda or viewdirs.dim() != 2 or viewdirs.shape[1] != 3:
+    if viewdirs.dtype != torch.float32 or not _capi.on_device(viewdirs) or viewdirs.dim() != 2 or viewdirs.shape[1] != 3:
         raise TypeError("viewdirs must be a CUDA fp32 [n,3] tensor")
     if viewdirs.stride(1) != 1:
         raise ValueError("viewdirs rows must be dense")

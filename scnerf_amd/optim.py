@@ -99,7 +99,7 @@ class FusedAdam(torch.optim.Optimizer):
                     segs.append(_Segment(cur, cur_key[1]))
                     cur, cur_key = [], None
                 continue
-            if not p.is_cuda:
+            if not _capi.on_device(p):
                 raise RuntimeError("FusedAdam needs GPU parameters (scnerf_amd has no CPU path)")
             decay = i >= self._decay_from
             contiguous = bool(cur) and p.data_ptr() == cur[-1].data_ptr() + 4 * cur[-1].numel()
@@ -192,7 +192,7 @@ class FusedAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         beta1, beta2 = g["betas"]
         lib = _capi.load()
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = _capi.current_stream()
         for s in self.segments():
             s.attach()
             s.step += 1

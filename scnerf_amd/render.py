@@ -57,7 +57,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     if not getattr(network_query_fn, "is_fused_query", False):
         raise TypeError("network_query_fn must come from scnerf_amd.create_nerf (FusedNetworkQuery)")
     network_query_fn.check(net_c)
-    if not ray_batch.is_cuda:
+    if not ops._capi.on_device(ray_batch):
         raise RuntimeError("ray_batch must be on the GPU: scnerf_amd has no CPU path")
     n = ray_batch.shape[0]
     dev = ray_batch.device
@@ -105,21 +105,31 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     return ret
 
 
+_COLOUR_KEYS = ("rgb0", "rgb1", "rgb_map")
+
+
 def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
-    """Render rays in chunks (reference :398-413), including its in-place saturation of the colour
-    outputs at 1 -- which also zeroes the gradient of saturated pixels."""
-    all_ret = {}
-    randoms = kwargs.pop("_randoms", None)            # (tests only) injected draws follow their rays
-    for i in range(0, rays_flat.shape[0], chunk):
+    """Renders `rays_flat` [N, 8|11] in slices of `chunk` rays and joins the per-slice dicts
+    (reference :398-413).  The colour outputs are saturated at 1 *in place* per slice, as there -- which
+    also zeroes the gradient of saturated pixels.  `_randoms` (tests only): injected draws follow
+    their rays."""
+    randoms = kwargs.pop("_randoms", None)
+    pieces = []
+    for lo in range(0, rays_flat.shape[0], chunk):
+        hi = lo + chunk
         if randoms is not None:
-            kwargs["_randoms"] = {k: v[i:i + chunk] for k, v in randoms.items()}
-        ret = render_rays(rays_flat[i:i + chunk], **kwargs)
-        for key in ["rgb0", "rgb1", "rgb_map"]:
-            if key in ret.keys():
-                ret[key][ret[key] >= 1.0] = 1.0
-        for k in ret:
-            all_ret.setdefault(k, []).append(ret[k])
-    return {k: (torch.cat(all_ret[k], 0) if len(all_ret[k]) > 1 else all_ret[k][0]) for k in all_ret}
+            kwargs["_randoms"] = {name: draw[lo:hi] for name, draw in randoms.items()}
+        out = render_rays(rays_flat[lo:hi], **kwargs)
+        for key in _COLOUR_KEYS:
+            colour = out.get(key)
+            if colour is not None:
+                colour[colour >= 1.0] = 1.0
+        pieces.append(out)
+    if not pieces:
+        return {}
+    if len(pieces) == 1:
+        return dict(pieces[0])
+    return {key: torch.cat([piece[key] for piece in pieces], 0) for key in pieces[0]}
 
 
 def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False, _noise=None):
@@ -155,73 +165,103 @@ def sample_pdf(bins, weights, N_samples, det=False, pytest=False, _u=None):
     return samples
 
 
+# ---- render(): where the rays of a call come from -------------------------------------------------------
+# The reference's render() (:27-103) is a five-way if-chain over (rays given?, camera model?, mode); here
+# each ray source is a table entry: the preconditions it asserts (argument name -> must be None / must be
+# given) and a builder returning (rays_o, rays_d, focal-for-the-NDC-warp).  Failed preconditions raise
+# AssertionError like the reference's asserts; a mode outside train / val / test without precomputed rays
+# trips the same "should not appear" assertion.
+
+def _rays_precomputed(a):
+    rays_o, rays_d = a["rays"]
+    return rays_o, rays_d, (a["noisy_focal"] if a["camera_model"] is None else None)
+
+
+def _rays_trained_camera_train_view(a):
+    i_map = np.asarray(a["i_map"])
+    assert a["image_idx"] in i_map
+    slot = np.where(i_map == a["image_idx"])[0][0]
+    rays_o, rays_d = get_rays_full_image_use_camera(H=a["H"], W=a["W"], camera_model=a["camera_model"],
+                                                    extrinsic=a["noisy_extrinsic"][slot])
+    return rays_o, rays_d, None
+
+
+def _rays_trained_camera_held_out_view(a):
+    rays_o, rays_d = get_rays_full_image_use_camera(H=a["H"], W=a["W"], camera_model=a["camera_model"],
+                                                    extrinsic=a["transform_align"])
+    return rays_o, rays_d, None
+
+
+def _rays_noisy_pinhole_train_view(a):
+    focal = a["noisy_focal"]
+    rays_o, rays_d = get_rays_full_image_no_camera(H=a["H"], W=a["W"], focal=focal,
+                                                   extrinsic=a["noisy_extrinsic"][a["image_idx"]])
+    return rays_o, rays_d, focal
+
+
+def _rays_ground_truth_pinhole(a):
+    focal = a["gt_intrinsic"][0][0].item()
+    rays_o, rays_d = get_rays_full_image_no_camera(H=a["H"], W=a["W"], focal=focal,
+                                                   extrinsic=a["gt_extrinsic"][a["image_idx"]])
+    return rays_o, rays_d, focal
+
+
+_GIVEN, _ABSENT = False, True          # value = "must be None"
+# (camera model present, phase) -> (preconditions, builder); phase: "train" or "eval" (= val / test)
+_RAY_SOURCES = {
+    (True, "train"): ({"i_map": _GIVEN, "gt_intrinsic": _ABSENT, "gt_extrinsic": _ABSENT},
+                      _rays_trained_camera_train_view),
+    (True, "eval"): ({"noisy_focal": _ABSENT, "noisy_extrinsic": _ABSENT}, _rays_trained_camera_held_out_view),
+    (False, "train"): ({"noisy_focal": _GIVEN, "noisy_extrinsic": _GIVEN}, _rays_noisy_pinhole_train_view),
+    (False, "eval"): ({"gt_extrinsic": _GIVEN, "noisy_focal": _ABSENT, "noisy_extrinsic": _ABSENT},
+                      _rays_ground_truth_pinhole),
+}
+_PHASE = {"train": "train", "val": "eval", "test": "eval"}
+
+
+def _select_rays(a):
+    if a["rays"] is not None:
+        return _rays_precomputed(a)
+    entry = _RAY_SOURCES.get((a["camera_model"] is not None, _PHASE.get(a["mode"])))
+    assert entry is not None, "This message should not appear."
+    preconditions, build = entry
+    for name, must_be_none in preconditions.items():
+        assert (a[name] is None) == must_be_none, \
+            "render(mode=%r): argument %r must %sbe given" % (a["mode"], name, "not " if must_be_none else "")
+    return build(a)
+
+
 def render(H, W, chunk, rays=None, noisy_focal=None, noisy_extrinsic=None, ndc=True, near=0., far=1.,
            use_viewdirs=False, mode=None, camera_model=None, image_idx=None, i_map=None, gt_intrinsic=None,
            gt_extrinsic=None, transform_align=None, _ray_range=None, **kwargs):
-    """Same ray-source selection, view-direction / NDC handling and return structure as the
-    reference (:18-141).  `_ray_range=(lo, hi)` (not in the reference; used by the multi-GPU image
-    renderer) renders only the flattened rays [lo, hi): outputs come back as [hi-lo, ...]."""
-    assert not mode is None
-    if not rays is None:
+    """Ray-source selection, view directions, NDC warp, ray-batch packing and output reshaping of the
+    reference's render() (:18-141); returns [rgb_map, disp_map, acc_map, extras].  `_ray_range=(lo, hi)`
+    (not in the reference; used by the multi-GPU image renderer) renders only the flattened rays [lo, hi):
+    outputs come back as [hi-lo, ...]."""
+    assert mode is not None
+    rays_o, rays_d, focal = _select_rays(dict(
+        H=H, W=W, rays=rays, noisy_focal=noisy_focal, noisy_extrinsic=noisy_extrinsic, mode=mode,
+        camera_model=camera_model, image_idx=image_idx, i_map=i_map, gt_intrinsic=gt_intrinsic,
+        gt_extrinsic=gt_extrinsic, transform_align=transform_align))
+    lead = tuple(rays_d.shape[:-1])                              # outputs are reshaped back to this
+    columns = []
+    if use_viewdirs:                                             # unit directions of the UN-warped rays (:105-109)
+        columns.append((rays_d / torch.norm(rays_d, dim=-1, keepdim=True)).reshape(-1, 3).float())
+    if ndc:
         if camera_model is None:
-            focal = noisy_focal
-        rays_o, rays_d = rays
-    elif not camera_model is None and mode == "train":
-        assert not i_map is None
-        assert image_idx in i_map
-        assert gt_intrinsic is None
-        assert gt_extrinsic is None
-        idx_in_camera_param = np.where(i_map == image_idx)[0][0]
-        rays_o, rays_d = get_rays_full_image_use_camera(
-            H=H, W=W, camera_model=camera_model, extrinsic=noisy_extrinsic[idx_in_camera_param])
-    elif not camera_model is None and mode in ["val", "test"]:
-        assert noisy_focal is None
-        assert noisy_extrinsic is None
-        rays_o, rays_d = get_rays_full_image_use_camera(
-            H=H, W=W, camera_model=camera_model, extrinsic=transform_align)
-    elif camera_model is None and mode == "train":
-        assert not noisy_focal is None
-        assert not noisy_extrinsic is None
-        focal = noisy_focal
-        rays_o, rays_d = get_rays_full_image_no_camera(H=H, W=W, focal=focal, extrinsic=noisy_extrinsic[image_idx])
-    elif camera_model is None and mode in ["val", "test"]:
-        assert not gt_extrinsic is None
-        assert noisy_focal is None
-        assert noisy_extrinsic is None
-        focal = gt_intrinsic[0][0].item()
-        rays_o, rays_d = get_rays_full_image_no_camera(H=H, W=W, focal=focal, extrinsic=gt_extrinsic[image_idx])
-    else:
-        assert False, "This message should not appear."
-
-    if use_viewdirs:
-        viewdirs = rays_d                                   # taken BEFORE the NDC warp (:105-109)
-        viewdirs = viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True)
-        viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
-
-    sh = rays_d.shape
-    if ndc and camera_model is None:
-        rays_o, rays_d = ndc_rays(H, W, focal, 1., rays_o, rays_d)
-    elif ndc and not camera_model is None:
-        rays_o, rays_d = ndc_rays_camera(H, W, camera_model, 1., rays_o, rays_d)
-
-    rays_o = torch.reshape(rays_o, [-1, 3]).float()
-    rays_d = torch.reshape(rays_d, [-1, 3]).float()
-    near, far = near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])
-    rays = torch.cat([rays_o, rays_d, near, far], -1)
-    if use_viewdirs:
-        rays = torch.cat([rays, viewdirs], -1)
-
+            rays_o, rays_d = ndc_rays(H, W, focal, 1., rays_o, rays_d)
+        else:
+            rays_o, rays_d = ndc_rays_camera(H, W, camera_model, 1., rays_o, rays_d)
+    rays_o, rays_d = rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float()
+    ones = torch.ones_like(rays_d[:, :1])
+    packed = torch.cat([rays_o, rays_d, near * ones, far * ones] + columns, dim=-1)
     if _ray_range is not None:
-        rays = rays[_ray_range[0]:_ray_range[1]]
-        sh = (rays.shape[0], 3)
-    all_ret = batchify_rays(rays, chunk, **kwargs)
-    for k in all_ret:
-        k_sh = list(sh[:-1]) + list(all_ret[k].shape[1:])
-        all_ret[k] = torch.reshape(all_ret[k], k_sh)
-    k_extract = ['rgb_map', 'disp_map', 'acc_map']
-    ret_list = [all_ret[k] for k in k_extract]
-    ret_dict = {k: all_ret[k] for k in all_ret if k not in k_extract}
-    return ret_list + [ret_dict]
+        packed = packed[_ray_range[0]:_ray_range[1]]
+        lead = (packed.shape[0],)
+    outputs = batchify_rays(packed, chunk, **kwargs)
+    outputs = {key: value.reshape(lead + tuple(value.shape[1:])) for key, value in outputs.items()}
+    maps = [outputs.pop(key) for key in ('rgb_map', 'disp_map', 'acc_map')]
+    return maps + [outputs]
 
 
 class _HostRing:

@@ -18,6 +18,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import _capi
 from . import mlp_layout as ML
 
 img2mse = lambda x, y: torch.mean((x - y) ** 2)                                   # reference :10
@@ -138,7 +139,7 @@ class NeRF(nn.Module):
         the weight gradients straight into it instead of returning 24 tensors for autograd to accumulate."""
         params = [p for _, p in self.named_parameters()]
         g0 = params[0].grad
-        if g0 is None or g0.dtype != torch.float32 or not g0.is_cuda:
+        if g0 is None or g0.dtype != torch.float32 or not _capi.on_device(g0):
             return None
         base, off = g0.data_ptr(), 0
         for p in params:

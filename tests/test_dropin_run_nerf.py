@@ -1,0 +1,218 @@
+"""The drop-in claim of the north star: the reference's training script runs on this package UNCHANGED.
+
+CPU part (build container, where /root/reference exists):
+  * the unmodified NeRF/run_nerf.py imports under `scnerf_amd.dropin.install()` (absent third-party packages
+    stubbed) and every global name it loads is defined -- `torch`, `np`, `wandb` ... reach it only through
+    `from model.camera_model import *`;
+  * its real `train()` runs four iterations -- the frozen-camera start, the `add_ie` and `add_od` curriculum
+    toggles, the `global_step % 2000 == 1` logging branch that unpacks `log_noises`, the projected-ray-distance
+    term -- with the kernels executed by the CPU SIMT interpreter build of the same .hip sources
+    (tests/emu/host_on_emu.py); the loss must fall and the camera parameters must move only once unfrozen;
+  * the call surface of `train()` (every call into the mirrored modules with its keyword names) equals the
+    committed fixture, and tests/run_nerf_loop.py -- the driver the GPU box uses, where the reference tree
+    does not exist -- makes every one of those calls.
+
+GPU part: tests/run_nerf_loop.py trains on the device (batched and single-image ray sources, PRD term,
+checkpoint + reload through create_nerf, validation / test / end-of-training / render-only image renders); on a
+machine that has both a GPU and the reference tree the unmodified script itself is driven the same way."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from tests import dropin_support as S  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+needs_reference = pytest.mark.skipif(not S.reference_available(), reason="reference tree not present")
+
+# calls of train() the GPU driver does not make, with the reason
+NOT_REPLAYED = {
+    # reached only with camera_model None *after* get_rays_kps_use_camera(camera_model=None) three lines
+    # earlier (run_nerf.py:531-546 -> :549), which raises in the reference itself
+    ("proj_ray_dist_loss_single", ("H", "W", "args", "device", "extrinsic", "img_idx0", "img_idx1", "intrinsic",
+                                   "kps0_list", "kps1_list", "method", "mode", "rays0", "rays1")),
+}
+
+
+class _LoopFinished(Exception):
+    pass
+
+
+def _stop_after_training(*args, **kwargs):
+    """Stands in for projected_ray_distance_evaluation: its first call with mode="train" is the first thing
+    the script does after the optimisation loop (run_nerf.py:912), which is where these tests stop."""
+    if kwargs.get("mode") == "train":
+        raise _LoopFinished()
+    return torch.tensor(0.0)
+
+
+def _prepare(mod, tmp_path, n_iters, extra=(), device="cpu", n_rand=8):
+    H, W = 24, 32
+    mod.load_llff_data = lambda *a, **k: S.synthetic_llff(H=H, W=W, device=device)
+    mod.projected_ray_distance_evaluation = _stop_after_training
+    mod.runSIFTSinglePair = S.synthetic_matcher(H, W)
+    mod.image_pair_candidates = lambda poses, args, i_map: {int(i): [int(j) for j in i_map if j != i] for i in i_map}
+    argv = S.train_argv(tmp_path, n_iters, extra)
+    argv[argv.index("--N_rand") + 1] = str(n_rand)
+    return argv
+
+
+@needs_reference
+def test_unmodified_run_nerf_imports_and_resolves_every_name():
+    mod = S.import_reference_run_nerf()
+    assert mod.__file__ == os.path.join(S.REF_ROOT, "NeRF", "run_nerf.py")
+    # the hot path resolves to this package, the rest stays the reference's
+    for name in ("render", "render_path", "create_nerf", "get_rays_kps_use_camera", "img2mse",
+                 "proj_ray_dist_loss_single", "preprocess_match"):
+        assert getattr(mod, name).__module__.startswith("scnerf_amd."), name
+    assert mod.config_parser.__module__ == "config_argparse"
+    assert mod.image_pair_candidates.__module__ == "model.reprojection"
+    for name in ("torch", "np", "wandb", "Image", "to_pil", "to_pil_normalize"):
+        assert hasattr(mod, name), name
+    assert S.undefined_globals(mod) == []
+
+
+@needs_reference
+def test_unmodified_train_runs_on_the_simt_interpreter(tmp_path, monkeypatch):
+    from tests.emu.host_on_emu import emulated_device
+    mod = S.import_reference_run_nerf()
+    argv = _prepare(mod, tmp_path, 5, extra=["--ray_loss_type", "proj_ray_dist", "--i_ray_dist_loss", "1",
+                                             "--add_prd", "3", "--ray_dist_loss_weight", "1e-4"])
+    argv[argv.index("--ray_loss_type")] = "--ignored_dup"          # train_argv already carries "none": drop it
+    argv = [a for i, a in enumerate(argv) if not (a == "--ignored_dup" or (i > 0 and argv[i - 1] == "--ignored_dup"))]
+    monkeypatch.setattr(sys, "argv", argv)
+    seen = {}
+    real_create = mod.create_nerf
+
+    def spy_create(*a, **k):
+        out = real_create(*a, **k)
+        seen["camera_model"], seen["optimizer"] = out[5], out[4]
+        seen["net"] = out[0]["network_fn"]
+        return out
+    mod.create_nerf = spy_create
+    history = mod.wandb.history if hasattr(mod.wandb, "history") else None
+    if history is not None:
+        del history[:]
+    with emulated_device():
+        with pytest.raises(_LoopFinished):
+            mod.train()
+    cam = seen["camera_model"]
+    assert cam is not None and type(cam).__module__ == "scnerf_amd.camera_model"
+    # curriculum: frozen at i = 1, intrinsics / extrinsics from i = 2, ray noise from i = 3
+    assert cam.intrinsics_noise.requires_grad and cam.ray_o_noise.requires_grad
+    assert float(cam.intrinsics_noise.abs().max()) > 0 and float(cam.extrinsics_noise.abs().max()) > 0
+    assert float(cam.ray_d_noise.abs().max()) > 0
+    if history is not None:
+        logs = [d for _, d in history]
+        assert len(logs) == 4
+        losses = [d["train/loss"] for d in logs]
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+        # global_step == 1 (second iteration): the log_noises pair was unpacked into the log
+        assert "camera/fx_err" in logs[1] and "camera/extrinisic_err" in logs[1] and "camera/ray_o_noise" in logs[1]
+        assert "camera/fx_err" not in logs[0]
+        assert any("train/ray_dist_loss" in d for d in logs[2:]), "the PRD term never ran"
+
+
+@needs_reference
+def test_call_surface_fixture_is_current():
+    with open(os.path.join(S.REF_ROOT, "NeRF", "run_nerf.py")) as f:
+        live = S.call_surface(f.read(), "train")
+    with open(os.path.join(GOLDEN, "run_nerf_calls.json")) as f:
+        assert json.load(f)["calls"] == live
+
+
+def test_gpu_driver_makes_every_call_of_the_reference_train():
+    with open(os.path.join(GOLDEN, "run_nerf_calls.json")) as f:
+        wanted = {(c[0], c[1], tuple(c[2]), c[3]) for c in json.load(f)["calls"]}
+    with open(os.path.join(ROOT, "tests", "run_nerf_loop.py")) as f:
+        made = {(c[0], c[1], tuple(c[2]), c[3]) for c in S.call_surface(f.read())}
+    missing = {c for c in wanted - made if (c[0], c[2]) not in NOT_REPLAYED}
+    assert not missing, "tests/run_nerf_loop.py does not replay: %s" % sorted(missing)
+
+
+def test_mirrors_accept_every_keyword_the_reference_passes():
+    """inspect-level check of the same fixture: each recorded keyword set binds to the mirror's signature."""
+    import inspect
+    from scnerf_amd import create_nerf, get_rays, ray_dist_loss, render, run_nerf_helpers
+    where = {}
+    for m in (render, get_rays, create_nerf, run_nerf_helpers, ray_dist_loss):
+        for n in S.API_FUNCTIONS:
+            if hasattr(m, n) and n not in where:
+                where[n] = getattr(m, n)
+    with open(os.path.join(GOLDEN, "run_nerf_calls.json")) as f:
+        calls = json.load(f)["calls"]
+    for name, npos, kws, _ in calls:
+        if name.startswith("."):
+            continue
+        sig = inspect.signature(where[name])
+        sig.bind_partial(*([None] * npos), **{k: None for k in kws})
+
+
+def _namespace(tmp_path, **over):
+    with open(os.path.join(GOLDEN, "run_nerf_args.json")) as f:
+        ns = json.load(f)["namespace"]
+    ns.update(basedir=str(tmp_path), expname="dropin", n_gpus=1)
+    ns.update(over)
+    from tests.run_nerf_loop import namespace
+    return namespace(ns)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batching", [False, True])
+def test_gpu_training_loop_through_the_mirrored_api(tmp_path, batching):
+    from tests.run_nerf_loop import Loop
+    H, W = 24, 32
+    args = _namespace(tmp_path, N_rand=256, N_samples=16, N_importance=16, no_batching=not batching, N_iters=9,
+                      i_weights=4, ray_loss_type="proj_ray_dist", i_ray_dist_loss=1, add_prd=3,
+                      ray_dist_loss_weight=1e-4, lrate=2e-3)
+    data = S.synthetic_llff(H=H, W=W, device="cuda")
+    loop = Loop(args, data, torch.device("cuda"), matcher=S.synthetic_matcher(H, W)).run()
+    cam = loop.camera_model
+    logs = loop.history
+    assert len(logs) == 8
+    losses = [d["train/loss"] for d in logs]
+    assert all(np.isfinite(losses)) and min(losses[-3:]) < losses[0]
+    assert "camera/fx_err" in logs[1] and "camera/ray_d_noise" in logs[1] and "camera/fx_err" not in logs[2]
+    assert float(cam.intrinsics_noise.abs().max()) > 0 and float(cam.ray_o_noise.abs().max()) > 0
+    if not batching:
+        assert any("train/ray_dist_loss" in d for d in logs[2:])
+    # image renders through the test-time kwargs
+    rgb, disp, psnr = loop.validation_render()
+    assert rgb.shape == (H, W, 3) and disp.shape == (H, W) and np.isfinite(psnr)
+    rgbs, disps = loop.test_render(savedir=None)
+    assert rgbs.shape == (1, H, W, 3) and disps.shape == (1, H, W) and np.isfinite(rgbs).all()
+    rgbs, _ = loop.train_view_render()
+    assert rgbs.shape == (1, H, W, 3)
+    rgbs, _ = loop.render_only()
+    assert rgbs.shape[1:] == (H, W, 3)
+    # checkpoint written at i = 4 and 8 is found and restored by create_nerf (no_reload unset)
+    assert os.path.basename(loop.last_checkpoint) == "000008.tar"
+    again = Loop(args, data, torch.device("cuda"), matcher=S.synthetic_matcher(H, W)).setup()
+    assert again.global_step == 7 and again.start == 8
+    for a, b in zip(again.camera_model.parameters(), cam.parameters()):
+        assert torch.equal(a, b)
+    pa = again.render_kwargs_train["network_fine"].state_dict()
+    pb = loop.render_kwargs_train["network_fine"].state_dict()
+    assert all(torch.equal(pa[k], pb[k]) for k in pa)
+
+
+@pytest.mark.gpu
+@needs_reference
+def test_gpu_unmodified_train(tmp_path, monkeypatch):
+    """Only where a GPU and the reference tree coexist (not the graft GPU box)."""
+    mod = S.import_reference_run_nerf()
+    argv = _prepare(mod, tmp_path, 5, device="cuda", n_rand=256)
+    monkeypatch.setattr(sys, "argv", argv)
+    torch.set_default_tensor_type('torch.cuda.FloatTensor')
+    try:
+        with pytest.raises(_LoopFinished):
+            mod.train()
+    finally:
+        torch.set_default_tensor_type('torch.FloatTensor')
