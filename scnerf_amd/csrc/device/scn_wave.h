@@ -65,6 +65,13 @@ __device__ __forceinline__ float max_raw(float a, float b) {
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// a + b as ONE v_add_f32 (plain `+` on neighbouring values is SLP-packed into v_pk_add_f32, which is slower
+// than two scalar adds next to fp32 MFMAs: MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+__device__ __forceinline__ float add_raw(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // bits = 2 * bits + (v > 0): one compare into VCC and one add-with-carry
 __device__ __forceinline__ unsigned shift_in_positive(unsigned bits, float v) {
     asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(v) : "vcc");

@@ -19,6 +19,7 @@
 #include "launch.h"
 #include "mlp_common.h"
 #include "scnerf_hip.h"
+#include "wgrad256.h"
 
 namespace {
 
@@ -354,6 +355,14 @@ int launch_wgrad(const WgradArgs& a, int G, hipStream_t stream) {
 
 
 
+// the 256 x 256 tile-native GEMMs of a pass in one launch, grid (chunks, jobs) (wgrad256.h)
+int launch_wgrad256(const wg256::Args& a, int G, hipStream_t stream) {
+    constexpr int F = wg256::kSpread;
+    SCN_LDS_OPT_IN((wg256::wgrad256_kernel<F>), wg256::kLdsBytes);
+    hipLaunchKernelGGL((wg256::wgrad256_kernel<F>), dim3(G, a.n_jobs), dim3(wg256::kThreads), wg256::kLdsBytes, stream, a);
+    return scn_launch_status();
+}
+
 struct Shape { int BN, BK; };
 
 bool pick_shape(int n_load, int k_load, Shape* s) {
@@ -377,10 +386,10 @@ namespace {
 // GEMM into partials at `workspace`; fills `job` (the reduction that finishes it) and returns the floats used
 int wgrad_gemm(const float* dz, int lda, int n_load, int n_out, int dz_tiled, const float* x, int ldb, int k_load,
                int k_out, int x_tiled, long long n_samples, int n_chunks, float* workspace, float* dW, int ldo,
-               int col0, float* db, hipStream_t st, ReduceJob* job, long long* used) {
+               int col0, float* db, hipStream_t st, ReduceJob* job, long long* used, wg256::Args* batch = nullptr) {
     SCN_RETURN_IF(!dz || !x || !workspace || !dW || n_samples < 0 || n_chunks < 1, SCN_EINVAL);
     SCN_RETURN_IF(lda % 4 || ldb % 4 || n_load % 4 || k_load % 4 || n_out > n_load || k_out > k_load, SCN_EINVAL);
-    SCN_RETURN_IF(((uintptr_t)dz | (uintptr_t)x) & 15, SCN_EINVAL);
+    SCN_RETURN_IF(((uintptr_t)dz | (uintptr_t)x | (uintptr_t)workspace) & 15, SCN_EINVAL);
     Shape s;
     SCN_RETURN_IF(!pick_shape(n_load, k_load, &s), SCN_ENOSUP);
     // a tile-native operand must fill the block tile exactly (its HBM block is the LDS image)
@@ -398,7 +407,18 @@ int wgrad_gemm(const float* dz, int lda, int n_load, int n_out, int dz_tiled, co
     a.part_w = workspace;
     a.part_b = a.part_w + (long)G * s.BN * s.BK;
     int rc;
-    if (s.BN == 256 && s.BK == 256) rc = launch_wgrad<4, 4>(a, G, st);
+    const bool both_tiled_256 = s.BN == 256 && s.BK == 256 && dz_tiled && x_tiled && n_load == 256 && k_load == 256;
+    if (both_tiled_256) {
+        // multi-GEMM kernel: queued into `batch` when the caller launches several at once
+        wg256::Args one;
+        wg256::Args* q = batch ? batch : &one;
+        if (!batch) one.n_jobs = 0;
+        SCN_RETURN_IF(q->n_jobs >= wg256::kMaxJobs, SCN_EINVAL);
+        q->Ppad = a.Ppad;
+        q->chunk = a.chunk;
+        q->job[q->n_jobs++] = wg256::Job{dz, x, a.part_w, db ? a.part_b : nullptr};
+        rc = batch ? 0 : launch_wgrad256(one, G, st);
+    } else if (s.BN == 256 && s.BK == 256) rc = launch_wgrad<4, 4>(a, G, st);
     else if (s.BN == 256 && s.BK == 128) rc = launch_wgrad<4, 2>(a, G, st);
     else if (s.BN == 256 && s.BK == 64) rc = launch_wgrad<4, 1>(a, G, st);
     else if (s.BN == 128 && s.BK == 256) rc = launch_wgrad<2, 4>(a, G, st);
@@ -452,6 +472,9 @@ extern "C" int scnerf_nerf_param_count(int pt_dims) {
 }
 
 namespace {
+// the GEMM slabs behind the vecmat partials stay 16-byte aligned (the persistent kernel stores them as float4)
+long long vecmat_ws_floats(long long n_chunks) { return (257 * n_chunks + 3) / 4 * 4; }
+
 template <int PD>
 int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long long P, int n_chunks,
                float* workspace, float* g, int accumulate, void* stream) {
@@ -467,12 +490,14 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
     ReduceJobs jobs;
     jobs.n = 0;
     jobs.accumulate = accumulate;
-    float* ws = workspace + 257LL * n_chunks;          // [0, 257 G): the vecmat partials
+    wg256::Args big;                 // the eight 256 x 256 GEMMs go out as one launch
+    big.n_jobs = 0;
+    float* ws = workspace + vecmat_ws_floats(n_chunks);   // [0, 257 G) rounded up: the vecmat partials
     hipStream_t st = (hipStream_t)stream;
 #define SCN_WG(...)                                                                            \
     {                                                                                          \
         long long used__ = 0;                                                                  \
-        rc = wgrad_gemm(__VA_ARGS__, st, &jobs.j[jobs.n], &used__);                            \
+        rc = wgrad_gemm(__VA_ARGS__, st, &jobs.j[jobs.n], &used__, &big);                      \
         if (rc != 0) return rc;                                                                \
         ws += used__;                                                                          \
         ++jobs.n;                                                                              \
@@ -498,6 +523,10 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
     // rgb_linear: dZ = d_raw[:, 0:3] (row-major), X = hidden of the views layer
     SCN_WG(d_raw, 4, 4, 3, 0, S(kSaveHv), 128, 128, 128, 1, P, n_chunks, ws, g + V::kWRGB, 128, 0, g + V::kBRGB)
 #undef SCN_WG
+    if (big.n_jobs > 0) {
+        rc = launch_wgrad256(big, n_chunks, st);
+        if (rc != 0) return rc;
+    }
     // one launch finishes all twelve GEMMs (fixed-order sums: deterministic)
     int blocks = 0;
     for (int i = 0; i < jobs.n; ++i) {
@@ -524,5 +553,5 @@ extern "C" long long scnerf_nerf_wgrad_workspace_floats(int n_chunks) {
     // (128 x 256), (128 x 64), (64 x 128) blocks + the vecmat partials
     const long long G = n_chunks;
     auto blk = [&](long long bn, long long bk) { return G * (bn * bk + bn); };
-    return 257 * G + 9 * blk(256, 256) + 2 * blk(256, 128) + blk(128, 256) + blk(128, 64) + blk(64, 128);
+    return vecmat_ws_floats(G) + 9 * blk(256, 256) + 2 * blk(256, 128) + blk(128, 256) + blk(128, 64) + blk(64, 128);
 }

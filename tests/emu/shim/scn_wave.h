@@ -77,6 +77,7 @@ inline void sched_fence() {}
 inline int uniform(int v) { return v; }
 template <typename T> inline const T* uniform_ptr(const T* p) { return p; }
 inline float max_raw(float a, float b) { return a > b ? a : b; }
+inline float add_raw(float a, float b) { return a + b; }
 template <int POS> inline float keep_if_bit(float v, unsigned bits) { return ((bits >> POS) & 1u) ? v : 0.f; }
 inline unsigned shift_in_positive(unsigned bits, float v) { return bits + bits + (v > 0.f ? 1u : 0u); }
 template <int N> inline void sched_group_mfma() {}

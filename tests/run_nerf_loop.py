@@ -254,7 +254,10 @@ class Loop:
                                transform_align=aligned)
 
     def train_view_render(self, savedir=None):
-        """End-of-training rendering of train view 0 (:958-990; `i_train = [0]` there)."""
+        """End-of-training rendering of train view 0 (:958-990).  The script sets `i_train = [0]` but still hands
+        over the poses of ALL train views, so its render_path indexes i_map[1] and stops with an IndexError
+        after the first image whenever there is more than one train view; here the poses are cut to the views
+        in i_train, which is what that first image is."""
         cam, args = self.camera_model, self.args
         i_train = [0]
         with torch.no_grad():
@@ -263,7 +266,7 @@ class Loop:
                                    hwf=[self.H, self.W, self.noisy_focal], chunk=args.chunk,
                                    render_kwargs=self.render_kwargs_train, mode="train", gt_imgs=self.images[i_train],
                                    savedir=savedir, args=args)
-            return render_path(render_poses=cam.get_extrinsic(), noisy_extrinsic=cam.get_extrinsic(),
+            return render_path(render_poses=cam.get_extrinsic()[i_train], noisy_extrinsic=cam.get_extrinsic(),
                                hwf=(self.H, self.W, None), chunk=args.chunk, render_kwargs=self.render_kwargs_train,
                                mode="train", gt_imgs=self.images[i_train], savedir=savedir, camera_model=cam,
                                args=args, i_map=i_train)

@@ -181,8 +181,7 @@ def test_gpu_training_loop_through_the_mirrored_api(tmp_path, batching):
     assert all(np.isfinite(losses)) and min(losses[-3:]) < losses[0]
     assert "camera/fx_err" in logs[1] and "camera/ray_d_noise" in logs[1] and "camera/fx_err" not in logs[2]
     assert float(cam.intrinsics_noise.abs().max()) > 0 and float(cam.ray_o_noise.abs().max()) > 0
-    if not batching:
-        assert any("train/ray_dist_loss" in d for d in logs[2:])
+    assert any("train/ray_dist_loss" in d for d in logs[2:])
     # image renders through the test-time kwargs
     rgb, disp, psnr = loop.validation_render()
     assert rgb.shape == (H, W, 3) and disp.shape == (H, W) and np.isfinite(psnr)
