@@ -201,6 +201,78 @@ __device__ __forceinline__ void stream_commit(WStream& ws, const f32x4 (&stage)[
     ws.g += N_F4 * kThreads;
 }
 
+// ---- spread schedule -----------------------------------------------------------------------------------
+// A chunk is walked in NB bundles of 8 MFMAs.  Issued as bursts (all loads at the head, all LDS writes
+// half-way, all activation stores at the head) the memory instructions of the four waves collide: each wave
+// sits in front of a full queue while its matrix pipe drains (measured on the weight-gradient GEMM, which has
+// the same structure: 119 -> 140 TFLOP/s by spreading, profiles/r02_wgrad_lab_*.txt).  Spread:
+//   bundles [0, NB/4)       the global loads of the NEXT chunk,
+//   bundles [NB/4, 3NB/4)   its LDS writes, one or two per bundle, in load order,
+//   bundle  3NB/4           the workgroup barrier (unchanged),
+//   bundles [3NB/4, NB)     the activation / gradient stores of this chunk's B operands (training).
+// Chunks with fewer than 8 bundles keep the burst form.
+template <int NB, int N>
+struct Spread {
+    static constexpr bool kOn =
+#ifdef SCN_BURST                    // (timing experiments only: the round-1 schedule)
+        false;
+#else
+        NB >= 8 && N > 0;
+#endif
+    static constexpr int kQ = NB / 4;
+    static constexpr int load_at(int i) { return (i * kQ) / (N > 0 ? N : 1); }
+    static constexpr int commit_at(int i) { return kQ + (i * 2 * kQ) / (N > 0 ? N : 1); }
+    static constexpr int store_at(int k, int n_store) { return 3 * kQ + (k * (NB - 3 * kQ)) / n_store; }
+};
+
+template <int N_F4>
+__device__ __forceinline__ void stream_issue_piece(const WStream& ws, f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1], int i) {
+#ifndef SCN_ABLATE_NO_STREAM
+    stage[i] = ws.g[i * kThreads + threadIdx.x];
+#else
+    stage[i] = f32x4{1.f, 2.f, 3.f, (float)threadIdx.x};
+#endif
+}
+
+template <int N_F4>
+__device__ __forceinline__ void stream_commit_piece(const WStream& ws, const f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1], int i) {
+    f32x4* dst = reinterpret_cast<f32x4*>(WStream::buf(ws.next()));
+    dst[i * kThreads + threadIdx.x] = stage[i];
+}
+
+// store k (= (t - T0) * 4 + q) of store_tiles<T0, T1>
+template <int T0, int N>
+__device__ __forceinline__ void store_tile_piece(const float (&regs)[N], float* tile, int k) {
+#ifdef SCN_ABLATE_NO_ROWSTORE
+    return;
+#endif
+    if (tile == nullptr) return;
+    const int t = T0 + k / 4, q = k % 4;
+    f32x4 v = {regs[16 * t + 4 * q + 0], regs[16 * t + 4 * q + 1], regs[16 * t + 4 * q + 2], regs[16 * t + 4 * q + 3]};
+    *reinterpret_cast<f32x4*>(tile + (t * 4 + q) * 256) = v;
+}
+
+// everything the spread schedule does in bundle p of a chunk (compile-time p after unrolling)
+template <int NB, int N_F4, int NSTEP, int T0, int T1>
+__device__ __forceinline__ void spread_bundle(int p, WStream& ws, f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1],
+                                              const float (&b)[NSTEP], float* save_tile) {
+    using S = Spread<NB, N_F4>;
+    if constexpr (S::kOn) {
+#pragma unroll
+        for (int i = 0; i < N_F4; ++i)
+            if (S::load_at(i) == p) stream_issue_piece<N_F4>(ws, stage, i);
+#pragma unroll
+        for (int i = 0; i < N_F4; ++i)
+            if (S::commit_at(i) == p) stream_commit_piece<N_F4>(ws, stage, i);
+    }
+    if constexpr (Spread<NB, 1>::kOn && T1 > T0) {
+        constexpr int NS = (T1 - T0) * 4;
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+            if (Spread<NB, 1>::store_at(k, NS) == p) store_tile_piece<T0, NSTEP>(b, save_tile, k);
+    }
+}
+
 // First chunk of the whole stream (kernel prologue).
 template <int N_F4>
 __device__ __forceinline__ void stream_prime(WStream& ws) {
@@ -238,9 +310,10 @@ __device__ __forceinline__ void store_tiles(const float (&regs)[N], float* tile)
 // registers of the NEXT chunk are written to the next LDS buffer, at three quarters the workgroup
 // synchronises; CONT_IN: the ring already holds this chunk's first pair (fetched by the previous chunk);
 // CONT_OUT: fetch the next chunk's first pair from the next buffer (same part: same fragment geometry).
-template <int NSTEP, int NT, int CS, int B0, int N_F4, bool CONT_IN, bool CONT_OUT>
+template <int NSTEP, int NT, int CS, int B0, int N_F4, bool CONT_IN, bool CONT_OUT, int T0 = 0, int T1 = 0>
 __device__ __forceinline__ void mfma_chunk(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
-                                           const f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1], f32x4 (&ring)[8], int lane) {
+                                           f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1], f32x4 (&ring)[8], int lane,
+                                           float* save_tile = nullptr) {
     constexpr int G = CS / 4;
     constexpr int NF = G * NT;                 // fragments, order f = g * NT + t
     const f32x4* A = reinterpret_cast<const f32x4*>(WStream::buf(ws.cur)) + lane;
@@ -263,13 +336,22 @@ __device__ __forceinline__ void mfma_chunk(const float (&b)[NSTEP], f32x16 (&acc
         constexpr int COMMIT_AT = (NB * SCN_COMMIT_NUM) / SCN_COMMIT_DEN;
         constexpr int SYNC_AT = (NB * SCN_SYNC_NUM) / SCN_SYNC_DEN >= NB ? NB - 1 : (NB * SCN_SYNC_NUM) / SCN_SYNC_DEN;
         const f32x4* An = reinterpret_cast<const f32x4*>(WStream::buf(ws.next())) + lane;
+        constexpr bool SPREAD = Spread<NB, N_F4>::kOn;
+        static_assert(!SPREAD || (SYNC_AT == 3 * (NB / 4) && Spread<NB, N_F4>::commit_at(N_F4 - 1) < SYNC_AT),
+                      "every LDS write of the next chunk is issued before the barrier");
+        if constexpr (!SPREAD) {
+            stream_issue<N_F4>(ws, stage);
+            sched_fence();      // the loads stay at the head of the chunk: half a chunk of MFMAs covers them
+        }
+        if constexpr (!Spread<NB, 1>::kOn) store_tiles<T0, T1, NSTEP>(b, save_tile);
         if constexpr (!CONT_IN) {
 #pragma unroll
             for (int k = 0; k < IW; ++k) ring[k] = A[((k % NT) * G + k / NT) * 64];
         }
 #pragma unroll
         for (int p = 0; p < NB; ++p) {
-            if (p == COMMIT_AT) stream_commit<N_F4>(ws, stage);
+            spread_bundle<NB, N_F4, NSTEP, T0, T1>(p, ws, stage, b, save_tile);
+            if (!SPREAD && p == COMMIT_AT) stream_commit<N_F4>(ws, stage);
             if (p == SYNC_AT) {
 #ifndef SCN_ABLATE_NO_BARRIER      // (timing experiments only: tools/ablate.sh)
                 block_sync();
@@ -293,8 +375,12 @@ __device__ __forceinline__ void mfma_chunk(const float (&b)[NSTEP], f32x16 (&acc
                 for (int k = 0; k < IW; ++k)
                     acc[t + k] = mfma_32x32x2(ring[IW * (p & 1) + k][j], b[B0 + 4 * g + j], acc[t + k]);
         }
+        if constexpr (SPREAD) ws.g += N_F4 * kThreads;
     } else {
         static_assert(!CONT_IN && !CONT_OUT, "single-tile parts do not chain");
+        stream_issue<N_F4>(ws, stage);
+        sched_fence();
+        store_tiles<T0, T1, NSTEP>(b, save_tile);
         constexpr int COMMIT_AT = NF / 2;
         constexpr int SYNC_AT = (NF * 3) / 4;
         f32x4 r3[3];
@@ -340,14 +426,17 @@ struct EpiTail {       // slices (P, g, j) for K = 4 g + j = K .. 4 G - 1
     }
 };
 
-template <int NSTEP, int NT, int CS, int B0, int N_F4, bool CONT_IN, class EPI, int Q>
+template <int NSTEP, int NT, int CS, int B0, int N_F4, bool CONT_IN, class EPI, int Q, int T0 = 0, int T1 = 0>
 struct LastChunk {
     static constexpr int G = CS / 4, NPAIR = NT / 2, NQ = NPAIR * G;
     static constexpr int P = Q / G, g = Q % G;
+    static constexpr bool SPREAD = Spread<NQ, N_F4>::kOn;
+    static_assert(!SPREAD || Spread<NQ, N_F4>::commit_at(N_F4 - 1) < (NQ * 3) / 4, "LDS writes before the barrier");
     static __device__ __forceinline__ void run(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
-                                               const f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1], f32x4 (&ring)[8],
-                                               const f32x4* A, EPI& epi) {
-        if constexpr (Q == NQ / 2) stream_commit<N_F4>(ws, stage);
+                                               f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1], f32x4 (&ring)[8],
+                                               const f32x4* A, EPI& epi, float* save_tile) {
+        spread_bundle<NQ, N_F4, NSTEP, T0, T1>(Q, ws, stage, b, save_tile);
+        if constexpr (!SPREAD && Q == NQ / 2) stream_commit<N_F4>(ws, stage);
         if constexpr (Q == (NQ * 3) / 4) {
 #ifndef SCN_ABLATE_NO_BARRIER
             block_sync();
@@ -381,26 +470,33 @@ struct LastChunk {
 #endif
         }
         if constexpr (Q + 1 < NQ) {
-            LastChunk<NSTEP, NT, CS, B0, N_F4, CONT_IN, EPI, Q + 1>::run(b, acc, ws, stage, ring, A, epi);
+            LastChunk<NSTEP, NT, CS, B0, N_F4, CONT_IN, EPI, Q + 1, T0, T1>::run(b, acc, ws, stage, ring, A, epi, save_tile);
         } else {
+            if constexpr (SPREAD) ws.g += N_F4 * kThreads;
             sched_fence();
             EpiTail<EPI, NPAIR - 1, G, 0>::run(epi);      // the last pair's epilogue: nothing left to hide it under
         }
     }
 };
 
-template <int NSTEP, int NT, int CS, int B0, int N_F4, bool CONT_IN, class EPI>
+template <int NSTEP, int NT, int CS, int B0, int N_F4, bool CONT_IN, class EPI, int T0 = 0, int T1 = 0>
 __device__ __forceinline__ void mfma_chunk_last(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
-                                                const f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1], f32x4 (&ring)[8],
-                                                int lane, EPI& epi) {
+                                                f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1], f32x4 (&ring)[8],
+                                                int lane, EPI& epi, float* save_tile = nullptr) {
     static_assert(NT % 2 == 0 && CS == 16, "tile-pair-major last chunk: 4 step groups");
     constexpr int G = CS / 4;
+    constexpr int NQ = (NT / 2) * G;
+    if constexpr (!Spread<NQ, N_F4>::kOn) {
+        stream_issue<N_F4>(ws, stage);
+        sched_fence();
+    }
+    if constexpr (!Spread<NQ, 1>::kOn) store_tiles<T0, T1, NSTEP>(b, save_tile);
     const f32x4* A = reinterpret_cast<const f32x4*>(WStream::buf(ws.cur)) + lane;
     if constexpr (!CONT_IN) {
         ring[0] = A[(0 * G + 0) * 64];
         ring[1] = A[(1 * G + 0) * 64];
     }
-    LastChunk<NSTEP, NT, CS, B0, N_F4, CONT_IN, EPI, 0>::run(b, acc, ws, stage, ring, A, epi);
+    LastChunk<NSTEP, NT, CS, B0, N_F4, CONT_IN, EPI, 0, T0, T1>::run(b, acc, ws, stage, ring, A, epi, save_tile);
 }
 
 template <int NSTEP, int NT, int CS, int NEXT_F4, int C, class EPI = NoEpi>
@@ -416,16 +512,17 @@ struct PartLoop {
     static __device__ __forceinline__ void run(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
                                                f32x4 (&ring)[8], int lane, float* save_tile, EPI& epi) {
         f32x4 stage[N_F4 > 0 ? N_F4 : 1];
-        stream_issue<N_F4>(ws, stage);
-        sched_fence();      // the loads stay at the head of the chunk: half a chunk of MFMAs covers them
         // the B operands of this part are the previous layer's activations (forward) / this layer's
-        // output gradient (backward): the slice this chunk contracts over is stored now, so the
-        // training-mode HBM writes trickle out under the MFMAs instead of bursting at a layer end
-        if constexpr (CS >= 16) store_tiles<(C * CS) / 16, ((C + 1) * CS) / 16, NSTEP>(b, save_tile);
+        // output gradient (backward): the slice this chunk contracts over (tiles T0 .. T1) is stored by the
+        // chunk itself, so the training-mode HBM writes trickle out under the MFMAs instead of bursting at a
+        // layer end; the chunk also issues the loads and LDS writes of the chunk that follows (Spread)
+        constexpr int T0 = CS >= 16 ? (C * CS) / 16 : 0, T1 = CS >= 16 ? ((C + 1) * CS) / 16 : 0;
         if constexpr (C + 1 == NC && !std::is_same<EPI, NoEpi>::value)
-            mfma_chunk_last<NSTEP, NT, CS, C * CS, N_F4, CHAIN && (C > 0), EPI>(b, acc, ws, stage, ring, lane, epi);
+            mfma_chunk_last<NSTEP, NT, CS, C * CS, N_F4, CHAIN && (C > 0), EPI, T0, T1>(b, acc, ws, stage, ring, lane,
+                                                                                       epi, save_tile);
         else
-            mfma_chunk<NSTEP, NT, CS, C * CS, N_F4, CHAIN && (C > 0), CHAIN && (C + 1 < NC)>(b, acc, ws, stage, ring, lane);
+            mfma_chunk<NSTEP, NT, CS, C * CS, N_F4, CHAIN && (C > 0), CHAIN && (C + 1 < NC), T0, T1>(
+                b, acc, ws, stage, ring, lane, save_tile);
         ws.cur = ws.next();
         if constexpr (C + 1 < NC) PartLoop<NSTEP, NT, CS, NEXT_F4, C + 1, EPI>::run(b, acc, ws, ring, lane, save_tile, epi);
     }

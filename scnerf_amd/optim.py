@@ -2,8 +2,8 @@
 
 `FusedAdam` and `CustomAdamOptimizer` are drop-ins for torch.optim.Adam and the reference's
 CustomAdamOptimizer (/root/reference NeRF/create_nerf.py:257-335: Adam whose weight decay touches only
-the trailing ray-origin / ray-direction / distortion tensors, decided by substring tests on
-`args.camera_model`, :219-226).  Parameters that share one contiguous buffer (every scnerf_amd.NeRF
+the trailing tensors of the stepped list -- ray-origin / ray-direction / distortion noise once they are
+learnable --, their number decided by substring tests on `args.camera_model`, :219-226).  Parameters that share one contiguous buffer (every scnerf_amd.NeRF
 does: `flat_parameters()`) form one *segment* with one flat gradient buffer (the `.grad`s are views of
 it, so autograd accumulates in place and an all-reduce can run on the same memory), one pair of flat
 moment buffers and ONE kernel launch per step instead of ~8 element-wise launches per tensor.
@@ -26,34 +26,37 @@ def decayed_lr(lrate: float, lrate_decay: float, global_step: int) -> float:
 
 
 class _Segment:
-    def __init__(self, params: List[torch.nn.Parameter], decay: bool):
+    """A run of parameters that tile one contiguous fp32 range and share a step count and a decay flag:
+    one flat view of the parameters, one slice of the optimizer's gradient arena, one pair of moment buffers,
+    one kernel launch per step."""
+
+    def __init__(self, params: List[torch.nn.Parameter], decay: bool, step: int, flat_grad: torch.Tensor):
         self.params = params
         self.decay = decay
-        self.step = 0
+        self.step = step
         first = params[0]
         n = sum(p.numel() for p in params)
-        # the parameters must tile one contiguous fp32 range
         base = first.data_ptr()
         off = 0
         for p in params:
             assert p.dtype == torch.float32 and p.is_contiguous() and p.data_ptr() == base + 4 * off
             off += p.numel()
+        assert flat_grad.numel() == n
         self.n = n
         self.flat_param = torch.as_strided(first.data, (n,), (1,))      # view over the whole range
-        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=first.device)
+        self.flat_grad = flat_grad
         self.exp_avg = torch.zeros_like(self.flat_grad)
         self.exp_avg_sq = torch.zeros_like(self.flat_grad)
-        self.attach()
 
-    def attach(self):
+    def attach(self, keep_existing=False):
         o = 0
         for p in self.params:
             g = p.grad
             want = self.flat_grad.data_ptr() + 4 * o
             if g is None or g.data_ptr() != want:
                 view = self.flat_grad[o:o + p.numel()].view(p.shape)
-                if g is not None:
-                    view.copy_(g)           # a gradient produced before the optimizer existed
+                if g is not None and keep_existing:
+                    view.copy_(g)           # a gradient produced before the optimizer (re)built its buffers
                 p.grad = view
             o += p.numel()
 
@@ -74,61 +77,108 @@ def _pad16(t: torch.Tensor) -> bool:
 class FusedAdam(torch.optim.Optimizer):
     """Adam (no amsgrad) with one fused HIP launch per contiguous parameter segment.
 
-    `decay_from`: index into the parameter list from which weight decay applies (None = nowhere when
-    weight_decay == 0, everywhere otherwise ... use CustomAdamOptimizer for the reference's rule)."""
+    Weight decay: everywhere when `weight_decay != 0` (torch.optim.Adam), unless `decay_tail = k` restricts it
+    to the LAST k tensors among those that currently take part in the step (requires_grad) -- the reference's
+    CustomAdamOptimizer rule, which counts inside `params_with_grad` (create_nerf.py:216-226, :290-303): while
+    the camera's ray-noise tensors are frozen the decayed tail is therefore made of whatever tensors come last
+    among the active ones.
+
+    All gradients live in ONE arena (`flat_gradient()`): every `.grad` is a view of it, so autograd (and the
+    weight-gradient kernels) accumulate in place and a ray-parallel all-reduce is one collective on one buffer
+    (scnerf_amd.parallel.FlatGradAllReduce.for_optimizer)."""
 
     def __init__(self, params: Iterable, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 decay_from=None):
+                 decay_tail=None):
         params = list(params)
         if params and isinstance(params[0], dict):
             raise NotImplementedError("FusedAdam takes one flat parameter list (as the reference does)")
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
-        self._decay_from = (0 if weight_decay != 0 else len(params)) if decay_from is None else decay_from
+        self._decay_tail = decay_tail
         self._segments = None
-        self._loaded_steps = {}          # parameter index -> step count restored from a checkpoint
+        self._arena = None
+        self.grad_sync = None            # a parallel.FlatGradAllReduce.for_optimizer(self, ...): step() all-reduces first
+        self._loaded = {}                # id(parameter) -> (step, exp_avg, exp_avg_sq) restored from a checkpoint
         self._step_as_tensor = True      # torch.optim.Adam keeps `step` as a tensor, the reference's class an int
 
     # -- segments ---------------------------------------------------------------------------------
+    def _per_parameter_state(self):
+        """(step, exp_avg, exp_avg_sq) of every parameter that has been stepped or restored, keyed by id."""
+        out = dict(self._loaded)
+        for s in (self._segments or []):
+            if s.step == 0:
+                continue
+            o = 0
+            for p in s.params:
+                n = p.numel()
+                out[id(p)] = (s.step, s.exp_avg[o:o + n], s.exp_avg_sq[o:o + n])
+                o += n
+        return out
+
     def _build_segments(self):
         plist = self.param_groups[0]["params"]
-        segs, cur, cur_key = [], [], None
+        carried = self._per_parameter_state()
+        pending = {id(p): p.grad for p in plist if p.requires_grad and p.grad is not None}
+        active = [i for i, p in enumerate(plist) if p.requires_grad]
+        wd = self.param_groups[0]["weight_decay"]
+        if self._decay_tail is None:
+            decayed = set(active) if wd != 0 else set()
+        else:
+            decayed = set(active[len(active) - self._decay_tail:]) if self._decay_tail > 0 else set()
+        runs, cur, cur_key = [], [], None
         for i, p in enumerate(plist):
             if not p.requires_grad:
                 if cur:
-                    segs.append(_Segment(cur, cur_key[1]))
+                    runs.append((cur, cur_key))
                     cur, cur_key = [], None
                 continue
             if not _capi.on_device(p):
                 raise RuntimeError("FusedAdam needs GPU parameters (scnerf_amd has no CPU path)")
-            decay = i >= self._decay_from
             contiguous = bool(cur) and p.data_ptr() == cur[-1].data_ptr() + 4 * cur[-1].numel()
-            # tensors restored with different step counts (bias corrections differ) cannot share a launch
-            key = (p.device, decay, self._loaded_steps.get(i, 0))
+            # tensors with different step counts (bias corrections differ) cannot share a launch
+            key = (p.device, i in decayed, carried[id(p)][0] if id(p) in carried else 0)
             if cur and contiguous and cur_key == key:
                 cur.append(p)
             else:
                 if cur:
-                    segs.append(_Segment(cur, cur_key[1]))
+                    runs.append((cur, cur_key))
                 cur, cur_key = [p], key
         if cur:
-            segs.append(_Segment(cur, cur_key[1]))
-        for s in segs:
-            if not _pad16(s.flat_param):
+            runs.append((cur, cur_key))
+        # one gradient arena; every segment's slice starts on a 16-byte boundary
+        sizes = [sum(p.numel() for p in ps) for ps, _ in runs]
+        starts, total = [], 0
+        for n in sizes:
+            starts.append(total)
+            total += (n + 3) // 4 * 4
+        dev = runs[0][0][0].device if runs else torch.device("cpu")
+        self._arena = torch.zeros(total, dtype=torch.float32, device=dev)
+        segs = []
+        for (ps, key), st, n in zip(runs, starts, sizes):
+            seg = _Segment(ps, key[1], key[2], self._arena[st:st + n])
+            o = 0
+            for p in ps:                                  # moments follow their parameter through a rebuild
+                got = carried.get(id(p))
+                if got is not None:
+                    seg.exp_avg[o:o + p.numel()].copy_(got[1].reshape(-1))
+                    seg.exp_avg_sq[o:o + p.numel()].copy_(got[2].reshape(-1))
+                g = pending.get(id(p))
+                if g is not None:
+                    seg.flat_grad[o:o + p.numel()].copy_(g.reshape(-1))
+                o += p.numel()
+            seg.attach()
+            if not _pad16(seg.flat_param):
                 raise RuntimeError("parameter segment is not 16-byte aligned")
+            segs.append(seg)
         self._segments = segs
+        self._loaded = {}
         self._req = [p.requires_grad for p in plist]
 
     def segments(self):
         plist = self.param_groups[0]["params"]
         if (self._segments is None or self._req != [p.requires_grad for p in plist]
                 or not all(s.still_valid() for s in self._segments)):
-            old = {id(s.params[0]): s for s in (self._segments or [])}
             self._build_segments()
-            for s in self._segments:        # keep the moments / step of segments that did not change
-                o = old.get(id(s.params[0]))
-                if o is not None and o.n == s.n:
-                    s.exp_avg, s.exp_avg_sq, s.step = o.exp_avg, o.exp_avg_sq, o.step
         return self._segments
 
     # -- checkpoints: torch.optim's per-parameter format, so files written by the reference load here ----
@@ -137,51 +187,47 @@ class FusedAdam(torch.optim.Optimizer):
         exp_avg, exp_avg_sq}` per parameter index that has been stepped, `param_groups`): checkpoints
         are interchangeable with the reference's (run_nerf.py:626-641, create_nerf.py:142-172)."""
         self.state.clear()
-        for s in (self._segments or []):
-            if s.step == 0:
+        by_id = {id(p): p for p in self.param_groups[0]["params"]}
+        for pid, (step, m, v) in self._per_parameter_state().items():
+            p = by_id.get(pid)
+            if p is None:
                 continue
-            o = 0
-            for p in s.params:
-                n = p.numel()
-                self.state[p] = {
-                    "step": torch.tensor(float(s.step)) if self._step_as_tensor else int(s.step),
-                    "exp_avg": s.exp_avg[o:o + n].view(p.shape).clone(),
-                    "exp_avg_sq": s.exp_avg_sq[o:o + n].view(p.shape).clone()}
-                o += n
+            self.state[p] = {"step": torch.tensor(float(step)) if self._step_as_tensor else int(step),
+                             "exp_avg": m.reshape(p.shape).clone(), "exp_avg_sq": v.reshape(p.shape).clone()}
         sd = super().state_dict()
         self.state.clear()
         return sd
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)          # validates the groups, casts tensors to the parameters' device
-        plist = self.param_groups[0]["params"]
-        index = {id(p): i for i, p in enumerate(plist)}
-        loaded = {index[id(p)]: st for p, st in self.state.items() if id(p) in index and len(st)}
-        self._loaded_steps = {i: int(float(st["step"])) for i, st in loaded.items()}
-        self._segments = None
-        for s in self.segments():
-            o = 0
-            for p in s.params:
-                st = loaded.get(index[id(p)])
-                n = p.numel()
-                if st is not None:
-                    if "max_exp_avg_sq" in st:
-                        raise NotImplementedError("amsgrad state is not supported")
-                    s.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
-                    s.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
-                    s.step = int(float(st["step"]))
-                o += n
+        loaded = {}
+        for p, st in self.state.items():
+            if not len(st):
+                continue
+            if "max_exp_avg_sq" in st:
+                raise NotImplementedError("amsgrad state is not supported")
+            loaded[id(p)] = (int(float(st["step"])), st["exp_avg"].detach().float().reshape(-1),
+                             st["exp_avg_sq"].detach().float().reshape(-1))
         self.state.clear()
+        self._segments = None                        # whatever was stepped before is replaced by the file
+        self._loaded = loaded
+        self.segments()
 
     def zero_grad(self, set_to_none: bool = False):
-        """Zeroes the flat gradient buffers in place (the .grad views stay attached)."""
-        for s in self.segments():
-            s.flat_grad.zero_()
+        """Zeroes the gradient arena in place (the .grad views stay attached)."""
+        segs = self.segments()
+        self._arena.zero_()
+        for s in segs:
             s.attach()
 
     def flat_gradients(self):
-        """The flat gradient buffers (one per segment) -- what a ray-parallel all-reduce sums."""
+        """The per-segment gradient buffers (views of the arena)."""
         return [s.flat_grad for s in self.segments()]
+
+    def flat_gradient(self) -> torch.Tensor:
+        """The ONE buffer every .grad is a view of -- what a ray-parallel all-reduce sums."""
+        self.segments()
+        return self._arena
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -193,8 +239,12 @@ class FusedAdam(torch.optim.Optimizer):
         beta1, beta2 = g["betas"]
         lib = _capi.load()
         stream = _capi.current_stream()
-        for s in self.segments():
-            s.attach()
+        segs = self.segments()
+        for s in segs:
+            s.attach(keep_existing=True)
+        if self.grad_sync is not None:
+            self.grad_sync.all_reduce()          # ray-parallel ranks: one collective on the arena, then step
+        for s in segs:
             s.step += 1
             wd = g["weight_decay"] if s.decay else 0.0
             st = lib.scnerf_adam_step(s.flat_param.data_ptr(), s.flat_grad.data_ptr(), s.exp_avg.data_ptr(),
@@ -212,11 +262,10 @@ class CustomAdamOptimizer(FusedAdam):
         if amsgrad:
             raise NotImplementedError("amsgrad is not used by SCNeRF and not implemented")
         params = list(params)
-        decay_from = len(params)
+        tail = 0
         if args.camera_model != "none":
-            decay_from -= "rayo" in args.camera_model
-            decay_from -= "rayd" in args.camera_model
-            decay_from -= "dist" in args.camera_model
-        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decay_from=decay_from)
+            tail = ("rayo" in args.camera_model) + ("rayd" in args.camera_model) + ("dist" in args.camera_model)
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                         decay_tail=tail if weight_decay != 0 else 0)
         self.args, self.H, self.W = args, H, W
         self._step_as_tensor = False

@@ -15,8 +15,19 @@ import torch
 
 
 class FlatGradAllReduce:
-    """Owns one flat gradient buffer; every parameter's .grad is a view of it, so autograd
-    accumulates straight into the buffer the collective runs on."""
+    """One flat fp32 gradient buffer and one all-reduce per step.
+
+    Two ways to get the buffer (it must have ONE owner, or a later zero_grad() re-points the .grad views and
+    the collective would run on stale memory):
+      * `FlatGradAllReduce(modules, world)` allocates it and attaches every parameter's .grad as a view
+        (no optimizer involved: bench.py, tests);
+      * `FlatGradAllReduce.for_optimizer(optimizer, world)` borrows the gradient arena of a
+        scnerf_amd.optim.FusedAdam / CustomAdamOptimizer -- the optimizer stays the owner, `zero()` is its
+        zero_grad().  `optimizer.grad_sync = reducer` makes `optimizer.step()` run the collective first, so
+        a training loop written for DistributedDataParallel (zero_grad / backward / step) needs no change.
+
+    `all_reduce(local_rays, total_rays)`: each rank's gradient is that of the MEAN loss over its own rays; the
+    global-batch mean weights rank r by n_r / N.  Without counts every rank weighs 1 / world (equal shards)."""
 
     def __init__(self, modules: Iterable[torch.nn.Module], world_size: int, process_group=None):
         self.params: List[torch.nn.Parameter] = []
@@ -28,35 +39,52 @@ class FlatGradAllReduce:
                     self.params.append(p)
         self.world_size = int(world_size)
         self.group = process_group
+        self.optimizer = None
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._own = torch.zeros(n, dtype=torch.float32, device=dev)
         self.attach()
 
+    @classmethod
+    def for_optimizer(cls, optimizer, world_size: int, process_group=None):
+        self = cls.__new__(cls)
+        self.params, self._own = None, None
+        self.world_size, self.group, self.optimizer = int(world_size), process_group, optimizer
+        optimizer.flat_gradient()                      # builds the arena and attaches the views
+        return self
+
+    @property
+    def flat(self) -> torch.Tensor:
+        return self._own if self.optimizer is None else self.optimizer.flat_gradient()
+
     def attach(self):
+        if self.optimizer is not None:
+            return self.optimizer.flat_gradient()
         o = 0
         for p in self.params:
-            p.grad = self.flat[o:o + p.numel()].view(p.shape)
+            p.grad = self._own[o:o + p.numel()].view(p.shape)
             o += p.numel()
 
     def zero(self):
-        self.flat.zero_()
+        if self.optimizer is not None:
+            return self.optimizer.zero_grad()
+        self._own.zero_()
         # autograd may have replaced a .grad (e.g. after set_to_none): re-point cheaply
         o = 0
         for p in self.params:
             g = p.grad
-            if g is None or g.data_ptr() != self.flat.data_ptr() + 4 * o:
-                p.grad = self.flat[o:o + p.numel()].view(p.shape)
+            if g is None or g.data_ptr() != self._own.data_ptr() + 4 * o:
+                p.grad = self._own[o:o + p.numel()].view(p.shape)
             o += p.numel()
 
-    def all_reduce(self):
-        """sum over ranks, then / world_size (== the gradient of the mean loss over the global batch
-        when every rank renders the same number of rays)."""
+    def all_reduce(self, local_rays=None, total_rays=None):
+        flat = self.flat
         if self.world_size > 1:
             import torch.distributed as dist
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.mul_(1.0 / self.world_size)
-        return self.flat
+            weight = 1.0 / self.world_size if local_rays is None else float(local_rays) / float(total_rays)
+            flat.mul_(weight)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        return flat
 
 
 def shard_rays(n_total: int, rank: int, world_size: int):
@@ -85,6 +113,12 @@ def render_path_sharded(render_poses, hwf, chunk, render_kwargs, mode, rank: int
     lo, hi = shard_rays(n_pix, rank, world_size)
     width = -(-n_pix // world_size)                      # padded shard length
     rgbs, disps = [], []
+    ring = None                                           # pinned staging + copy stream (GPU tensors only)
+
+    def collect(img):
+        rgbs.append(img[:, :3].reshape(H, W, 3).copy())
+        disps.append(img[:, 3].reshape(H, W).copy())
+
     for i, _pose in enumerate(render_poses):
         kw = _image_kwargs(i, hwf, chunk, render_kwargs, mode, path_kwargs.get("camera_model"),
                            path_kwargs.get("noisy_extrinsic"), path_kwargs.get("gt_intrinsic"),
@@ -106,7 +140,17 @@ def render_path_sharded(render_poses, hwf, chunk, render_kwargs, mode, rank: int
             img = torch.cat(parts, 0)
         else:
             img = mine[:n_pix]
-        img = img.cpu().numpy()
-        rgbs.append(img[:, :3].reshape(H, W, 3).copy())
-        disps.append(img[:, 3].reshape(H, W).copy())
+        if img.is_cuda:
+            # as the single-GPU render_path: image i leaves through a pinned buffer on a side stream while
+            # image i+1 renders; the host only waits when it needs the pixels
+            from .render import _HostRing
+            if ring is None:
+                ring = _HostRing(img.device)
+            ring.push(img)
+            if i > 0:
+                collect(ring.get(i - 1)[0])
+        else:
+            collect(img.numpy())
+    if ring is not None and ring.pending:
+        collect(ring.get(len(ring.pending) - 1)[0])
     return np.stack(rgbs, 0), np.stack(disps, 0)

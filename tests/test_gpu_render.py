@@ -8,11 +8,34 @@ import numpy as np
 import pytest
 import torch
 
+import json
+import os
+
 from oracle import scnerf_oracle as O
 from scnerf_amd import synthetic as synth
 from conftest import t
+from tests import parity_attribution as PA
 
 pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = {}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def parity_report():
+    """Everything the parity tests measured goes to one JSON: gpurun_out/ (travels back from the GPU box; the
+    copy committed as profiles/parity_r02.json is this file) and profiles/ in the tree the tests ran in."""
+    yield
+    if not REPORT:
+        return
+    for d in ("gpurun_out", "profiles"):
+        try:
+            os.makedirs(os.path.join(ROOT, d), exist_ok=True)
+            with open(os.path.join(ROOT, d, "parity_r02.json"), "w") as f:
+                json.dump(REPORT, f, indent=1, sort_keys=True)
+        except OSError:
+            pass
 
 CASES = ["c64_f0_det", "c64_f0_pert", "c64_f128_pert", "c64_f128_det", "c64_f64_lindisp"]
 
@@ -93,11 +116,29 @@ def test_render_rays_vs_reference_golden(R, golden, tag):
         np.testing.assert_allclose(ret[name].detach().cpu().numpy(), g[k + name], rtol=0, atol=tol, err_msg=name)
     for name in (["disp0"] if sf > 0 else ["disp_map"]):
         np.testing.assert_allclose(ret[name].detach().cpu().numpy(), g[k + name], rtol=1e-4, atol=1e-4, err_msg=name)
+    clean = np.ones(n, bool)
     if sf > 0:
-        for name in ("rgb_map", "acc_map"):
-            frac, worst = rays_within(ret[name], g[k + name], 1e-4)
-            assert frac >= 0.9 and worst < 1e-2, (name, frac, worst)
-        np.testing.assert_allclose(ret["z_std"].cpu().numpy(), g[k + "z_std"], rtol=1e-3, atol=1e-5)
+        # every ray beyond the bar owns a sample the reference algorithm itself places discontinuously
+        # (tests/parity_attribution.py): compared on the cdf / search indices both sides expose
+        from scnerf_amd.functional import host_linspace
+        u_dev = rnd["u"] if perturb > 0 else host_linspace(sf, "cuda").expand(n, sf).contiguous()
+        st = PA.gpu_sampling_state(R["ops"], host_linspace, rays.detach(), net_c, rnd.get("t_rand"), u_dev,
+                                   rnd.get("noise_c"), sc, bool(lindisp), bool(wb))
+        same = torch.equal(torch.where(st["rgb0"] >= 1.0, torch.ones_like(st["rgb0"]), st["rgb0"]), ret["rgb0"].detach())
+        z_c = st["z_c"].cpu()
+        cls = PA.classify(u_dev.cpu(), 0.5 * (z_c[:, 1:] + z_c[:, :-1]), st["cdf"].cpu(), st["inds"].cpu(),
+                          g[k + "cdf"], g[k + "inds"])
+        clean = ~(cls["index"] | cls["branch"] | cls["illcond"])
+        rep = {}
+        for name, rel in (("rgb_map", False), ("acc_map", False), ("disp_map", True)):
+            err = PA.per_ray_error(ret[name], g[k + name], relative=rel)
+            rep[name] = PA.summary(err, cls)
+            assert rep[name]["over_bar_unexplained"] == 0, (name, rep[name])
+            assert rep[name]["max"] < 1e-2, (name, rep[name])
+        rep["coarse_rerun_bit_identical"] = bool(same)      # the re-run IS the coarse stage inside render_rays
+        REPORT["golden/" + tag] = rep
+        zs = np.abs(ret["z_std"].cpu().numpy() - g[k + "z_std"])
+        assert zs[clean].max(initial=0.0) <= 1e-5 + 1e-3 * np.abs(g[k + "z_std"]).max()
     else:
         np.testing.assert_allclose(ret["raw"].detach().cpu().numpy(), g[k + "raw"], rtol=0, atol=1e-4)
     target = t(g[k + "target"]).cuda()
@@ -109,7 +150,12 @@ def test_render_rays_vs_reference_golden(R, golden, tag):
     cols = [0, 1, 2, 3, 4, 5, 8, 9, 10]
     tq = 2e-3 if sf > 0 else 1e-3
     ge = np.abs(rays.grad[:, cols].cpu().numpy() - g[k + "g_rays"][:, cols]).max(1) / np.abs(g[k + "g_rays"]).max()
-    assert (ge < tq).mean() >= 0.9 and ge.max() < 0.1, ("d ray_batch", float((ge < tq).mean()), float(ge.max()))
+    # rays whose samples sit where the reference places them: the ray gradient holds to 1e-3 of the largest entry
+    # but for single ReLU-flip rays (<= 10 %); rays with a moved sample are only bounded
+    REPORT.setdefault("golden/" + tag, {})["d_ray_batch"] = dict(
+        clean_rays=int(clean.sum()), clean_within_1e3=float((ge[clean] < 1e-3).mean()), clean_max=float(ge[clean].max()),
+        all_max=float(ge.max()))
+    assert (ge[clean] < 1e-3).mean() >= 0.9 and ge.max() < 0.1, ("d ray_batch", float((ge[clean] < 1e-3).mean()), float(ge.max()))
     assert float(rays.grad[:, 6:8].abs().max()) == 0.0
     nets = {"coarse": net_c, "fine": net_f}
     for key in g:
@@ -211,39 +257,72 @@ def test_run_network_matches_oracle_with_grads(R):
 
 
 def test_headline_size_against_oracle(R):
-    """4096 rays x (64 + 128): the BASELINE.json configuration, against the CPU oracle on the same
-    seeded inputs.  Reports the error distribution; asserts the 1e-4 bar at the 99.9th percentile
-    and the oracle's own fp32 noise floor (its fp32-vs-fp64 spread) as the yardstick for the max."""
+    """4096 rays x (64 + 128): the BASELINE.json configuration, against the CPU oracle on the same seeded inputs.
+
+    Coarse outputs: every ray within 1e-4.  Fine outputs (rgb, acc absolute; disparity relative): every ray whose
+    128 new samples sit where the oracle puts them is within 1e-4; each ray beyond the bar owns a sample the
+    reference algorithm places discontinuously (search index or `denom < 1e-5` branch differs between the two
+    fp32 sides, tests/parity_attribution.py) -- and re-rendering exactly those rays' fine stage on the GPU from the
+    ORACLE's merged depths brings every one of them within 1e-4.  The distribution goes to profiles/parity_r02.json."""
+    from scnerf_amd.functional import host_linspace
     n, sc, sf = 4096, 64, 128
     net_c, net_f = make_net(R, 0), make_net(R, 1)
     pc, pf = synth.network_params(seed=0), synth.network_params(seed=1)
     rays = synth.ray_batch(n, seed=1)
     rnd = synth.render_randoms(n, sc, sf, seed=3)
+    rnd_d = {k: v.cuda() for k, v in rnd.items()}
     ret = R["render"].render_rays(rays.cuda(), net_c, make_query(R), sc, retraw=True, perturb=1.0,
-                                  N_importance=sf, network_fine=net_f, raw_noise_std=1.0,
-                                  _randoms={k: v.cuda() for k, v in rnd.items()})
+                                  N_importance=sf, network_fine=net_f, raw_noise_std=1.0, _randoms=rnd_d)
     torch.set_num_threads(max(1, min(64, torch.get_num_threads())))
     with torch.no_grad():
         o32 = O.render_rays(rays, pc, pf, sc, sf, rnd["t_rand"], rnd["u"], rnd["noise_c"], rnd["noise_f"], rowsum="aten")
         dd = lambda d_: {k: v.double() for k, v in d_.items()}
         o64 = O.render_rays(rays.double(), dd(pc), dd(pf), sc, sf, rnd["t_rand"].double(), rnd["u"].double(),
                             rnd["noise_c"].double(), rnd["noise_f"].double())
-    report = {}
-    for name in ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0"):
-        got = ret[name].cpu().double()
-        e_ref = (got - o32[name].double()).abs().flatten()
-        e_truth = (got - o64[name]).abs().flatten()
-        floor = (o32[name].double() - o64[name]).abs().flatten()
-        report[name] = dict(vs_oracle32_p999=float(e_ref.kthvalue(int(0.999 * e_ref.numel()))[0]),
-                            vs_oracle32_max=float(e_ref.max()), vs_fp64_max=float(e_truth.max()),
-                            oracle32_vs_fp64_max=float(floor.max()))
-    print("\nheadline parity report:", report)
-    for name in ("rgb_map", "rgb0", "acc_map"):
-        assert report[name]["vs_oracle32_p999"] <= 1e-4, (name, report[name])
-        assert report[name]["vs_fp64_max"] <= max(1e-4, 3 * report[name]["oracle32_vs_fp64_max"]), (name, report[name])
-    # fine-sample indices: bit-exact whenever the two sides see the same cdf; count rows that differ
-    z_same = float((ret["z_std"].cpu() - o32["z_std"]).abs().max())
-    assert z_same < 1e-3
+    st = PA.gpu_sampling_state(R["ops"], host_linspace, rays.cuda(), net_c, rnd_d["t_rand"], rnd_d["u"], rnd_d["noise_c"], sc)
+    np.testing.assert_array_equal(st["z_c"].cpu().numpy(), o32["z_coarse"].numpy())          # stratified depths: bit-exact
+    z_c = o32["z_coarse"]
+    cls = PA.classify(rnd["u"], 0.5 * (z_c[:, 1:] + z_c[:, :-1]), st["cdf"].cpu(), st["inds"].cpu(), o32["cdf"], o32["inds"])
+    moved = cls["index"] | cls["branch"] | cls["illcond"]
+    report = {"rays_with_a_discontinuously_placed_sample": int(moved.sum()),
+              "rays_index": int(cls["index"].sum()), "rays_branch": int(cls["branch"].sum()),
+              "rays_illcond": int(cls["illcond"].sum()),
+              "coarse_rerun_bit_identical": bool(torch.equal(st["rgb0"], ret["rgb0"])),
+              "sample_indices_equal_fraction": float((st["inds"].cpu() == o32["inds"]).float().mean())}
+    for name in ("rgb0", "acc0"):                                                        # coarse: strict
+        err = PA.per_ray_error(ret[name], o32[name])
+        report[name] = PA.summary(err, cls)
+        assert err.max() <= 1e-4, (name, report[name])
+    err = PA.per_ray_error(ret["disp0"], o32["disp0"], relative=True)
+    report["disp0"] = PA.summary(err, cls)
+    assert err.max() <= 1e-4, ("disp0", report["disp0"])
+    for name, rel in (("rgb_map", False), ("acc_map", False), ("disp_map", True)):        # fine: attributed
+        err = PA.per_ray_error(ret[name], o32[name], relative=rel)
+        rep = PA.summary(err, cls)
+        rep["vs_fp64_max"] = float(PA.per_ray_error(ret[name], o64[name], relative=rel).max())
+        rep["oracle32_vs_fp64_max"] = float(PA.per_ray_error(o32[name], o64[name], relative=rel).max())
+        report[name] = rep
+        assert rep["over_bar_unexplained"] == 0 and rep["max_among_clean_rays"] <= 1e-4, (name, rep)
+        assert rep["over_bar"] <= 0.005 * n, (name, rep)                  # a handful of rays, not a tail
+        assert rep["vs_fp64_max"] <= max(1e-4, 3 * rep["oracle32_vs_fp64_max"]), (name, rep)   # no further from fp64 than fp32 is
+    # the flagged rays, fine stage re-rendered on the GPU from the oracle's merged depths: within the bar, all of them
+    idx = torch.from_numpy(np.nonzero(moved)[0])
+    if idx.numel():
+        sub = rays[idx].cuda().contiguous()
+        z_f = o32["z_fine"][idx].cuda().contiguous()
+        pts = (sub[:, None, 0:3] + sub[:, None, 3:6] * z_f[:, :, None]).contiguous()
+        with torch.no_grad():
+            raw = make_query(R)(pts, sub[:, 8:11].contiguous(), net_f)
+            rgb, disp, acc, _, _ = R["render"].raw2outputs(raw, z_f, sub[:, 3:6], _noise=rnd["noise_f"][idx].cuda())
+        redo = {}
+        for name, got, rel in (("rgb_map", rgb, False), ("acc_map", acc, False), ("disp_map", disp, True)):
+            e = PA.per_ray_error(got, o32[name][idx], relative=rel)
+            redo[name] = float(e.max())
+            assert e.max() <= 1e-4, ("re-rendered from the oracle's samples", name, float(e.max()))
+        report["flagged_rays_rerendered_from_oracle_samples_max"] = redo
+    assert float((ret["z_std"].cpu() - o32["z_std"]).abs()[~torch.from_numpy(moved)].max()) < 1e-5
+    REPORT["headline_4096x(64+128)"] = report
+    print("\nheadline parity report:", json.dumps(report))
 
 
 def test_weight_gradients_accumulate_into_attached_flat_buffers(R):

@@ -107,3 +107,32 @@ def test_render_path_sharded_two_ranks(tmp_path):
         for i in range(3):
             np.testing.assert_array_equal(rgbs[i].reshape(-1, 3), np.stack([pix, pix * 0.5 + i, -pix], -1))
             np.testing.assert_array_equal(disps[i].reshape(-1), pix + 100.0 * i)
+
+
+def _check_ray_parallel(tmp_path, world):
+    f = [np.load(tmp_path / ("flat%d.npy" % r)) for r in range(world)]
+    for r in range(1, world):
+        np.testing.assert_array_equal(f[0], f[r])                       # every rank holds the same reduced buffer
+    full = np.load(tmp_path / "full.npy")
+    assert full.shape == f[0].shape and np.isfinite(full).all()
+    scale = np.abs(full).max()
+    # networks (2 x 595 844) and camera block: fp32 sums over a different partition of the samples
+    assert np.abs(f[0] - full).max() <= 5e-6 * scale, (np.abs(f[0] - full).max(), scale)
+    cam = slice(2 * 595844, None)
+    assert np.abs(full[cam]).max() > 0                                   # camera gradients are in the collective
+    assert np.abs(f[0][cam] - full[cam]).max() <= 5e-6 * np.abs(full[cam]).max() + 1e-9
+
+
+@pytest.mark.parametrize("with_optimizer", [False, True])
+def test_ray_parallel_nerf_and_camera_gradients_two_ranks(tmp_path, with_optimizer):
+    """Two gloo ranks, each rendering its UNEQUAL shard (4 + 3 rays) of one global batch through the real host
+    layer (camera rays -> render -> loss -> backward with the weight gradients accumulated straight into the
+    attached flat buffer) with the kernels on the SIMT interpreter: the weighted all-reduce of the flat buffer
+    (NeRF coarse + fine + camera parameters) equals the full-batch gradient of one process; with the buffer owned
+    by FusedAdam (for_optimizer) the parameters of the two ranks stay identical after the step."""
+    from tests.parallel_nerf_worker import worker
+    world = 2
+    mp.spawn(worker, args=(world, _free_port(), str(tmp_path), "cpu", 7, 8, 8, True, with_optimizer), nprocs=world, join=True)
+    _check_ray_parallel(tmp_path, world)
+    if with_optimizer:
+        np.testing.assert_array_equal(np.load(tmp_path / "param0.npy"), np.load(tmp_path / "param1.npy"))

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Timing experiments: builds variants of libscnerf_hip.so with -DSCN_<flag> defines into scnerf_amd/_ablate/
-# (git-ignored) ; run each on the GPU box with  SCNERF_HIP_LIB=scnerf_amd/_ablate/lib_<tag>.so python tools/microbench.py
+# Timing experiments: builds variants of libscnerf_hip.so with -DSCN_<flag> defines into tools/ubench/
+# (*.so is git-ignored but travels to the GPU box); run each there with
+#   SCNERF_HIP_LIB=tools/ubench/lib_<tag>.so python tools/microbench.py
 #   tools/ablate.sh TAG "-DSCN_X=1 -DSCN_Y=2" [TAG2 "..."] ...
 set -e
 cd "$(dirname "$0")/.."
-mkdir -p scnerf_amd/_ablate
 while [ $# -gt 1 ]; do
   tag=$1; defs=$2; shift 2
   objs=""
@@ -15,6 +15,6 @@ while [ $# -gt 1 ]; do
     objs="$objs $o"
   done
   wait
-  hipcc --offload-arch=gfx950 -shared -fPIC -o scnerf_amd/_ablate/lib_${tag}.so $objs
-  echo "built scnerf_amd/_ablate/lib_${tag}.so"
+  hipcc --offload-arch=gfx950 -shared -fPIC -o tools/ubench/lib_${tag}.so $objs
+  echo "built tools/ubench/lib_${tag}.so"
 done
