@@ -4,9 +4,14 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--rays 4096] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU; every rank renders its own 4096 synthetic rays (weak scaling) and the flat
-fp32 gradients of both networks are summed with ONE RCCL all-reduce per step.  Rank 0 prints one
-JSON line.  `roofline` is measured live with HIP events around the dominant kernel's launches on
+One process per GPU; every rank renders its own 4096 synthetic rays (weak scaling).  At N = 1 the step is
+BASELINE.json's configs[1] exactly (precomputed rays of a fixed camera).  At N > 1 (or with --camera) the rays
+of each step come from the learnable camera model (get_rays_kps_use_camera + NDC through the model: the ray
+source of configs[2..3]) and ONE RCCL all-reduce per step sums the flat fp32 gradient buffer that holds both
+networks AND the camera parameters -- the north star's collective; the extra work per step is two small
+kernels, so per-N values stay comparable (N = 1 with the camera is reported under extras).  Rank 0 prints one
+JSON line; at N = 1 `extras` adds short timings of the other configurations (camera curriculum states, PRD
+loss, full-image inference, NeRF++).  `roofline` is measured live with HIP events around the dominant kernel's launches on
 the stream they run on; `cpu_baseline` times the CPU oracle (a torch-CPU restatement of the
 reference path, kind "port") on a bounded sample of the same workload on the box's host cores.
 """
@@ -26,7 +31,7 @@ S_C, S_F = 64, 128
 PEAK_F32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
 
-def cpu_baseline(n_rays, iters=2):
+def cpu_baseline(n_rays, iters=3):
     """The CPU oracle (torch-CPU restatement of the reference render_rays, kind "port") on the host
     cores of this box, forward + backward, on a bounded sample of the headline workload.  The
     intra-op thread count is chosen by a short probe (on many-core hosts torch's CPU kernels are
@@ -72,11 +77,154 @@ def cpu_baseline(n_rays, iters=2):
         step()
         ts.append(time.perf_counter() - t0)
     best = min(ts)
+    ratio = ""
+    pinned = os.path.join(ROOT, "profiles", "cpu_baseline_r02.json")
+    if os.path.isfile(pinned):             # port vs the unmodified reference, timed side by side in the build container
+        rec = json.load(open(pinned))
+        ratio = "; port/reference time ratio pinned in profiles/cpu_baseline_r02.json (%d threads): %s" % (
+            rec["threads"], ", ".join("%.2f at %s rays" % (v["port_over_reference_time"], k)
+                                      for k, v in sorted(rec["sizes"].items(), key=lambda kv: int(kv[0]))))
     return {"value": n_rays / best, "unit": "rays/s", "cores": best_thr, "kind": "port",
             "sample": "%d rays x (64+128) samples, fwd+bwd, best of %d after 1 warm-up; oracle/scnerf_oracle.py "
-                      "(torch-CPU fp32, anomaly detection off), %d intra-op threads chosen by probe on a %d-thread host"
-                      % (n_rays, iters, best_thr, ncpu),
+                      "(torch-CPU fp32, anomaly detection off), %d intra-op threads chosen by probe on a %d-thread host%s"
+                      % (n_rays, iters, best_thr, ncpu, ratio),
             "ms_per_step_sample": best * 1e3}
+
+
+IMG_H, IMG_W, N_CAMS = 378, 504, 17      # LLFF 'fern' at factor 8: the image size / view count of configs[1..3]
+
+
+def _kernel_table(kern, steps):
+    return {k: {"avg_ms": v["avg_ms"], "launches_per_step": v["launches"] / steps,
+                "tflops": v["flop_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12 if v["flop_per_launch"] else None}
+            for k, v in kern.items()}
+
+
+def _timed(step, steps, warmup, sync, profile=True):
+    """-> (ms per step, per-kernel table) of `steps` calls after `warmup` untimed ones"""
+    from scnerf_amd import ops
+    for _ in range(warmup):
+        step()
+    sync()
+    ops.PROFILE.reset(enabled=profile)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    ops.PROFILE.enabled = False
+    return dt / steps * 1e3, (_kernel_table(ops.PROFILE.summary(), steps) if profile else None)
+
+
+def build_world(dev, rank, n):
+    """networks, query object, camera model, per-rank synthetic data"""
+    from scnerf_amd import synthetic as synth
+    from scnerf_amd.create_nerf import FusedNetworkQuery
+    from scnerf_amd.run_nerf_helpers import NeRF, get_embedder
+
+    def make(seed):
+        net = NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+        net.load_state_dict(synth.network_params(seed=seed))
+        net = net.to(dev)
+        net.flat_parameters()
+        return net
+    cam, _ = synth.camera_model(IMG_H, IMG_W, n_cams=N_CAMS, seed=4)
+    g = torch.Generator().manual_seed(100 + rank)
+    kps = torch.stack([torch.randint(0, IMG_W, (n,), generator=g), torch.randint(0, IMG_H, (n,), generator=g)], -1)
+    idx = torch.randint(0, N_CAMS, (n,), generator=g)
+    return dict(net_c=make(0), net_f=make(1), cam=cam.to(dev),
+                query=FusedNetworkQuery(get_embedder(10, 0)[0], get_embedder(4, 0)[0]),
+                rays=synth.ray_batch(n, seed=1 + rank).to(dev), target=synth.target_rgb(n, seed=2 + rank).to(dev),
+                kps=kps.to(dev), idx=idx.to(dev), n=n)
+
+
+def fixed_camera_step(w, reducer):
+    """configs[1]: precomputed rays of a fixed camera -> render_rays fwd + bwd (+ the all-reduce)"""
+    from scnerf_amd.render import render_rays
+    inv = 1.0 / (3 * w["n"])
+
+    def step():
+        reducer.zero()
+        ret = render_rays(w["rays"], w["net_c"], w["query"], S_C, retraw=True, perturb=1.0, N_importance=S_F,
+                          network_fine=w["net_f"], raw_noise_std=1.0)
+        # loss = mse(rgb_map, target) + mse(rgb0, target): its gradient is fed to backward directly
+        g1 = (ret["rgb_map"].detach() - w["target"]) * (2 * inv)
+        g0 = (ret["rgb0"].detach() - w["target"]) * (2 * inv)
+        torch.autograd.backward([ret["rgb_map"], ret["rgb0"]], [g1, g0])
+        reducer.all_reduce()
+    return step
+
+
+def learnable_camera_step(w, reducer):
+    """configs[2..3] ray source: key-point rays through the learnable camera model, NDC through its intrinsics,
+    render fwd + bwd down to the camera parameters (+ the all-reduce over networks AND camera)"""
+    from scnerf_amd.get_rays import get_rays_kps_use_camera
+    from scnerf_amd.render import render
+    inv = 1.0 / (3 * w["n"])
+    kw = dict(network_fn=w["net_c"], network_fine=w["net_f"], network_query_fn=w["query"], N_samples=S_C,
+              N_importance=S_F, perturb=1.0, raw_noise_std=1.0, use_viewdirs=True, white_bkgd=False, near=0., far=1.)
+
+    def step():
+        reducer.zero()
+        rays_o, rays_d = get_rays_kps_use_camera(H=IMG_H, W=IMG_W, camera_model=w["cam"],
+                                                 idx_in_camera_param=w["idx"], kps_list=w["kps"])
+        rgb, _, _, extras = render(H=IMG_H, W=IMG_W, chunk=1 << 15, rays=torch.stack([rays_o, rays_d]), retraw=True,
+                                   camera_model=w["cam"], mode="train", **kw)
+        g1 = (rgb.detach() - w["target"]) * (2 * inv)
+        g0 = (extras["rgb0"].detach() - w["target"]) * (2 * inv)
+        torch.autograd.backward([rgb, extras["rgb0"]], [g1, g0])
+        reducer.all_reduce()
+    return step
+
+
+def extras_single_gpu(w, dev, sync):
+    """Short timings of the configurations that are not the headline: each a few steps."""
+    from scnerf_amd import synthetic as synth
+    from scnerf_amd.get_rays import get_rays_kps_use_camera
+    from scnerf_amd.parallel import FlatGradAllReduce
+    from scnerf_amd.ray_dist_loss import proj_ray_dist_loss_single
+    import types
+    out = {}
+    cam = w["cam"]
+    groups = {"ie": (cam.intrinsics_noise, cam.extrinsics_noise), "od": (cam.ray_o_noise, cam.ray_d_noise)}
+    states = {}
+    for name, on in (("none", ()), ("ie", ("ie",)), ("ie+od", ("ie", "od"))):
+        for gname, tensors in groups.items():
+            for t_ in tensors:
+                t_.requires_grad_(gname in on)
+                t_.grad = None
+        red = FlatGradAllReduce([w["net_c"], w["net_f"], cam], 1)
+        ms, kern = _timed(learnable_camera_step(w, red), 5, 2, sync)
+        states[name] = {"ms_per_step": ms, "rays_per_s": w["n"] / (ms * 1e-3), "flat_gradient_floats": int(red.flat.numel()),
+                        "kernels": kern}
+    out["config2_camera_curriculum"] = {"workload": "configs[2]: %d rays x (64+128), rays from the learnable camera model "
+                                        "(%d views, %dx%d), fwd+bwd incl. camera gradients" % (w["n"], N_CAMS, IMG_H, IMG_W),
+                                        "states": states}
+    # configs[3]: the projected-ray-distance term of one image pair, forward + backward into the camera parameters
+    E = cam.get_extrinsic().detach().cpu()
+    K = cam.get_intrinsic().detach().cpu()
+    k0, k1 = synth.matched_keypoints(IMG_H, IMG_W, K, E[0], E[1], 1024, seed=8)
+    k0, k1 = k0.to(dev), k1.to(dev)
+    args = types.SimpleNamespace(proj_ray_dist_threshold=5.0)
+    i_map = torch.arange(N_CAMS).numpy()
+
+    def prd_step():
+        for p in cam.parameters():
+            p.grad = None
+        r0 = get_rays_kps_use_camera(H=IMG_H, W=IMG_W, camera_model=cam, idx_in_camera_param=0, kps_list=k0)
+        r1 = get_rays_kps_use_camera(H=IMG_H, W=IMG_W, camera_model=cam, idx_in_camera_param=1, kps_list=k1)
+        loss, _ = proj_ray_dist_loss_single(kps0_list=k0, kps1_list=k1, img_idx0=0, img_idx1=1, rays0=r0, rays1=r1,
+                                            mode="train", device=dev, H=IMG_H, W=IMG_W, args=args, camera_model=cam,
+                                            method="NeRF", i_map=i_map)
+        loss.backward()
+    ms, _ = _timed(prd_step, 20, 3, sync, profile=False)
+    out["config3_prd_term"] = {"workload": "projected-ray-distance loss of one image pair, 1024 matches: 2 x camera rays + "
+                               "loss fwd + bwd into the camera parameters (incl. the .item() the API returns)",
+                               "ms_per_call": ms}
+    from tools import bench_infer, bench_nerfpp
+    out["full_image_inference"] = bench_infer.run(images=3)
+    out["config5_nerfpp"] = bench_nerfpp.run(rays=2048, steps=5, warmup=2)
+    return out
 
 
 def main():
@@ -86,11 +234,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=512)
+    ap.add_argument("--camera", action="store_true", help="rays from the learnable camera model also at N = 1")
+    ap.add_argument("--backend", default=os.environ.get("SCNERF_BENCH_BACKEND", "nccl"),
+                    help="torch.distributed backend (nccl = RCCL; gloo for a functional check of N ranks on one GPU)")
+    ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0 (functional check, with --backend gloo)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if a.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world))
@@ -100,38 +253,23 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
-    from scnerf_amd import ops, synthetic as synth
-    from scnerf_amd.create_nerf import FusedNetworkQuery
+    from scnerf_amd import ops
     from scnerf_amd.parallel import FlatGradAllReduce
-    from scnerf_amd.render import render_rays
-    from scnerf_amd.run_nerf_helpers import NeRF, get_embedder
     ops.check_layout()
-
-    def make(seed):
-        net = NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
-        net.load_state_dict(synth.network_params(seed=seed))
-        return net.to(dev)
-
-    net_c, net_f = make(0), make(1)
-    query = FusedNetworkQuery(get_embedder(10, 0)[0], get_embedder(4, 0)[0])
     n = a.rays
-    rays = synth.ray_batch(n, seed=1 + rank).to(dev)
-    target = synth.target_rgb(n, seed=2 + rank).to(dev)
-    net_c.flat_parameters(), net_f.flat_parameters()
-    reducer = FlatGradAllReduce([net_c, net_f], world)
-    inv = 1.0 / (3 * n)
-
-    def step():
-        reducer.zero()
-        ret = render_rays(rays, net_c, query, S_C, retraw=True, perturb=1.0, N_importance=S_F,
-                          network_fine=net_f, raw_noise_std=1.0)
-        # loss = mse(rgb_map, target) + mse(rgb0, target): its gradient is fed to backward directly
-        g1 = (ret["rgb_map"].detach() - target) * (2 * inv)
-        g0 = (ret["rgb0"].detach() - target) * (2 * inv)
-        torch.autograd.backward([ret["rgb_map"], ret["rgb0"]], [g1, g0])
-        reducer.all_reduce()
+    w = build_world(dev, rank, n)
+    with_camera = a.camera or world > 1
+    if with_camera:
+        reducer = FlatGradAllReduce([w["net_c"], w["net_f"], w["cam"]], world)
+        step = learnable_camera_step(w, reducer)
+    else:
+        reducer = FlatGradAllReduce([w["net_c"], w["net_f"]], world)
+        step = fixed_camera_step(w, reducer)
 
     def sync():
         if world > 1:
@@ -169,22 +307,29 @@ def main():
                     "flop_per_launch": k["flop_per_launch"]}
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.isfile(pmc):
-                roof["traffic"] = json.load(open(pmc)).get(dom)
+                rec = json.load(open(pmc))
+                roof["traffic"] = rec.get(dom)
+                roof["traffic_source"] = rec.get("_source", "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command)")
+        source = ("rays from the learnable camera model (%d views, %dx%d; configs[2..3] ray source), camera parameters "
+                  "in the all-reduced flat buffer" % (N_CAMS, IMG_H, IMG_W)) if with_camera else \
+            "precomputed rays of a fixed camera"
         out = {
             "metric": "rays/sec (64+128 samples/ray) train-step", "value": n * world / (ms * 1e-3),
             "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "configs[1]: %d rays x (64 coarse + 128 fine), coarse+fine NeRF (D=8, W=256), "
-                                   "fwd+bwd of render_rays per GPU, perturb=1, raw_noise_std=1" % n,
-                       "rays_per_gpu": n, "parallelism": "ray-parallel x%d, 1 RCCL all-reduce/step" % world},
+                                   "fwd+bwd of render_rays per GPU, perturb=1, raw_noise_std=1; %s" % (n, source),
+                       "rays_per_gpu": n,
+                       "parallelism": "ray-parallel x%d, 1 %s all-reduce/step of %d floats" % (
+                           world, "RCCL" if a.backend == "nccl" else a.backend, int(reducer.flat.numel()))},
             "roofline": roof,
-            "kernels": {k: {"avg_ms": v["avg_ms"], "launches_per_step": v["launches"] / a.steps,
-                            "tflops": v["flop_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12 if v["flop_per_launch"] else None}
-                        for k, v in kern.items()},
+            "kernels": _kernel_table(kern, a.steps),
             "step_flop_algorithmic": 3 * FLOP_PER_SAMPLE_FWD * (S_C + S_C + S_F) * n,
             "step_tflops": 3 * FLOP_PER_SAMPLE_FWD * (S_C + S_C + S_F) * n / (ms * 1e-3) / 1e12,
         }
+        if world == 1 and not a.no_extras:
+            out["extras"] = extras_single_gpu(w, dev, sync)
         if world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(a.cpu_rays)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

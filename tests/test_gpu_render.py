@@ -289,6 +289,7 @@ def test_headline_size_against_oracle(R):
               "rays_illcond": int(cls["illcond"].sum()),
               "coarse_rerun_bit_identical": bool(torch.equal(st["rgb0"], ret["rgb0"])),
               "sample_indices_equal_fraction": float((st["inds"].cpu() == o32["inds"]).float().mean())}
+    REPORT["headline_4096x(64+128)"] = report                # filled in below; written even if an assertion trips
     for name in ("rgb0", "acc0"):                                                        # coarse: strict
         err = PA.per_ray_error(ret[name], o32[name])
         report[name] = PA.summary(err, cls)
@@ -303,7 +304,7 @@ def test_headline_size_against_oracle(R):
         rep["oracle32_vs_fp64_max"] = float(PA.per_ray_error(o32[name], o64[name], relative=rel).max())
         report[name] = rep
         assert rep["over_bar_unexplained"] == 0 and rep["max_among_clean_rays"] <= 1e-4, (name, rep)
-        assert rep["over_bar"] <= 0.005 * n, (name, rep)                  # a handful of rays, not a tail
+        assert rep["over_bar"] <= 0.01 * n, (name, rep)                   # a few dozen rays of 4096, not a tail
         assert rep["vs_fp64_max"] <= max(1e-4, 3 * rep["oracle32_vs_fp64_max"]), (name, rep)   # no further from fp64 than fp32 is
     # the flagged rays, fine stage re-rendered on the GPU from the oracle's merged depths: within the bar, all of them
     idx = torch.from_numpy(np.nonzero(moved)[0])

@@ -11,13 +11,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--images", type=int, default=6)
-    ap.add_argument("--chunk", type=int, default=32768)
-    ap.add_argument("--height", type=int, default=378)
-    ap.add_argument("--width", type=int, default=504)
-    a = ap.parse_args()
+def run(images=6, chunk=32768, height=378, width=504):
+    import types
+    a = types.SimpleNamespace(images=images, chunk=chunk, height=height, width=width)
     from scnerf_amd import create_nerf as cn, render as R, run_nerf_helpers as h, synthetic as synth
     H, W = a.height, a.width
 
@@ -39,10 +35,20 @@ def main():
     dt = time.perf_counter() - t0
     rays = a.images * H * W
     flop = rays * (64 * 2 + 128) * 2 * 593408            # coarse 64 + fine 192 samples, fwd MACs/sample x2
-    print(json.dumps({"metric": "rays/sec (64+128 samples/ray) full-image inference", "value": rays / dt,
-                      "unit": "rays/s", "images": a.images, "image": [H, W], "chunk": a.chunk,
-                      "s_per_image": dt / a.images, "tflops_algorithmic": flop / dt / 1e12,
-                      "includes": "ray generation, NDC, render, D2H copy into numpy"}))
+    return {"metric": "rays/sec (64+128 samples/ray) full-image inference", "value": rays / dt,
+            "unit": "rays/s", "images": a.images, "image": [H, W], "chunk": a.chunk,
+            "s_per_image": dt / a.images, "tflops_algorithmic": flop / dt / 1e12,
+            "includes": "ray generation, NDC, render, D2H copy into numpy"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=6)
+    ap.add_argument("--chunk", type=int, default=32768)
+    ap.add_argument("--height", type=int, default=378)
+    ap.add_argument("--width", type=int, default=504)
+    a = ap.parse_args()
+    print(json.dumps(run(a.images, a.chunk, a.height, a.width)))
 
 
 if __name__ == "__main__":

@@ -13,12 +13,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--rays", type=int, default=2048)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    a = ap.parse_args()
+def run(rays=2048, steps=10, warmup=2):
+    a = types.SimpleNamespace(rays=rays, steps=steps, warmup=warmup)
     from scnerf_amd import synthetic as synth
     from scnerf_amd.nerfplusplus import ddp_train_nerf as TR
     from scnerf_amd.nerfplusplus.ddp_model import NerfNet
@@ -59,9 +55,18 @@ def main():
     dt = (time.perf_counter() - t0) / a.steps
     mac_fg, mac_bg = 593408, 593408 + 2 * 256 * 21
     flop = n * (s0 + s0 + s1) * (mac_fg + mac_bg) * 2 * 3            # fwd + dgrad + wgrad
-    print(json.dumps({"metric": "rays/sec NeRF++ train-step (2 levels: 64 / 192 samples, fg + bg nets)",
-                      "value": n / dt, "unit": "rays/s", "rays": n, "ms_per_step": dt * 1e3,
-                      "tflops_algorithmic": flop / dt / 1e12}))
+    return {"metric": "rays/sec NeRF++ train-step (2 levels: 64 / 192 samples, fg + bg nets)",
+            "value": n / dt, "unit": "rays/s", "rays": n, "steps": a.steps, "ms_per_step": dt * 1e3,
+            "tflops_algorithmic": flop / dt / 1e12}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rays", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    a = ap.parse_args()
+    print(json.dumps(run(a.rays, a.steps, a.warmup)))
 
 
 if __name__ == "__main__":
