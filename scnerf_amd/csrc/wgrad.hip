@@ -20,6 +20,7 @@
 #include "mlp_common.h"
 #include "scnerf_hip.h"
 #include "wgrad256.h"
+#include "wgrad_tiles.h"
 
 namespace {
 
@@ -363,6 +364,15 @@ int launch_wgrad256(const wg256::Args& a, int G, hipStream_t stream) {
     return scn_launch_status();
 }
 
+// narrower shapes with a tile-native dZ (wgrad_tiles.h)
+template <int NA, int NB, bool B_ROWMAJOR>
+int launch_wgrad_tiles(const wgt::Args& a, int G, hipStream_t stream) {
+    constexpr unsigned lds = wgt::lds_bytes<NA, NB, B_ROWMAJOR>();
+    if (lds > 64 * 1024) SCN_LDS_OPT_IN((wgt::wgrad_tiles_kernel<NA, NB, B_ROWMAJOR>), lds);
+    hipLaunchKernelGGL((wgt::wgrad_tiles_kernel<NA, NB, B_ROWMAJOR>), dim3(G), dim3(wgt::kThreads), lds, stream, a);
+    return scn_launch_status();
+}
+
 struct Shape { int BN, BK; };
 
 bool pick_shape(int n_load, int k_load, Shape* s) {
@@ -418,6 +428,12 @@ int wgrad_gemm(const float* dz, int lda, int n_load, int n_out, int dz_tiled, co
         q->chunk = a.chunk;
         q->job[q->n_jobs++] = wg256::Job{dz, x, a.part_w, db ? a.part_b : nullptr};
         rc = batch ? 0 : launch_wgrad256(one, G, st);
+    } else if (dz_tiled && n_load == lda && k_load == ldb && n_out <= n_load &&
+               ((n_load == 256 && !x_tiled && (k_load == 64 || k_load == 128)) || (n_load == 128 && x_tiled && k_load == 256))) {
+        wgt::Args t{dz, x, a.part_w, db ? a.part_b : nullptr, a.P, a.Ppad, a.chunk};
+        if (n_load == 128) rc = launch_wgrad_tiles<128, 256, false>(t, G, st);
+        else if (k_load == 64) rc = launch_wgrad_tiles<256, 64, true>(t, G, st);
+        else rc = launch_wgrad_tiles<256, 128, true>(t, G, st);
     } else if (s.BN == 256 && s.BK == 256) rc = launch_wgrad<4, 4>(a, G, st);
     else if (s.BN == 256 && s.BK == 128) rc = launch_wgrad<4, 2>(a, G, st);
     else if (s.BN == 256 && s.BK == 64) rc = launch_wgrad<4, 1>(a, G, st);
