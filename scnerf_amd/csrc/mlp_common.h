@@ -177,6 +177,17 @@ struct WStream {
     static __device__ __forceinline__ float* buf(int i) { return dynamic_lds<float>() + i * 8192; }
 };
 
+// a 16-byte store to the activation / gradient workspace: written once, read by a LATER kernel, 7-8 GB per
+// launch -- non-temporal, so the stream does not displace the packed weights every workgroup re-reads from L2
+// (dgrad -0.8 %, forward unchanged)
+__device__ __forceinline__ void store_ws(f32x4* p, f32x4 v) {
+#ifdef SCN_PLAIN_STORE              // (timing experiment)
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
+
 // All counts are compile-time so the staging registers stay registers.
 template <int N_F4>
 __device__ __forceinline__ void stream_issue(const WStream& ws, f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1]) {
@@ -249,7 +260,7 @@ __device__ __forceinline__ void store_tile_piece(const float (&regs)[N], float* 
     if (tile == nullptr) return;
     const int t = T0 + k / 4, q = k % 4;
     f32x4 v = {regs[16 * t + 4 * q + 0], regs[16 * t + 4 * q + 1], regs[16 * t + 4 * q + 2], regs[16 * t + 4 * q + 3]};
-    *reinterpret_cast<f32x4*>(tile + (t * 4 + q) * 256) = v;
+    store_ws(reinterpret_cast<f32x4*>(tile + (t * 4 + q) * 256), v);
 }
 
 // everything the spread schedule does in bundle p of a chunk (compile-time p after unrolling)
@@ -299,7 +310,7 @@ __device__ __forceinline__ void store_tiles(const float (&regs)[N], float* tile)
         for (int q = 0; q < 4; ++q) {
             f32x4 v = {regs[16 * t + 4 * q + 0], regs[16 * t + 4 * q + 1], regs[16 * t + 4 * q + 2],
                        regs[16 * t + 4 * q + 3]};
-            *reinterpret_cast<f32x4*>(tile + (t * 4 + q) * 256) = v;     // 64 lanes x 16 B contiguous
+            store_ws(reinterpret_cast<f32x4*>(tile + (t * 4 + q) * 256), v);     // 64 lanes x 16 B contiguous
         }
 }
 
@@ -577,9 +588,14 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NT]) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 }
 
-// this lane's slot in the tile-native section of `width` features that starts at `section`
+// this lane's slot in the tile-native section of `width` features that starts at `section`.  The result is
+// declared non-null: the stores behind it test the pointer (nullptr = nothing to save, the inference
+// instantiation), and a per-lane test the compiler cannot fold is a divergent branch around EVERY store --
+// 32 extra basic blocks per trunk layer, each a barrier for the instruction scheduler.
 __device__ __forceinline__ float* tile_ptr(float* section, long wave_tile, int width, int lane) {
-    return section + wave_tile * (32L * width) + lane * 4;
+    float* p = section + wave_tile * (32L * width) + lane * 4;
+    __builtin_assume(p != nullptr);
+    return p;
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
         FwdEpi<TRAIN> epi{acc, hreg, wpk + (l < 7 ? V::kFwdBias + 256 * (l + 1) : V::kFwdBiasF), h,
                    l < 8 ? 0.f : -__builtin_huge_valf(), bits, 0u, 0u, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         mfma_part_epi<128, 8, 16, 8>(hreg, acc, ws,       // every chunk that can follow is 8 x 16 B / thread
-                                     save ? tile_ptr(save + (long)(kSaveAct + 256 * (l - 1)) * Ppad, wave_tile, 256, lane) : nullptr,
+                                     TRAIN ? tile_ptr(save + (long)(kSaveAct + 256 * (l - 1)) * Ppad, wave_tile, 256, lane) : nullptr,
                                      epi);
         if (save && l < 8) {
             u32x4 m = {bits[0], bits[1], bits[2], bits[3]};
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     f32x16 accv[4];
     init_bias<4>(accv, wpk + V::kFwdBiasV, h);
     mfma_part<128, 4, 32, 4>(hreg, accv, ws,             // then VE: 4 tiles x 16 steps = 4 f4
-                             save ? tile_ptr(save + (long)kSaveFeat * Ppad, wave_tile, 256, lane) : nullptr);
+                             TRAIN ? tile_ptr(save + (long)kSaveFeat * Ppad, wave_tile, 256, lane) : nullptr);
     mfma_part<16, 4, 16, 4>(ev, accv, ws);               // then RGB: 1 tile x 64 steps = 4 f4
     float hv[64];
     relu_to_regs<64>(accv, hv, true);
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
 
     f32x16 accc[1];
     init_bias<1>(accc, wpk + V::kFwdBiasRGB, h);
-    mfma_part<64, 1, 64, 0>(hv, accc, ws, save ? tile_ptr(save + (long)kSaveHv * Ppad, wave_tile, 128, lane) : nullptr);
+    mfma_part<64, 1, 64, 0>(hv, accc, ws, TRAIN ? tile_ptr(save + (long)kSaveHv * Ppad, wave_tile, 128, lane) : nullptr);
 
     const float sigma = sigma_part + shfl_xor(sigma_part, 32) + wpk[V::kFwdAlphaB];
     if (live && h == 0) {
