@@ -242,6 +242,13 @@ int scnerf_prd_loss_bwd(const float* kps0, const float* kps1, const float* rays0
                         const float* g_loss, float* g_rays0_o, float* g_rays0_d, float* g_rays1_o,
                         float* g_rays1_d, float* g_K, float* g_E2, float* workspace36, void* stream);
 
+/* filter_matches_with_gt (model/prd_evaluation.py:189-332): keep[i] = 1 when match i re-projects within
+ * `threshold` (the reference uses 1.0, squared pixels) both ways through the GROUND-TRUTH K (negate_fx as above)
+ * and E2 = the two ground-truth poses, and both closest points lie in front of their cameras.  keep: m bytes. */
+int scnerf_prd_filter(const float* kps0, const float* kps1, const float* rays0_o, const float* rays0_d,
+                      const float* rays1_o, const float* rays1_d, const float* K, const float* E2,
+                      float eps, float threshold, int negate_fx, int m, unsigned char* keep, void* stream);
+
 /* ------------------------------------------------------------------ NeRF++ ----------- */
 /* The per-ray pieces of the NeRF++ path around the fused networks; the foreground
  * network is scnerf_mlp_* with pt_dims = 3, the background one with pt_dims = 4. */

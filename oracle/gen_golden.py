@@ -690,7 +690,34 @@ def gen_nerfpp(ns_unused):
     np.savez_compressed(os.path.join(GOLDEN, "nerfpp.npz"), **out)
 
 
-ALL = dict(optimizer=gen_optimizer, init=gen_init_check, embedder=gen_embedder, mlp=gen_mlp, sample_pdf=gen_sample_pdf,
+def gen_prd_filter(ns):
+    """filter_matches_with_gt (model/prd_evaluation.py:189-332) -- the reference's own function, executed from
+    where it lies (its module imports cv2 / SuperGlue at the top, so only the function is taken) -- on synthetic
+    matches: pixel noise, 25 % unrelated pairs, sub-threshold and beyond-threshold errors, points behind a camera."""
+    from oracle.ref_import import REF_ROOT, _functions_from_source
+    fn_ns = {"torch": torch, "np": np}
+    _functions_from_source(os.path.join(REF_ROOT, "model", "prd_evaluation.py"), ["filter_matches_with_gt"], fn_ns)
+    filt = fn_ns["filter_matches_with_gt"]
+    H, W = 120, 160
+    spec = synth.camera_spec(H, W, n_cams=3, seed=11, focal=140.0)
+    K, E = spec["K_init"], spec["poses"]
+    out = {"H": np.array(H), "W": np.array(W), "K": np32(K), "E": np32(E)}
+    for tag, noise, seed in (("tight", 0.3, 8), ("loose", 1.2, 9)):
+        k0, k1 = synth.matched_keypoints(H, W, K, E[0], E[1], 300, seed=seed, noise_px=noise)
+        k0, k1 = k0.round(), k1.round()                      # detected key points are pixel centres; rays use .long()
+        r0 = ns.get_rays.get_rays_kps_no_camera(H=H, W=W, focal=K[0][0], extrinsic=E[0], kps_list=k0)
+        r1 = ns.get_rays.get_rays_kps_no_camera(H=H, W=W, focal=K[0][0], extrinsic=E[1], kps_list=k1)
+        keep = filt(kps0_list=k0, kps1_list=k1, H=H, W=W, gt_intrinsic=K, gt_extrinsic=E[[0, 1]], rays0=r0, rays1=r1,
+                    args=None, device="cpu", method="NeRF")
+        k = tag + "/"
+        out.update({k + "kps0": np32(k0), k + "kps1": np32(k1), k + "rays0_o": np32(r0[0].contiguous()),
+                    k + "rays0_d": np32(r0[1]), k + "rays1_o": np32(r1[0].contiguous()), k + "rays1_d": np32(r1[1]),
+                    k + "keep": keep.numpy()})
+        print(tag, "kept", int(keep.sum()), "of", keep.numel())
+    np.savez_compressed(os.path.join(GOLDEN, "prd_filter.npz"), **out)
+
+
+ALL = dict(optimizer=gen_optimizer, prd_filter=gen_prd_filter, init=gen_init_check, embedder=gen_embedder, mlp=gen_mlp, sample_pdf=gen_sample_pdf,
            composite=gen_composite, render_rays=gen_render_rays, camera=gen_camera,
            rowsum=gen_rowsum, prd=gen_prd, checkpoint=gen_checkpoint, nerfpp=gen_nerfpp)
 

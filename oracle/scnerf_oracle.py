@@ -385,16 +385,10 @@ def lr_schedule(lrate, lrate_decay, global_step):
 
 # ----------------------------------------------------------------------------- PRD loss
 
-def prd_loss(kps0, kps1, rays0_o, rays0_d, rays1_o, rays1_d, K, E2, threshold, eps=1e-10, negate_fx=True,
-             eval_mode=False):
-    """Projected-ray-distance loss of one image pair (model/ray_dist_loss.py:97-246), written per
-    match instead of with batched einsums: the mutually closest points p0 / p1 of the two rays
-    (:127-158), each re-projected into the other camera through E^-1 = [R^T | -R^T t] (:107-111,168-169)
-    and K with K[0][0] negated for NeRF's axes (:102-105,170-176), squared pixel error against the
-    matched key point (:203-208).  Train (:211-229): mean over {chirality t0,t1>0 and error < threshold
-    and finite}, separately per direction, halved sum; also returns the count valid in both.
-    Eval (:231-246): errors above the threshold / non-finite are set to it, mean over the
-    chirality-valid.  Differentiable in every float argument (torch autograd)."""
+def prd_match_errors(kps0, kps1, rays0_o, rays0_d, rays1_o, rays1_d, K, E2, eps=1e-10, negate_fx=True):
+    """Per match: squared re-projection errors (l0 in image 0, l1 in image 1) of the mutually closest points
+    of the two rays, and the chirality flag t0, t1 > 0 (model/ray_dist_loss.py:97-208; the same arithmetic is
+    filter_matches_with_gt, model/prd_evaluation.py:206-325, with eps = 1e-6)."""
     def unit(v):
         return v / (v.norm(p=2, dim=-1, keepdim=True) + eps)
     d0, d1 = unit(rays0_d), unit(rays1_d)
@@ -418,9 +412,21 @@ def prd_loss(kps0, kps1, rays0_o, rays0_d, rays1_o, rays1_d, K, E2, threshold, e
         return n[:, :2] / (n[:, 2:3] + eps)
     u01 = reproject(p0, E2[1])
     u10 = reproject(p1, E2[0])
-    chir = (t0 > 0) & (t1 > 0)
-    l0 = ((u10 - kps0) ** 2).sum(-1)[chir]
-    l1 = ((u01 - kps1) ** 2).sum(-1)[chir]
+    return ((u10 - kps0) ** 2).sum(-1), ((u01 - kps1) ** 2).sum(-1), (t0 > 0) & (t1 > 0)
+
+
+def prd_loss(kps0, kps1, rays0_o, rays0_d, rays1_o, rays1_d, K, E2, threshold, eps=1e-10, negate_fx=True,
+             eval_mode=False):
+    """Projected-ray-distance loss of one image pair (model/ray_dist_loss.py:97-246), written per
+    match instead of with batched einsums: the mutually closest points p0 / p1 of the two rays
+    (:127-158), each re-projected into the other camera through E^-1 = [R^T | -R^T t] (:107-111,168-169)
+    and K with K[0][0] negated for NeRF's axes (:102-105,170-176), squared pixel error against the
+    matched key point (:203-208).  Train (:211-229): mean over {chirality t0,t1>0 and error < threshold
+    and finite}, separately per direction, halved sum; also returns the count valid in both.
+    Eval (:231-246): errors above the threshold / non-finite are set to it, mean over the
+    chirality-valid.  Differentiable in every float argument (torch autograd)."""
+    l0, l1, chir = prd_match_errors(kps0, kps1, rays0_o, rays0_d, rays1_o, rays1_d, K, E2, eps, negate_fx)
+    l0, l1 = l0[chir], l1[chir]
     if not eval_mode:
         ok0 = (l0 < threshold) & torch.isfinite(l0)
         ok1 = (l1 < threshold) & torch.isfinite(l1)

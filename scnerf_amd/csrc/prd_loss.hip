@@ -128,6 +128,19 @@ __global__ __launch_bounds__(256) void prd_fwd_kernel(PrdArgs a, float* sums) {
     }
 }
 
+// keep[i] = both re-projection errors below `threshold` and both closest points in front of their cameras
+// (filter_matches_with_gt, model/prd_evaluation.py:189-332, which fixes threshold = 1 pixel^2)
+__global__ __launch_bounds__(256) void prd_filter_kernel(PrdArgs a, unsigned char* keep) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.m) return;
+    float Kk[3][4];
+    kmat(a, Kk);
+    const Cam c0 = load_cam(a.E), c1 = load_cam(a.E + 16);
+    Match f;
+    match_forward(a, Kk, c0, c1, i, &f);
+    keep[i] = (f.chir && f.L0 < a.threshold && f.L1 < a.threshold) ? 1 : 0;
+}
+
 __global__ void prd_finish_kernel(const float* sums, float* loss, float* n_match) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         *loss = 0.5f * (sums[0] / sums[1] + sums[2] / sums[3]);     // empty selection -> nan, as the reference
@@ -272,5 +285,14 @@ extern "C" int scnerf_prd_loss_bwd(const float* kps0, const float* kps1, const f
         hipLaunchKernelGGL(prd_bwd_kernel, dim3(scn_ceil_div(m, 256)), dim3(256), 0, st, a, sums6, g_loss, g_rays0_o,
                            g_rays0_d, g_rays1_o, g_rays1_d, workspace36);
     hipLaunchKernelGGL(prd_unpack_kernel, dim3(1), dim3(64), 0, st, workspace36, g_K, g_E2);
+    return scn_launch_status();
+}
+
+extern "C" int scnerf_prd_filter(const float* kps0, const float* kps1, const float* rays0_o, const float* rays0_d,
+                                 const float* rays1_o, const float* rays1_d, const float* K, const float* E2,
+                                 float eps, float threshold, int negate_fx, int m, unsigned char* keep, void* stream) {
+    SCN_RETURN_IF(!kps0 || !kps1 || !rays0_o || !rays0_d || !rays1_o || !rays1_d || !K || !E2 || !keep || m < 0, SCN_EINVAL);
+    const PrdArgs a = make(kps0, kps1, rays0_o, rays0_d, rays1_o, rays1_d, K, E2, eps, threshold, negate_fx, 1, m);
+    if (m > 0) hipLaunchKernelGGL(prd_filter_kernel, dim3(scn_ceil_div(m, 256)), dim3(256), 0, (hipStream_t)stream, a, keep);
     return scn_launch_status();
 }

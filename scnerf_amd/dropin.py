@@ -23,6 +23,9 @@ _MAP = {
     "model.ray_dist_loss": "scnerf_amd.ray_dist_loss",
     # model/prd_evaluation.py:2 imports it as a top-level module (load_llff.py:6 puts ../model on sys.path)
     "ray_dist_loss": "scnerf_amd.ray_dist_loss",
+    # run_nerf.py:73 `from prd_evaluation import projected_ray_distance_evaluation` (model/ is on sys.path)
+    "prd_evaluation": "scnerf_amd.prd_evaluation",
+    "model.prd_evaluation": "scnerf_amd.prd_evaluation",
 }
 
 

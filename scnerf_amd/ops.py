@@ -454,3 +454,18 @@ def prd_loss_bwd(kps0, kps1, r0o, r0d, r1o, r1d, K, E2, eps: float, threshold: f
                                           small[48:].data_ptr(), _stream())
     _capi.check(st, "scnerf_prd_loss_bwd")
     return g[0], g[1], g[2], g[3], small[:16].view(4, 4), small[16:48].view(2, 4, 4)
+
+
+def prd_filter(kps0, kps1, r0o, r0d, r1o, r1d, K, E2, eps: float, threshold: float, negate_fx: bool) -> Tensor:
+    """-> bool [M]: matches that re-project within `threshold` both ways and lie in front of both cameras."""
+    import ctypes
+    for name, t in (("kps0", kps0), ("kps1", kps1), ("rays0_o", r0o), ("rays0_d", r0d), ("rays1_o", r1o),
+                    ("rays1_d", r1d), ("K", K), ("E2", E2)):
+        _f(t, name)
+    m = kps0.shape[0]
+    keep = torch.empty(m, dtype=torch.uint8, device=kps0.device)
+    st = _capi.load().scnerf_prd_filter(_p(kps0), _p(kps1), _p(r0o), _p(r0d), _p(r1o), _p(r1d), _p(K), _p(E2),
+                                        ctypes.c_float(eps), ctypes.c_float(threshold), int(negate_fx), m,
+                                        _p(keep), _stream())
+    _capi.check(st, "scnerf_prd_filter")
+    return keep.bool()

@@ -214,7 +214,8 @@ import ast   # noqa: E402
 # functions of the mirrored modules (render, get_rays, run_nerf_helpers, create_nerf, model.ray_dist_loss)
 API_FUNCTIONS = ("render", "render_path", "get_rays_kps_use_camera", "get_rays_kps_no_camera",
                  "get_rays_full_image_use_camera", "get_rays_full_image_no_camera", "get_rays_np", "create_nerf",
-                 "img2mse", "mse2psnr", "fix_seeds", "preprocess_match", "proj_ray_dist_loss_single")
+                 "img2mse", "mse2psnr", "fix_seeds", "preprocess_match", "proj_ray_dist_loss_single",
+                 "projected_ray_distance_evaluation")
 # methods of the objects create_nerf hands back (camera model, optimizer, networks)
 API_METHODS = ("log_noises", "get_extrinsic", "get_intrinsic", "requires_grad_", "zero_grad", "step", "state_dict")
 

@@ -18,6 +18,7 @@ import torch
 from scnerf_amd.create_nerf import create_nerf
 from scnerf_amd.get_rays import get_rays_kps_no_camera, get_rays_kps_use_camera, get_rays_np
 from scnerf_amd.camera_model import *                      # noqa: F401,F403  (the script's star import: wandb, np, torch ...)
+from scnerf_amd.prd_evaluation import projected_ray_distance_evaluation
 from scnerf_amd.ray_dist_loss import preprocess_match, proj_ray_dist_loss_single
 from scnerf_amd.render import render, render_path
 from scnerf_amd.run_nerf_helpers import fix_seeds, img2mse, mse2psnr
@@ -270,6 +271,39 @@ class Loop:
                                hwf=(self.H, self.W, None), chunk=args.chunk, render_kwargs=self.render_kwargs_train,
                                mode="train", gt_imgs=self.images[i_train], savedir=savedir, camera_model=cam,
                                args=args, i_map=i_train)
+
+    # ---- PRD evaluation (:693-731 test, :879-914 val, :912-951 after training) -----------------------------
+    def evaluate_prd(self, mode):
+        """mode: "test" / "val" (held-out views through the ground-truth poses) or "train" (the cameras under
+        training).  `self.matcher` is handed over as the matcher object; the match FUNCTIONS come from
+        scnerf_amd.prd_evaluation._matchers (the reference's reprojection module, or the test's stand-in)."""
+        cam, args, H, W = self.camera_model, self.args, self.H, self.W
+        if cam is None:
+            noisy_K = torch.tensor([[self.noisy_focal, 0, W / 2, 0], [0, self.noisy_focal, H / 2, 0], [0, 0, 1, 0],
+                                    [0, 0, 0, 1]], device=self.device)
+            intrinsic, extrinsic = (noisy_K, self.noisy_extrinsic) if mode == "train" else (self.gt_intrinsic, self.gt_extrinsic)
+            return projected_ray_distance_evaluation(images=self.images, index_list=self.i_train if mode == "train" else self.i_test,
+                                                     args=args, ray_fun=get_rays_kps_no_camera, ray_fun_gt=get_rays_kps_no_camera,
+                                                     H=H, W=W, mode=mode, matcher=self.matcher, gt_intrinsic=self.gt_intrinsic,
+                                                     gt_extrinsic=self.gt_extrinsic, method="NeRF", device=self.device,
+                                                     intrinsic=intrinsic, extrinsic=extrinsic)
+        if mode == "test":
+            return projected_ray_distance_evaluation(images=self.images, index_list=self.i_test, args=args,
+                                                     ray_fun=get_rays_kps_use_camera, ray_fun_gt=get_rays_kps_no_camera, H=H, W=W,
+                                                     mode="test", matcher=self.matcher, gt_intrinsic=self.gt_intrinsic,
+                                                     gt_extrinsic=self.gt_extrinsic, method="NeRF", device=self.device,
+                                                     camera_model=cam, intrinsic=self.gt_intrinsic, extrinsic=self.gt_extrinsic)
+        if mode == "val":
+            return projected_ray_distance_evaluation(images=self.images, index_list=self.i_val, args=args,
+                                                     ray_fun=get_rays_kps_use_camera, ray_fun_gt=get_rays_kps_no_camera, H=H, W=W,
+                                                     mode="val", matcher=self.matcher, gt_intrinsic=self.gt_intrinsic,
+                                                     gt_extrinsic=self.gt_extrinsic, method="NeRF", device=self.device,
+                                                     camera_model=cam)
+        return projected_ray_distance_evaluation(images=self.images, index_list=self.i_train, args=args,
+                                                 ray_fun=get_rays_kps_use_camera, ray_fun_gt=get_rays_kps_no_camera, H=H, W=W,
+                                                 mode="train", matcher=self.matcher, gt_intrinsic=self.gt_intrinsic,
+                                                 gt_extrinsic=self.gt_extrinsic, method="NeRF", device=self.device,
+                                                 camera_model=cam, i_map=self.i_train)
 
     def render_only(self, savedir=None):
         """`--render_only` (:224-262): the spiral path through the test-time kwargs (only the rotation block of

@@ -70,7 +70,7 @@ def test_unmodified_run_nerf_imports_and_resolves_every_name():
     assert mod.__file__ == os.path.join(S.REF_ROOT, "NeRF", "run_nerf.py")
     # the hot path resolves to this package, the rest stays the reference's
     for name in ("render", "render_path", "create_nerf", "get_rays_kps_use_camera", "img2mse",
-                 "proj_ray_dist_loss_single", "preprocess_match"):
+                 "proj_ray_dist_loss_single", "preprocess_match", "projected_ray_distance_evaluation"):
         assert getattr(mod, name).__module__.startswith("scnerf_amd."), name
     assert mod.config_parser.__module__ == "config_argparse"
     assert mod.image_pair_candidates.__module__ == "model.reprojection"
@@ -140,9 +140,9 @@ def test_gpu_driver_makes_every_call_of_the_reference_train():
 def test_mirrors_accept_every_keyword_the_reference_passes():
     """inspect-level check of the same fixture: each recorded keyword set binds to the mirror's signature."""
     import inspect
-    from scnerf_amd import create_nerf, get_rays, ray_dist_loss, render, run_nerf_helpers
+    from scnerf_amd import create_nerf, get_rays, prd_evaluation, ray_dist_loss, render, run_nerf_helpers
     where = {}
-    for m in (render, get_rays, create_nerf, run_nerf_helpers, ray_dist_loss):
+    for m in (render, get_rays, create_nerf, run_nerf_helpers, ray_dist_loss, prd_evaluation):
         for n in S.API_FUNCTIONS:
             if hasattr(m, n) and n not in where:
                 where[n] = getattr(m, n)
@@ -166,7 +166,7 @@ def _namespace(tmp_path, **over):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("batching", [False, True])
-def test_gpu_training_loop_through_the_mirrored_api(tmp_path, batching):
+def test_gpu_training_loop_through_the_mirrored_api(tmp_path, batching, monkeypatch):
     from tests.run_nerf_loop import Loop
     H, W = 24, 32
     args = _namespace(tmp_path, N_rand=256, N_samples=16, N_importance=16, no_batching=not batching, N_iters=9,
@@ -191,6 +191,13 @@ def test_gpu_training_loop_through_the_mirrored_api(tmp_path, batching):
     assert rgbs.shape == (1, H, W, 3)
     rgbs, _ = loop.render_only()
     assert rgbs.shape[1:] == (H, W, 3)
+    # PRD evaluation of held-out and train views (matchers are the reference's: a stand-in here)
+    from scnerf_amd import prd_evaluation as PE
+    match = S.synthetic_matcher(H, W)
+    monkeypatch.setattr(PE, "_matchers", lambda: (match, match, lambda poses, a_, idx: {int(i): [int(j) for j in idx if j != i] for i in idx}))
+    assert loop.evaluate_prd("train").dim() == 0       # (values are checked in tests/test_prd_evaluation.py)
+    for mode in ("val", "test"):          # one held-out view: no pair, an empty mean (nan), as the reference returns
+        assert torch.isnan(loop.evaluate_prd(mode))
     # checkpoint written at i = 4 and 8 is found and restored by create_nerf (no_reload unset)
     assert os.path.basename(loop.last_checkpoint) == "000008.tar"
     again = Loop(args, data, torch.device("cuda"), matcher=S.synthetic_matcher(H, W)).setup()
