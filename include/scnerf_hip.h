@@ -242,6 +242,15 @@ int scnerf_prd_loss_bwd(const float* kps0, const float* kps1, const float* rays0
                         const float* g_loss, float* g_rays0_o, float* g_rays0_d, float* g_rays1_o,
                         float* g_rays1_d, float* g_K, float* g_E2, float* workspace36, void* stream);
 
+/* Stand-alone positional encoding, Embedder.embed (NeRF/run_nerf_helpers.py:24-55): x [n,d] -> out
+ * [n, d (include_input + 2 n_freqs)] = [x | sin(x f0) | cos(x f0) | sin(x f1) | ...]; freqs: n_freqs device
+ * floats (the reference's freq_bands).  _bwd: g_x [n,d] from g_out.  (The render path encodes inside the fused
+ * network kernels; this is for callers of embed_fn.) */
+int scnerf_embed_fwd(const float* x, long long n, int d, const float* freqs, int n_freqs, int include_input,
+                     float* out, void* stream);
+int scnerf_embed_bwd(const float* x, const float* g_out, long long n, int d, const float* freqs, int n_freqs,
+                     int include_input, float* g_x, void* stream);
+
 /* filter_matches_with_gt (model/prd_evaluation.py:189-332): keep[i] = 1 when match i re-projects within
  * `threshold` (the reference uses 1.0, squared pixels) both ways through the GROUND-TRUTH K (negate_fx as above)
  * and E2 = the two ground-truth poses, and both closest points lie in front of their cameras.  keep: m bytes. */

@@ -35,6 +35,8 @@ PROTOTYPES = {
     "scnerf_upsample_grid_bwd": [P, F, I, I, I, I, P, P],
     "scnerf_prd_loss_fwd": [P, P, P, P, P, P, P, P, F, F, I, I, I, P, P, P, P],
     "scnerf_prd_loss_bwd": [P, P, P, P, P, P, P, P, F, F, I, I, P, P, P, P, P, P, P, P, P, P],
+    "scnerf_embed_fwd": [P, LL, I, P, I, I, P, P],
+    "scnerf_embed_bwd": [P, P, LL, I, P, I, I, P, P],
     "scnerf_prd_filter": [P, P, P, P, P, P, P, P, F, F, I, I, P, P],
     "scnerf_npp_intersect_fwd": [P, P, P, P, I, P],
     "scnerf_npp_intersect_bwd": [P, P, P, P, P, I, P],

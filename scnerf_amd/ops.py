@@ -469,3 +469,23 @@ def prd_filter(kps0, kps1, r0o, r0d, r1o, r1d, K, E2, eps: float, threshold: flo
                                         _p(keep), _stream())
     _capi.check(st, "scnerf_prd_filter")
     return keep.bool()
+
+
+def embed_fwd(x: Tensor, freqs: Tensor, include_input: bool) -> Tensor:
+    """x [n,d] -> [n, d (include_input + 2 F)] (Embedder.embed)."""
+    _f(x, "x"), _f(freqs, "freqs")
+    n, d = x.shape
+    out = torch.empty((n, d * (int(include_input) + 2 * freqs.numel())), dtype=torch.float32, device=x.device)
+    st = _capi.load().scnerf_embed_fwd(_p(x), n, d, _p(freqs), freqs.numel(), int(include_input), _p(out), _stream())
+    _capi.check(st, "scnerf_embed_fwd")
+    return out
+
+
+def embed_bwd(x: Tensor, g_out: Tensor, freqs: Tensor, include_input: bool) -> Tensor:
+    _f(x, "x"), _f(g_out, "g_out"), _f(freqs, "freqs")
+    n, d = x.shape
+    g_x = torch.empty_like(x)
+    st = _capi.load().scnerf_embed_bwd(_p(x), _p(g_out), n, d, _p(freqs), freqs.numel(), int(include_input), _p(g_x),
+                                       _stream())
+    _capi.check(st, "scnerf_embed_bwd")
+    return g_x

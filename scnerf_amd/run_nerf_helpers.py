@@ -38,21 +38,57 @@ class DenseLayer(nn.Linear):
             torch.nn.init.zeros_(self.bias)
 
 
+class _EmbedFunction(torch.autograd.Function):
+    """apply(x [n,d], freqs [F], include_input) -> [n, d (include_input + 2F)] (csrc/embed.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, freqs, include_input):
+        from . import ops
+        xf = x.detach().contiguous().float()
+        ctx.save_for_backward(xf, freqs)
+        ctx.include_input = include_input
+        return ops.embed_fwd(xf, freqs, include_input)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        xf, freqs = ctx.saved_tensors
+        return ops.embed_bwd(xf, g.contiguous().float(), freqs, ctx.include_input), None, None
+
+
 class Embedder:
-    """Positional-encoding *descriptor* (reference :24-55).  The fused kernels compute the encoding
-    in registers; this object only carries (multires, out_dim) so `create_nerf` / `run_network`
-    can recognise the standard configuration."""
+    """Positional encoding (reference :24-55): same constructor keywords, `out_dim`, and `embed(inputs)`
+    -> [..., out_dim] in the reference's column order.  The render path does not call `embed`: the fused
+    network kernels build the encoding in registers and only read (num_freqs, out_dim) from this object to
+    check that they match what the caller configured.  Called directly it runs a stand-alone HIP kernel
+    (forward and backward), for code that uses `embed_fn(x)` on its own."""
 
     def __init__(self, **kwargs):
         self.kwargs = kwargs
         d = kwargs["input_dims"]
         self.num_freqs = kwargs["num_freqs"]
-        self.out_dim = (d if kwargs["include_input"] else 0) + d * 2 * self.num_freqs
+        self.include_input = bool(kwargs["include_input"])
+        self.out_dim = (d if self.include_input else 0) + d * 2 * self.num_freqs
+        fns = list(kwargs.get("periodic_fns", [torch.sin, torch.cos]))
+        self._sin_cos = len(fns) == 2 and fns[0] is torch.sin and fns[1] is torch.cos
+        max_freq = kwargs["max_freq_log2"]
+        if kwargs.get("log_sampling", True):                   # the reference's freq_bands, computed the same way
+            self.freq_bands = 2. ** torch.linspace(0., max_freq, steps=self.num_freqs)
+        else:
+            self.freq_bands = torch.linspace(2. ** 0., 2. ** max_freq, steps=self.num_freqs)
+        self._bands_on = {}
 
     def embed(self, inputs):
-        raise NotImplementedError(
-            "scnerf_amd evaluates the positional encoding inside the fused HIP network kernel; "
-            "a stand-alone embedding op is not part of the hot path (use render_rays / run_network)")
+        if not self._sin_cos:
+            raise NotImplementedError("the embedding kernel implements periodic_fns = [torch.sin, torch.cos]")
+        if not _capi.on_device(inputs):
+            raise RuntimeError("inputs must be on the GPU: scnerf_amd has no CPU path")
+        key = str(inputs.device)
+        if key not in self._bands_on:
+            self._bands_on[key] = self.freq_bands.float().to(inputs.device)
+        lead = inputs.shape[:-1]
+        out = _EmbedFunction.apply(inputs.reshape(-1, inputs.shape[-1]), self._bands_on[key], self.include_input)
+        return out.reshape(*lead, self.out_dim)
 
     __call__ = embed
 
@@ -151,10 +187,34 @@ class NeRF(nn.Module):
         return torch.as_strided(g0, (off,), (1,))
 
     def forward(self, x):
-        raise NotImplementedError(
-            "scnerf_amd.NeRF is evaluated by the fused HIP kernels through render_rays / "
-            "run_network (points + view directions in, raw out); a forward on pre-embedded "
-            "inputs is not provided")
+        """x [..., input_ch + input_ch_views] = [encoded point | encoded view direction] -> [..., 4] (rgb logits,
+        sigma) as the reference's forward (:105-128) for the use_viewdirs network.
+
+        The fused kernels encode points themselves, so this entry takes the RAW point and direction out of the
+        encodings' leading columns (include_input puts them at [0:3] and [input_ch : input_ch + 3]) and evaluates
+        the network on those -- exact whenever `x` IS the positional encoding of its own leading columns, which is
+        how every caller in the reference builds it (create_nerf.py:18-32); that is checked on a handful of rows
+        the first time.  Gradient: d x is placed on those leading columns (it already contains the encoding's
+        chain rule), so embed -> forward differentiates correctly end to end."""
+        self.require_standard()
+        if x.shape[-1] != self.input_ch + self.input_ch_views:
+            raise ValueError("expected %d columns, got %d" % (self.input_ch + self.input_ch_views, x.shape[-1]))
+        lead = x.shape[:-1]
+        flat = x.reshape(-1, x.shape[-1])
+        pts, views = flat[:, 0:3], flat[:, self.input_ch:self.input_ch + 3]
+        if not getattr(self, "_forward_input_checked", False) and flat.shape[0] > 0:
+            rows = flat[:: max(1, flat.shape[0] // 16)][:16].detach()
+            want_p = get_embedder(ML.L_PTS, 0)[0](rows[:, 0:3].contiguous())
+            want_v = get_embedder(ML.L_VIEWS, 0)[0](rows[:, self.input_ch:self.input_ch + 3].contiguous())
+            err = max(float((want_p - rows[:, :self.input_ch]).abs().max()),
+                      float((want_v - rows[:, self.input_ch:]).abs().max()))
+            if not err <= 1e-3:
+                raise ValueError("NeRF.forward: x is not the positional encoding (multires %d / %d, include_input) of "
+                                 "its own leading columns (max deviation %g)" % (ML.L_PTS, ML.L_VIEWS, err))
+            self._forward_input_checked = True
+        from .create_nerf import _QueryFunction
+        raw = _QueryFunction.apply(pts.reshape(-1, 1, 3), views, self, *self.ordered_parameters())
+        return raw.reshape(*lead, 4)
 
     def load_weights_from_keras(self, weights):
         """Same tensor order as the reference (:130-157)."""
