@@ -106,6 +106,17 @@ int scnerf_ndc_bwd(int H, int W, const float* focal_xy, float near, const float*
                    const float* rays_d, const float* g_ndc_o, const float* g_ndc_d, float* g_rays_o,
                    float* g_rays_d, float* g_focal_xy, int n, void* stream);
 
+/* The rest of render() between the ray source and batchify_rays (NeRF/render.py:105-128) in one launch:
+ * ray_batch [n, cols] = [o', d', near, far (, viewdir)] with cols = 8 or 11; viewdir = rays_d / |rays_d| of the
+ * un-warped ray; (o', d') = the NDC warp (focal_xy: 2 device floats, ndc_near as scnerf_ndc_fwd) or, with
+ * focal_xy == NULL (ndc = False), the rays themselves.  _bwd: gradients to rays_o, rays_d and (optional) the two
+ * focal lengths; the near / far columns carry none. */
+int scnerf_pack_rays_fwd(int H, int W, const float* focal_xy, float ndc_near, const float* rays_o, const float* rays_d,
+                         float near, float far, int cols, float* ray_batch, int n, void* stream);
+int scnerf_pack_rays_bwd(int H, int W, const float* focal_xy, float ndc_near, const float* rays_o, const float* rays_d,
+                         int cols, const float* g_ray_batch, float* g_rays_o, float* g_rays_d, float* g_focal_xy, int n,
+                         void* stream);
+
 /* CameraModel.get_ray_o_noise / get_ray_d_noise (model/camera_model.py:24-46): bilinear
  * (align_corners=False) upsampling of a [gh,gw,3] grid to [H*W,3], times scale; and its gradient. */
 int scnerf_upsample_grid_fwd(const float* grid, float scale, int gh, int gw, int H, int W, float* out,

@@ -31,6 +31,8 @@ PROTOTYPES = {
     "scnerf_pinhole_rays": [P, I, P, F, I, I, P, P, I, P],
     "scnerf_ndc_fwd": [I, I, P, F, P, P, P, P, I, P],
     "scnerf_ndc_bwd": [I, I, P, F, P, P, P, P, P, P, P, I, P],
+    "scnerf_pack_rays_fwd": [I, I, P, F, P, P, F, F, I, P, I, P],
+    "scnerf_pack_rays_bwd": [I, I, P, F, P, P, I, P, P, P, P, I, P],
     "scnerf_upsample_grid_fwd": [P, F, I, I, I, I, P, P],
     "scnerf_upsample_grid_bwd": [P, F, I, I, I, I, P, P],
     "scnerf_prd_loss_fwd": [P, P, P, P, P, P, P, P, F, F, I, I, I, P, P, P, P],

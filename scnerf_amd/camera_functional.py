@@ -68,6 +68,16 @@ def camera_rays(H, W, camera_model, kps_list, idx_in_camera_param=None, extrinsi
             cam_idx = torch.as_tensor(idx, device=dev).reshape(-1).long()
         else:
             single = int(idx)
+        # camera indices: negative ones count from the end like the reference's tensor indexing; anything still
+        # out of range is an IndexError there -- raised here for a host integer, clamped for device indices
+        # (checking them would cost a host read of GPU memory per call; the kernels must not read out of bounds)
+        n_cams = int(camera_model.extrinsics_initial.shape[0])
+        if cam_idx is not None:
+            cam_idx = torch.where(cam_idx < 0, cam_idx + n_cams, cam_idx).clamp_(0, n_cams - 1)
+        else:
+            if not -n_cams <= single < n_cams:
+                raise IndexError("camera index %d out of range for %d cameras" % (single, n_cams))
+            single %= n_cams
     has_o, has_d = hasattr(camera_model, "ray_o_noise"), hasattr(camera_model, "ray_d_noise")
     meta = dict(single_idx=single, intr_init=camera_model.intrinsics_initial.detach().contiguous().float(),
                 intr_scale=float(camera_model.intrinsics_noise_scale),
@@ -115,6 +125,44 @@ def ndc(H, W, fx, fy, near, rays_o, rays_d):
     fy = fy if torch.is_tensor(fy) else torch.tensor(float(fy), device=dev)
     f2 = torch.stack([fx.to(dev).float().reshape(()), fy.to(dev).float().reshape(())])
     return NdcFunction.apply(int(H), int(W), f2, float(near), rays_o, rays_d)
+
+
+class PackRaysFunction(torch.autograd.Function):
+    """apply(H, W, f2 | None, rays_o, rays_d, near, far, cols) -> ray_batch [N, cols]: view directions of the
+    un-warped rays, NDC warp (f2 given) and ray-batch packing of render() in one launch each way."""
+
+    @staticmethod
+    def forward(ctx, H, W, f2, rays_o, rays_d, near, far, cols):
+        o, d = _cf(rays_o).reshape(-1, 3), _cf(rays_d).reshape(-1, 3)
+        f2c = _cf(f2)
+        ctx.state = (H, W, f2c, o, d, cols, rays_o.shape, rays_d.shape)
+        return ops.pack_rays_fwd(H, W, f2c, 1.0, o, d, near, far, cols)
+
+    @staticmethod
+    def backward(ctx, g):
+        H, W, f2, o, d, cols, so, sd = ctx.state
+        g_o, g_d, g_f = ops.pack_rays_bwd(H, W, f2, 1.0, o, d, cols, _cf(g), ctx.needs_input_grad[2])
+        return None, None, g_f, g_o.view(so), g_d.view(sd), None, None, None
+
+
+_focal_cache = {}
+
+
+def pack_ray_batch(H, W, rays_o, rays_d, near, far, use_viewdirs, ndc, focal=None, camera_model=None):
+    """ray_batch [N, 8|11] for batchify_rays from (rays_o, rays_d) [..., 3] (reference render.py:105-128)."""
+    f2 = None
+    if ndc:
+        dev = rays_o.device
+        if camera_model is not None:
+            f2 = camera_model.focal_xy()                        # differentiable w.r.t. the intrinsics residual
+        elif torch.is_tensor(focal):
+            f2 = torch.stack([focal.to(dev).float().reshape(()), focal.to(dev).float().reshape(())])
+        else:
+            key = (float(focal), str(dev))
+            if key not in _focal_cache:
+                _focal_cache[key] = torch.tensor([float(focal), float(focal)], dtype=torch.float32, device=dev)
+            f2 = _focal_cache[key]
+    return PackRaysFunction.apply(int(H), int(W), f2, rays_o, rays_d, float(near), float(far), 11 if use_viewdirs else 8)
 
 
 class UpsampleGridFunction(torch.autograd.Function):

@@ -117,6 +117,12 @@ class CameraModel(nn.Module):
 
 
 class _PinholeRotNoise(CameraModel):
+    def focal_xy(self):
+        """[fx, fy] of get_intrinsic() without building the 4x4 matrix (what the NDC warp needs per step)."""
+        p = self.intrinsics_initial[:2]
+        r = self.intrinsics_noise[:2] * self.intrinsics_noise_scale
+        return p + (r * p if self.multiplicative_noise else r)
+
     def get_intrinsic(self):
         if self.multiplicative_noise:
             p = self.intrinsics_initial + self.intrinsics_noise * self.intrinsics_noise_scale * self.intrinsics_initial

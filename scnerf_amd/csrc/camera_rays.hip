@@ -217,6 +217,10 @@ __device__ __forceinline__ void ray_forward(const CamArgs& a, int i, const Intri
                 d.x * f->R.x.y + d.y * f->R.y.y + d.z * f->R.z.y,
                 d.x * f->R.x.z + d.y * f->R.y.z + d.z * f->R.z.z);
     Vec3 o = f->t;
+    // the pixel the noise grids are sampled at is kept inside the image (callers validate the key points, but
+    // the host layer's check is asynchronous: an out-of-range batch must not read or scatter out of bounds)
+    px = min(max(px, 0), a.W - 1);
+    py = min(max(py, 0), a.H - 1);
     if (a.grid_o || a.grid_d) f->taps = bilinear_taps(py, px, a.gh, a.gw, a.H, a.W);
     if (a.grid_o) o = o + a.scale_o * sample_grid(a.grid_o, a.gw, f->taps);
     if (a.grid_d) {
@@ -244,10 +248,19 @@ __global__ __launch_bounds__(256) void camera_rays_fwd_kernel(CamArgs a, float* 
 
 // Per-ray reverse pass.  acc layout (floats): [0..3] d intrinsic params (fx, fy, cx, cy);
 // then per camera (or per explicit matrix) 12 floats: dR columns x, y, z (9) + dt (3).
+// lds_slots > 0: the 12 pose accumulators of each of `lds_slots` cameras are first summed in LDS by the workgroup
+// and flushed with one global atomic per non-zero entry -- thousands of rays share a few dozen cameras, and
+// 12 global float atomics per ray on ~200 addresses serialised the kernel (94 us at 4096 rays, 17 views)
 __global__ __launch_bounds__(256) void camera_rays_bwd_kernel(CamArgs a, const float* __restrict__ g_o,
                                                               const float* __restrict__ g_d, float* acc,
-                                                              float* d_grid_o, float* d_grid_d, float* acc_dist) {
+                                                              float* d_grid_o, float* d_grid_d, float* acc_dist,
+                                                              int lds_slots) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float* lacc = dynamic_lds<float>();
+    if (lds_slots > 0) {
+        for (int k = threadIdx.x; k < lds_slots * 12; k += blockDim.x) lacc[k] = 0.f;
+        block_sync();
+    }
     float gk[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // fx, fy, cx, cy, (k0, k1)
     if (i < a.n) {
         const Intrinsics K = intrinsics_of(a);
@@ -266,7 +279,7 @@ __global__ __launch_bounds__(256) void camera_rays_bwd_kernel(CamArgs a, const f
         if (a.grid_o && d_grid_o) scatter_grid(d_grid_o, a.gw, f.taps, a.scale_o * go);
         // R, t
         const int slot = a.extrinsic ? (a.n_ext == 1 ? 0 : i) : f.cam;
-        float* ar = acc + 4 + (size_t)slot * 12;
+        float* ar = lds_slots > 0 ? lacc + slot * 12 : acc + 4 + (size_t)slot * 12;
         const Vec3 dd = f.dirs;
         atomic_add(ar + 0, gr.x * dd.x); atomic_add(ar + 1, gr.y * dd.x); atomic_add(ar + 2, gr.z * dd.x);   // d col x
         atomic_add(ar + 3, gr.x * dd.y); atomic_add(ar + 4, gr.y * dd.y); atomic_add(ar + 5, gr.z * dd.y);   // d col y
@@ -298,6 +311,13 @@ __global__ __launch_bounds__(256) void camera_rays_bwd_kernel(CamArgs a, const f
             }
             gk[2] = gdx * ((dxdc - 1.f) / K.fx);
             gk[3] = gdy * ((dydc - 1.f) / K.fy);
+        }
+    }
+    if (lds_slots > 0) {
+        block_sync();
+        for (int k = threadIdx.x; k < lds_slots * 12; k += blockDim.x) {
+            const float v = lacc[k];
+            if (v != 0.f) atomic_add(acc + 4 + k, v);
         }
     }
     // wave reduce, then one atomic per wave
@@ -390,6 +410,31 @@ __global__ __launch_bounds__(256) void ndc_fwd_kernel(int H, int W, const float*
     ndc_forward(H, W, f2[0], f2[1], near, o + (size_t)i * 3, d + (size_t)i * 3, no + (size_t)i * 3, nd + (size_t)i * 3);
 }
 
+// gradient of the NDC warp of one ray: (a = d L / d ndc_o, b = d L / d ndc_d) -> g_o, g_d, and the ray's
+// contributions to d L / d fx, d L / d fy
+__device__ __forceinline__ void ndc_backward(int H, int W, float fx, float fy, float near, const float* oi, const float* di,
+                                             const float* a, const float* b, float* g_o, float* g_d, float* gfx, float* gfy) {
+    float no[3], nd[3];
+    const Ndc s = ndc_forward(H, W, fx, fy, near, oi, di, no, nd);
+    const float a0 = a[0], a1 = a[1], a2 = a[2], b0 = b[0], b1 = b[1], b2 = b[2];
+    const float A = s.ox / s.oz, B = s.oy / s.oz;
+    const float g_sx = a0 * A + b0 * (di[0] / di[2] - A);
+    const float g_sy = a1 * B + b1 * (di[1] / di[2] - B);
+    *gfx = g_sx * (-2.f / (float)W);
+    *gfy = g_sy * (-2.f / (float)H);
+    const float gA = (a0 - b0) * s.sx, gB = (a1 - b1) * s.sy;
+    const float gox = gA / s.oz, goy = gB / s.oz;
+    const float goz = -(gA * A + gB * B) / s.oz + (b2 - a2) * (2.f * near / (s.oz * s.oz));
+    float gdx = b0 * s.sx / di[2], gdy = b1 * s.sy / di[2];
+    float gdz = -(b0 * s.sx * di[0] + b1 * s.sy * di[1]) / (di[2] * di[2]);
+    const float gt = gox * di[0] + goy * di[1] + goz * di[2];
+    gdx += s.t * gox; gdy += s.t * goy; gdz += s.t * goz;
+    const float gz_o = goz + gt * (-1.f / di[2]);
+    gdz += gt * (near + oi[2]) / (di[2] * di[2]);
+    g_o[0] = gox; g_o[1] = goy; g_o[2] = gz_o;
+    g_d[0] = gdx; g_d[1] = gdy; g_d[2] = gdz;
+}
+
 __global__ __launch_bounds__(256) void ndc_bwd_kernel(int H, int W, const float* __restrict__ f2, float near,
                                                       const float* __restrict__ o, const float* __restrict__ d,
                                                       const float* __restrict__ g_no, const float* __restrict__ g_nd,
@@ -398,34 +443,75 @@ __global__ __launch_bounds__(256) void ndc_bwd_kernel(int H, int W, const float*
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float gfx = 0.f, gfy = 0.f;
     if (i < n) {
-        const float* oi = o + (size_t)i * 3;
-        const float* di = d + (size_t)i * 3;
-        float no[3], nd[3];
-        const Ndc s = ndc_forward(H, W, f2[0], f2[1], near, oi, di, no, nd);
-        const float a0 = g_no ? g_no[(size_t)i * 3] : 0.f, a1 = g_no ? g_no[(size_t)i * 3 + 1] : 0.f,
-                    a2 = g_no ? g_no[(size_t)i * 3 + 2] : 0.f;
-        const float b0 = g_nd ? g_nd[(size_t)i * 3] : 0.f, b1 = g_nd ? g_nd[(size_t)i * 3 + 1] : 0.f,
-                    b2 = g_nd ? g_nd[(size_t)i * 3 + 2] : 0.f;
-        const float A = s.ox / s.oz, B = s.oy / s.oz;
-        const float g_sx = a0 * A + b0 * (di[0] / di[2] - A);
-        const float g_sy = a1 * B + b1 * (di[1] / di[2] - B);
-        gfx = g_sx * (-2.f / (float)W);
-        gfy = g_sy * (-2.f / (float)H);
-        const float gA = (a0 - b0) * s.sx, gB = (a1 - b1) * s.sy;
-        const float gox = gA / s.oz, goy = gB / s.oz;
-        const float goz = -(gA * A + gB * B) / s.oz + (b2 - a2) * (2.f * near / (s.oz * s.oz));
-        float gdx = b0 * s.sx / di[2], gdy = b1 * s.sy / di[2];
-        float gdz = -(b0 * s.sx * di[0] + b1 * s.sy * di[1]) / (di[2] * di[2]);
-        const float gt = gox * di[0] + goy * di[1] + goz * di[2];
-        gdx += s.t * gox; gdy += s.t * goy; gdz += s.t * goz;
-        float gz_o = goz + gt * (-1.f / di[2]);
-        gdz += gt * (near + oi[2]) / (di[2] * di[2]);
-        g_o[(size_t)i * 3 + 0] = gox; g_o[(size_t)i * 3 + 1] = goy; g_o[(size_t)i * 3 + 2] = gz_o;
-        g_d[(size_t)i * 3 + 0] = gdx; g_d[(size_t)i * 3 + 1] = gdy; g_d[(size_t)i * 3 + 2] = gdz;
+        float a[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f};
+        if (g_no) { a[0] = g_no[(size_t)i * 3]; a[1] = g_no[(size_t)i * 3 + 1]; a[2] = g_no[(size_t)i * 3 + 2]; }
+        if (g_nd) { b[0] = g_nd[(size_t)i * 3]; b[1] = g_nd[(size_t)i * 3 + 1]; b[2] = g_nd[(size_t)i * 3 + 2]; }
+        ndc_backward(H, W, f2[0], f2[1], near, o + (size_t)i * 3, d + (size_t)i * 3, a, b, g_o + (size_t)i * 3,
+                     g_d + (size_t)i * 3, &gfx, &gfy);
     }
 #pragma unroll
     for (int o2 = 32; o2 > 0; o2 >>= 1) { gfx += shfl_xor(gfx, o2); gfy += shfl_xor(gfy, o2); }
     if (g_f2 && lane_id() == 0) { atomic_add(g_f2, gfx); atomic_add(g_f2 + 1, gfy); }
+}
+
+// ---- ray-batch packing: what render() does between the ray source and batchify_rays (render.py:105-128) ----
+// row = [o' (3), d' (3), near, far (, viewdir (3))]: the view direction is d / |d| of the UN-warped ray (:105-109),
+// (o', d') the NDC warp when `f2` is given (ndc = True), else (o, d); one thread per ray instead of ~10
+// element-wise launches (and as many again in the backward).
+__global__ __launch_bounds__(256) void pack_rays_fwd_kernel(int H, int W, const float* __restrict__ f2, float ndc_near,
+                                                            const float* __restrict__ o, const float* __restrict__ d,
+                                                            float near, float far, int cols, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* oi = o + (size_t)i * 3;
+    const float* di = d + (size_t)i * 3;
+    float* r = out + (size_t)i * cols;
+    if (cols > 8) {
+        const float nrm = sqrtf(di[0] * di[0] + di[1] * di[1] + di[2] * di[2]);
+        r[8] = di[0] / nrm; r[9] = di[1] / nrm; r[10] = di[2] / nrm;
+    }
+    if (f2) {
+        float no[3], nd[3];
+        ndc_forward(H, W, f2[0], f2[1], ndc_near, oi, di, no, nd);
+        r[0] = no[0]; r[1] = no[1]; r[2] = no[2]; r[3] = nd[0]; r[4] = nd[1]; r[5] = nd[2];
+    } else {
+        r[0] = oi[0]; r[1] = oi[1]; r[2] = oi[2]; r[3] = di[0]; r[4] = di[1]; r[5] = di[2];
+    }
+    r[6] = near; r[7] = far;
+}
+
+__global__ __launch_bounds__(256) void pack_rays_bwd_kernel(int H, int W, const float* __restrict__ f2, float ndc_near,
+                                                            const float* __restrict__ o, const float* __restrict__ d,
+                                                            int cols, const float* __restrict__ g, float* __restrict__ g_o,
+                                                            float* __restrict__ g_d, float* g_f2, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float gfx = 0.f, gfy = 0.f;
+    if (i < n) {
+        const float* oi = o + (size_t)i * 3;
+        const float* di = d + (size_t)i * 3;
+        const float* gr = g + (size_t)i * cols;
+        float go[3], gd[3];
+        if (f2) {
+            ndc_backward(H, W, f2[0], f2[1], ndc_near, oi, di, gr, gr + 3, go, gd, &gfx, &gfy);
+        } else {
+            go[0] = gr[0]; go[1] = gr[1]; go[2] = gr[2]; gd[0] = gr[3]; gd[1] = gr[4]; gd[2] = gr[5];
+        }
+        if (cols > 8) {             // v = d / |d|:  g_d += (g_v - v (v . g_v)) / |d|
+            const float nrm = sqrtf(di[0] * di[0] + di[1] * di[1] + di[2] * di[2]);
+            const float v0 = di[0] / nrm, v1 = di[1] / nrm, v2 = di[2] / nrm;
+            const float dotv = v0 * gr[8] + v1 * gr[9] + v2 * gr[10];
+            gd[0] += (gr[8] - v0 * dotv) / nrm;
+            gd[1] += (gr[9] - v1 * dotv) / nrm;
+            gd[2] += (gr[10] - v2 * dotv) / nrm;
+        }
+        g_o[(size_t)i * 3] = go[0]; g_o[(size_t)i * 3 + 1] = go[1]; g_o[(size_t)i * 3 + 2] = go[2];
+        g_d[(size_t)i * 3] = gd[0]; g_d[(size_t)i * 3 + 1] = gd[1]; g_d[(size_t)i * 3 + 2] = gd[2];
+    }
+    if (g_f2) {
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) { gfx += shfl_xor(gfx, o2); gfy += shfl_xor(gfy, o2); }
+        if (lane_id() == 0) { atomic_add(g_f2, gfx); atomic_add(g_f2 + 1, gfy); }
+    }
 }
 
 // ---- full-image upsampling of a noise grid (CameraModel.get_ray_{o,d}_noise) -------------------
@@ -516,9 +602,12 @@ extern "C" int scnerf_camera_rays_bwd(const float* kps, const long long* cam_idx
     if (d_grid_o) SCN_HIP(hipMemsetAsync(d_grid_o, 0, sizeof(float) * 3 * (size_t)gh * gw, st));
     if (d_grid_d && d_grid_d != d_grid_o) SCN_HIP(hipMemsetAsync(d_grid_d, 0, sizeof(float) * 3 * (size_t)gh * gw, st));
     if (d_extr_noise) SCN_HIP(hipMemsetAsync(d_extr_noise, 0, sizeof(float) * 9 * (size_t)n_cams, st));
-    if (n > 0)
-        hipLaunchKernelGGL(camera_rays_bwd_kernel, dim3(scn_ceil_div(n, 256)), dim3(256), 0, st, a, g_o, g_d,
-                           workspace, d_grid_o, d_grid_d, (float*)nullptr);
+    if (n > 0) {
+        // per-ray poses (n_ext == n) have one slot per ray: nothing to pre-reduce
+        const int lds_slots = (extrinsic && n_ext > 1) || slots > 1024 ? 0 : slots;
+        hipLaunchKernelGGL(camera_rays_bwd_kernel, dim3(scn_ceil_div(n, 256)), dim3(256), (size_t)lds_slots * 12 * sizeof(float),
+                           st, a, g_o, g_d, workspace, d_grid_o, d_grid_d, (float*)nullptr, lds_slots);
+    }
     hipLaunchKernelGGL(camera_finish_kernel, dim3(scn_ceil_div(slots, 64)), dim3(64), 0, st, a, workspace,
                        d_intr_noise, d_extr_noise, d_extrinsic);
     return scn_launch_status();
@@ -568,9 +657,11 @@ extern "C" int scnerf_npp_camera_rays_bwd(const long long* select, const float* 
     if (d_grid_o) SCN_HIP(hipMemsetAsync(d_grid_o, 0, sizeof(float) * 3 * (size_t)gh * gw, st));
     if (d_grid_d && d_grid_d != d_grid_o) SCN_HIP(hipMemsetAsync(d_grid_d, 0, sizeof(float) * 3 * (size_t)gh * gw, st));
     if (d_extr_noise) SCN_HIP(hipMemsetAsync(d_extr_noise, 0, sizeof(float) * 9 * (size_t)n_cams, st));
-    if (n > 0)
-        hipLaunchKernelGGL(camera_rays_bwd_kernel, dim3(scn_ceil_div(n, 256)), dim3(256), 0, st, a, g_o, g_d,
-                           workspace, d_grid_o, d_grid_d, dist2 ? d_dist2 : (float*)nullptr);
+    if (n > 0) {
+        const int lds_slots = slots > 1024 ? 0 : slots;
+        hipLaunchKernelGGL(camera_rays_bwd_kernel, dim3(scn_ceil_div(n, 256)), dim3(256), (size_t)lds_slots * 12 * sizeof(float),
+                           st, a, g_o, g_d, workspace, d_grid_o, d_grid_d, dist2 ? d_dist2 : (float*)nullptr, lds_slots);
+    }
     hipLaunchKernelGGL(camera_finish_kernel, dim3(scn_ceil_div(slots, 64)), dim3(64), 0, st, a, workspace,
                        d_intr_noise, d_extr_noise, d_extrinsic);
     return scn_launch_status();
@@ -603,6 +694,29 @@ extern "C" int scnerf_ndc_bwd(int H, int W, const float* focal_xy, float near, c
     if (n == 0) return 0;
     hipLaunchKernelGGL(ndc_bwd_kernel, dim3(scn_ceil_div(n, 256)), dim3(256), 0, st, H, W, focal_xy, near, rays_o,
                        rays_d, g_ndc_o, g_ndc_d, g_rays_o, g_rays_d, g_focal_xy, n);
+    return scn_launch_status();
+}
+
+extern "C" int scnerf_pack_rays_fwd(int H, int W, const float* focal_xy, float ndc_near, const float* rays_o,
+                                    const float* rays_d, float near, float far, int cols, float* ray_batch, int n,
+                                    void* stream) {
+    SCN_RETURN_IF(!rays_o || !rays_d || !ray_batch || n < 0 || (cols != 8 && cols != 11), SCN_EINVAL);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(pack_rays_fwd_kernel, dim3(scn_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, H, W, focal_xy,
+                       ndc_near, rays_o, rays_d, near, far, cols, ray_batch, n);
+    return scn_launch_status();
+}
+
+extern "C" int scnerf_pack_rays_bwd(int H, int W, const float* focal_xy, float ndc_near, const float* rays_o,
+                                    const float* rays_d, int cols, const float* g_ray_batch, float* g_rays_o,
+                                    float* g_rays_d, float* g_focal_xy, int n, void* stream) {
+    SCN_RETURN_IF(!rays_o || !rays_d || !g_ray_batch || !g_rays_o || !g_rays_d || n < 0 || (cols != 8 && cols != 11), SCN_EINVAL);
+    SCN_RETURN_IF(g_focal_xy && !focal_xy, SCN_EINVAL);
+    hipStream_t st = (hipStream_t)stream;
+    if (g_focal_xy) SCN_HIP(hipMemsetAsync(g_focal_xy, 0, 2 * sizeof(float), st));
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(pack_rays_bwd_kernel, dim3(scn_ceil_div(n, 256)), dim3(256), 0, st, H, W, focal_xy, ndc_near, rays_o,
+                       rays_d, cols, g_ray_batch, g_rays_o, g_rays_d, g_focal_xy, n);
     return scn_launch_status();
 }
 

@@ -489,3 +489,26 @@ def embed_bwd(x: Tensor, g_out: Tensor, freqs: Tensor, include_input: bool) -> T
                                        _stream())
     _capi.check(st, "scnerf_embed_bwd")
     return g_x
+
+
+def pack_rays_fwd(H, W, f2: Optional[Tensor], ndc_near: float, o: Tensor, d: Tensor, near: float, far: float, cols: int):
+    import ctypes
+    _f(o, "rays_o"), _f(d, "rays_d")
+    n = o.shape[0]
+    out = torch.empty((n, cols), dtype=torch.float32, device=o.device)
+    st = _capi.load().scnerf_pack_rays_fwd(int(H), int(W), _p(f2), ctypes.c_float(float(ndc_near)), _p(o), _p(d),
+                                           ctypes.c_float(float(near)), ctypes.c_float(float(far)), int(cols), _p(out), n,
+                                           _stream())
+    _capi.check(st, "scnerf_pack_rays_fwd")
+    return out
+
+
+def pack_rays_bwd(H, W, f2: Optional[Tensor], ndc_near: float, o: Tensor, d: Tensor, cols: int, g: Tensor, want_f2: bool):
+    import ctypes
+    _f(g, "g_ray_batch")
+    g_o, g_d = torch.empty_like(o), torch.empty_like(d)
+    g_f = torch.empty(2, dtype=torch.float32, device=o.device) if (want_f2 and f2 is not None) else None
+    st = _capi.load().scnerf_pack_rays_bwd(int(H), int(W), _p(f2), ctypes.c_float(float(ndc_near)), _p(o), _p(d), int(cols),
+                                           _p(g), _p(g_o), _p(g_d), _p(g_f), o.shape[0], _stream())
+    _capi.check(st, "scnerf_pack_rays_bwd")
+    return g_o, g_d, g_f

@@ -123,7 +123,9 @@ def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
         for key in _COLOUR_KEYS:
             colour = out.get(key)
             if colour is not None:
-                colour[colour >= 1.0] = 1.0
+                # in place like the reference's `ret[key][ret[key] >= 1.0] = 1.0`, but as a masked fill: boolean
+                # index assignment runs nonzero() and blocks the host on the GPU twice per chunk
+                colour.masked_fill_(colour >= 1.0, 1.0)
         pieces.append(out)
     if not pieces:
         return {}
@@ -244,17 +246,11 @@ def render(H, W, chunk, rays=None, noisy_focal=None, noisy_extrinsic=None, ndc=T
         camera_model=camera_model, image_idx=image_idx, i_map=i_map, gt_intrinsic=gt_intrinsic,
         gt_extrinsic=gt_extrinsic, transform_align=transform_align))
     lead = tuple(rays_d.shape[:-1])                              # outputs are reshaped back to this
-    columns = []
-    if use_viewdirs:                                             # unit directions of the UN-warped rays (:105-109)
-        columns.append((rays_d / torch.norm(rays_d, dim=-1, keepdim=True)).reshape(-1, 3).float())
-    if ndc:
-        if camera_model is None:
-            rays_o, rays_d = ndc_rays(H, W, focal, 1., rays_o, rays_d)
-        else:
-            rays_o, rays_d = ndc_rays_camera(H, W, camera_model, 1., rays_o, rays_d)
-    rays_o, rays_d = rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float()
-    ones = torch.ones_like(rays_d[:, :1])
-    packed = torch.cat([rays_o, rays_d, near * ones, far * ones] + columns, dim=-1)
+    # unit view directions of the UN-warped rays (:105-109), NDC warp (:113-117), near / far columns and the
+    # concatenation (:119-128): one fused launch (csrc/camera_rays.hip pack_rays), differentiable w.r.t. the rays
+    # and, through the camera model's focal lengths, its intrinsics
+    from .camera_functional import pack_ray_batch
+    packed = pack_ray_batch(H, W, rays_o, rays_d, near, far, use_viewdirs, ndc, focal=focal, camera_model=camera_model)
     if _ray_range is not None:
         packed = packed[_ray_range[0]:_ray_range[1]]
         lead = (packed.shape[0],)

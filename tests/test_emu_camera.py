@@ -178,3 +178,45 @@ def test_upsample_grid_matches_interpolate():
     dg = np.zeros((37, 50, 3), np.float32)
     H.call("scnerf_upsample_grid_bwd", go.numpy(), ctypes.c_float(1e-3), 37, 50, HH, WW, dg, None)
     np.testing.assert_allclose(dg, gt.grad.numpy(), rtol=2e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("ndc,use_viewdirs", [(True, True), (False, True), (True, False)])
+def test_pack_ray_batch_matches_the_reference_composition(ndc, use_viewdirs):
+    """render()'s view-direction / NDC / concatenation steps (reference render.py:105-128) as the one fused
+    launch, against the same steps written with torch ops on the oracle's NDC warp, with gradients to the rays
+    and to the two focal lengths."""
+    from tests.emu.host_on_emu import emulated_device
+    from oracle import scnerf_oracle as O
+    from scnerf_amd import camera_functional as CF
+    H, W, n = 48, 64, 37
+    g = torch.Generator().manual_seed(3)
+    o = torch.randn(n, 3, generator=g) * 0.3
+    d = torch.cat([torch.randn(n, 2, generator=g) * 0.4, -1.0 - torch.rand(n, 1, generator=g)], -1)
+    f2 = torch.tensor([55.0, 57.0])
+    gy = torch.randn(n, 11 if use_viewdirs else 8, generator=g)
+
+    class Cam:                                   # the only thing pack_ray_batch asks of a camera model
+        def __init__(self, f):
+            self.f = f
+
+        def focal_xy(self):
+            return self.f
+    with emulated_device():
+        oe, de, fe = o.clone().requires_grad_(True), d.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+        got = CF.pack_ray_batch(H, W, oe, de, 0.25, 3.0, use_viewdirs, ndc, camera_model=Cam(fe))
+        (got * gy).sum().backward()
+    orf, drf, frf = o.clone().requires_grad_(True), d.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+    cols = []
+    if use_viewdirs:
+        cols.append(drf / torch.norm(drf, dim=-1, keepdim=True))
+    ro, rd = O.ndc_rays(H, W, frf[0], frf[1], 1.0, orf, drf) if ndc else (orf, drf)
+    ones = torch.ones_like(rd[:, :1])
+    want = torch.cat([ro, rd, 0.25 * ones, 3.0 * ones] + cols, -1)
+    (want * gy).sum().backward()
+    np.testing.assert_allclose(got.detach().numpy(), want.detach().numpy(), rtol=2e-6, atol=2e-6)
+    for a, b, what in ((oe, orf, "rays_o"), (de, drf, "rays_d")):
+        assert float((a.grad - b.grad).abs().max()) <= 2e-5 * float(b.grad.abs().max()) + 1e-7, what
+    if ndc:
+        assert float((fe.grad - frf.grad).abs().max()) <= 2e-5 * float(frf.grad.abs().max())
+    else:
+        assert fe.grad is None

@@ -180,3 +180,30 @@ def test_render_through_camera_model_config3(M):
         got = getattr(cm, name).grad
         assert got is not None, name
         close(got, cam[name].grad.numpy(), tol, name)
+
+
+def test_key_point_range_check_is_deferred_but_raised(M):
+    """Out-of-image key points: the reference asserts at once (a host read of GPU memory per call); here the
+    verdict travels to pinned memory asynchronously and the AssertionError comes with the next ray-generation
+    call (or flush()); the kernel clamps the pixel it samples the noise grids at, so nothing is read out of bounds."""
+    from scnerf_amd.get_rays import KEYPOINT_CHECK
+    cm, spec, _ = make_camera(M, "pinhole_rot_noise_10k_rayo_rayd", True)
+    KEYPOINT_CHECK.flush()
+    good = torch.tensor([[3, 4], [WW - 1, HH - 1]], device="cuda")
+    bad = torch.tensor([[3, 4], [WW, 2]], device="cuda")
+    ro, rd = M.gr.get_rays_kps_use_camera(HH, WW, cm, good, idx_in_camera_param=1)
+    assert torch.isfinite(rd).all()
+    ro, rd = M.gr.get_rays_kps_use_camera(HH, WW, cm, bad, idx_in_camera_param=1)      # accepted for now
+    assert torch.isfinite(rd).all()
+    with pytest.raises(AssertionError):
+        KEYPOINT_CHECK.flush()
+    KEYPOINT_CHECK.flush()                                                                # reported once
+    with pytest.raises(AssertionError):
+        M.gr.get_rays_kps_no_camera(HH, WW, 100.0, torch.eye(4, device="cuda")[:3], torch.tensor([[-1, 0]], device="cuda"))
+        KEYPOINT_CHECK.flush()
+    with pytest.raises(IndexError):
+        M.gr.get_rays_kps_use_camera(HH, WW, cm, good, idx_in_camera_param=99)
+    ro2, _ = M.gr.get_rays_kps_use_camera(HH, WW, cm, good, idx_in_camera_param=-1)       # python-style negative index
+    ro3, _ = M.gr.get_rays_kps_use_camera(HH, WW, cm, good, idx_in_camera_param=4)
+    assert torch.equal(ro2, ro3)
+    KEYPOINT_CHECK.flush()
