@@ -160,6 +160,12 @@ def create_nerf(args, noisy_focal, noisy_poses, H, W, mode="train", device="cuda
                                         weight_decay=args.non_linear_weight_decay, H=H, W=W, args=args)
     else:
         optimizer = FusedAdam(grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    # one process per GPU (torch.distributed initialised by the launcher): the optimizer's step() first
+    # all-reduces its gradient arena -- networks AND camera parameters, one collective (parallel.py)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        from .parallel import FlatGradAllReduce
+        optimizer.grad_sync = FlatGradAllReduce.for_optimizer(optimizer, dist.get_world_size())
     start = 0
     ft_path = getattr(args, "ft_path", None)
     basedir, expname = getattr(args, "basedir", None), getattr(args, "expname", None)

@@ -2,9 +2,13 @@
 checkpoint reload, with the reference's structure and return values `(start, models, camera_model)`.
 
 Differences a maintainer should know: the networks are wrapped in a parameter-less `_Replica` container
-instead of gloo `DistributedDataParallel` (so state-dict keys keep the `module.` prefix): gradients are
-synchronised by ONE RCCL all-reduce per step over flat buffers (scnerf_amd.parallel.FlatGradAllReduce,
-`models['grad_sync']`), which -- unlike the reference (:64-65) -- also covers the camera parameters."""
+instead of gloo `DistributedDataParallel` (so state-dict keys keep the `module.` prefix).  Gradients are
+synchronised by ONE all-reduce per step of the optimizer's flat gradient arena
+(scnerf_amd.parallel.FlatGradAllReduce.for_optimizer), which -- unlike the reference (:64-65) -- also covers the
+camera parameters: when torch.distributed is initialised with more than one rank, `create_nerf` attaches the
+reducer as `models['optim'].grad_sync` (and `models['grad_sync']`), and `optim.step()` runs the collective before
+the update -- the training loop's `zero_grad() / backward() / step()` (ddp_train_nerf.py:400-470) stays as it is.
+Every rank must take the same curriculum steps (`requires_grad_` toggles change the arena's layout)."""
 from __future__ import annotations
 
 import json
@@ -32,6 +36,11 @@ class _Replica(nn.Module):
 
     def forward(self, *a, **k):
         return self.module(*a, **k)
+
+
+def _world_size():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
 def _build_camera(args, camera_info, device):
@@ -101,7 +110,8 @@ def create_nerf(rank, args, camera_info):
     cascade_samples, net_0 .. net_{L-1}, optim)."""
     torch.manual_seed(777)
     device = torch.device("cuda", rank) if isinstance(rank, int) else torch.device(rank)
-    torch.cuda.set_device(device)
+    if device.type == "cuda":
+        torch.cuda.set_device(device)
     camera_model, H, W = _build_camera(args, camera_info, device)
 
     models = OrderedDict()
@@ -126,6 +136,12 @@ def create_nerf(rank, args, camera_info):
                                               weight_decay=args.non_linear_weight_decay, H=H, W=W, args=args)
     else:
         models["optim"] = FusedAdam(parameters, lr=args.lrate)
+
+    world = _world_size()
+    if world > 1:
+        from ..parallel import FlatGradAllReduce
+        models["optim"].grad_sync = FlatGradAllReduce.for_optimizer(models["optim"], world)
+        models["grad_sync"] = models["optim"].grad_sync
 
     start = -1
     ckpts = _find_checkpoints(args)

@@ -136,3 +136,18 @@ def test_ray_parallel_nerf_and_camera_gradients_two_ranks(tmp_path, with_optimiz
     _check_ray_parallel(tmp_path, world)
     if with_optimizer:
         np.testing.assert_array_equal(np.load(tmp_path / "param0.npy"), np.load(tmp_path / "param1.npy"))
+
+
+def test_nerfpp_create_nerf_synchronises_gradients_in_step(tmp_path):
+    """NeRF++ under a 2-rank process group: the reference wrapped its networks in DistributedDataParallel
+    (nerfplusplus/create_nerf.py:56-65); here `create_nerf` attaches ONE all-reduce of the optimizer's gradient
+    arena to `optim.step()`.  Ranks with different rays (different local gradients) end the step with identical
+    parameters."""
+    from tests.nerfpp_ddp_worker import worker
+    world = 2
+    mp.spawn(worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a0, a1 = np.load(tmp_path / "after0.npy"), np.load(tmp_path / "after1.npy")
+    g0, g1 = np.load(tmp_path / "local_grad0.npy"), np.load(tmp_path / "local_grad1.npy")
+    assert np.abs(g0 - g1).max() > 0                     # the ranks really saw different data
+    np.testing.assert_array_equal(a0, a1)                # ... and still hold the same networks afterwards
+    assert float(np.load(tmp_path / "moved0.npy")) > 0
