@@ -185,6 +185,16 @@ int scnerf_mlp_fwd(int pt_dims, const float* pts, const float* viewdirs, int vd_
 long long scnerf_mlp_save_floats(int pt_dims, long long n_samples);
 long long scnerf_mlp_grad_floats(long long n_samples);
 
+/* The coarse stage of render_rays (NeRF/render.py:235-262) as ONE launch: scnerf_coarse_sample + scnerf_mlp_fwd
+ * (pt_dims = 3, samples_per_ray = 64, view directions = columns 8..10 of the ray batch) + scnerf_composite_fwd, with
+ * the stratified depths computed in the network kernel's prologue and the compositing in its epilogue (the two
+ * rays of a workgroup meet in LDS).  Same arguments and bit-identical outputs as those three calls; n_samples must
+ * be 64 (anything else: SCN_ENOSUP, use the three calls); save == NULL selects the inference instantiation. */
+int scnerf_coarse_stage_fwd(const float* rays, int ray_stride, const float* t_vals, const float* t_rand, int lindisp,
+                            const float* wpacked, float* save, const float* noise, int white_bkgd, float* z,
+                            float* pts, float* raw, float* rgb_map, float* disp_map, float* acc_map,
+                            float* depth_map, float* weights, int n_rays, int n_samples, void* stream);
+
 /* Data-gradient chain of the fused network (what autograd derives from NeRF.forward,
  * Embedder and run_network: NeRF/run_nerf_helpers.py:105-128, :24-72, create_nerf.py:18-32).
  * d_raw [n_samples, 4]; wpacked_bwd = backward packed buffer (mlp_layout.backward_index());

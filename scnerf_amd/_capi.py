@@ -60,6 +60,7 @@ PROTOTYPES = {
     "scnerf_gather_f32": [P, P, P, LL, P],
     "scnerf_mlp_layout_info": [I, P, I],
     "scnerf_mlp_fwd": [I, P, P, I, I, P, P, P, LL, P],
+    "scnerf_coarse_stage_fwd": [P, I, P, P, I, P, P, P, I, P, P, P, P, P, P, P, P, I, I, P],
     "scnerf_mlp_bwd": [I, P, P, P, I, I, P, P, P, P, P, LL, P],
     "scnerf_nerf_param_count": [I],
     "scnerf_nerf_wgrad": [I, P, P, P, LL, I, P, P, I, P],

@@ -9,6 +9,7 @@
 #include <scn_wave.h>
 
 #include "launch.h"
+#include "ray_stage.h"
 #include "scnerf_hip.h"
 
 namespace {
@@ -16,15 +17,6 @@ namespace {
 using namespace scn;
 
 constexpr int kRaysPerBlock = 4;
-
-__device__ __forceinline__ double wave_incl_prod(double v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double u = shfl_up(v, o);
-        if (lane >= o) v *= u;
-    }
-    return v;
-}
 
 __device__ __forceinline__ double wave_incl_sum_rev(double v, int lane) {
     // inclusive suffix sum: v[lane] + v[lane+1] + ... + v[63]
@@ -36,38 +28,12 @@ __device__ __forceinline__ double wave_incl_sum_rev(double v, int lane) {
     return v;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += shfl_xor(v, o);
-    return v;
-}
-
-__device__ __forceinline__ float ray_norm(const float* d) {
-    return sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-}
-
-struct SampleTerms {
-    float e;       // exp(-relu(sigma + noise) * dist)
-    float alpha;   // 1 - e
-    float q;       // 1 - alpha + 1e-10
-    float a;       // relu(sigma + noise)
-    float dist;    // (z[i+1] - z[i] | 1e10) * |d|
-    float draw;    // z[i+1] - z[i] | 1e10
-};
-
-__device__ __forceinline__ SampleTerms sample_terms(float sigma, float noise, float z, float z_next,
-                                                    bool last, float norm) {
-    SampleTerms t;
-    t.draw = last ? 1e10f : (z_next - z);
-    t.dist = t.draw * norm;
-    t.a = fmaxf(sigma + noise, 0.f);
-    t.e = expf(-t.a * t.dist);
-    t.alpha = 1.f - t.e;
-    t.q = 1.f - t.alpha + 1e-10f;
-    return t;
-}
-
-__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+using ray::ray_norm;
+using ray::SampleTerms;
+using ray::sample_terms;
+using ray::sigmoidf;
+using ray::wave_incl_prod;
+using ray::wave_sum;
 
 __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays, int ray_stride,
@@ -78,52 +44,15 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const bool live = ray < n;
     if (!live) ray = n - 1;
     const float norm = ray_norm(rays + (size_t)ray * ray_stride + 3);
+    const float* rr = raw + (size_t)ray * s * 4;
     const float* zr = z + (size_t)ray * s;
-    double carry = 1.0;
-    double sr = 0.0, sg = 0.0, sb = 0.0, sdepth = 0.0, sacc = 0.0;
-    for (int base = 0; base < s; base += 64) {
-        const int i = base + lane;
-        const bool in = i < s;
-        const int ic = in ? i : s - 1;
-        const f32x4 rw = *reinterpret_cast<const f32x4*>(raw + ((size_t)ray * s + ic) * 4);
-        const float zi = zr[ic];
-        const float zn = ic + 1 < s ? zr[ic + 1] : zi;
-        const float nz = noise ? noise[(size_t)ray * s + ic] : 0.f;
-        const SampleTerms t = sample_terms(rw[3], nz, zi, zn, ic == s - 1, norm);
-        const double qd = in ? (double)t.q : 1.0;
-        const double incl = wave_incl_prod(qd, lane) * carry;
-        // exclusive product = inclusive of the previous lane (carry for lane 0)
-        double excl = shfl_up(incl, 1);
-        if (lane == 0) excl = carry;
-        carry = shfl(incl, 63);
-        const float T = (float)excl;
-        const float w = t.alpha * T;
-        if (in) {
-            if (live && weights) weights[(size_t)ray * s + i] = w;
-            sr += (double)(w * sigmoidf(rw[0]));
-            sg += (double)(w * sigmoidf(rw[1]));
-            sb += (double)(w * sigmoidf(rw[2]));
-            sdepth += (double)(w * zi);
-            sacc += (double)w;
-        }
-    }
-    sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb);
-    sdepth = wave_sum(sdepth); sacc = wave_sum(sacc);
-    if (live && lane == 0) {
-        const float acc = (float)sacc, depth = (float)sdepth;
-        float r = (float)sr, g = (float)sg, b = (float)sb;
-        if (white_bkgd) {
-            const float bg = 1.f - acc;
-            r += bg; g += bg; b += bg;
-        }
-        rgb_map[(size_t)ray * 3 + 0] = r;
-        rgb_map[(size_t)ray * 3 + 1] = g;
-        rgb_map[(size_t)ray * 3 + 2] = b;
-        const float q = depth / (acc + 1e-10f);
-        disp_map[ray] = 1.f / fmaxf(1e-10f, q);
-        acc_map[ray] = acc;
-        if (depth_map) depth_map[ray] = depth;
-    }
+    auto fetch = [&](int i, f32x4* rw, float* zi) {
+        *rw = *reinterpret_cast<const f32x4*>(rr + (size_t)i * 4);
+        *zi = zr[i];
+    };
+    ray::composite_ray(fetch, s, norm, noise ? noise + (size_t)ray * s : nullptr, white_bkgd, live, lane,
+                       rgb_map + (size_t)ray * 3, disp_map + ray, acc_map + ray, depth_map ? depth_map + ray : nullptr,
+                       weights ? weights + (size_t)ray * s : nullptr);
 }
 
 // Backward of the above.  g_* are the incoming gradients of the four maps (any may be NULL);

@@ -14,6 +14,7 @@
 
 #include "launch.h"
 #include "mlp_common.h"
+#include "ray_stage.h"
 #include "scnerf_hip.h"
 
 namespace {
@@ -88,11 +89,25 @@ struct FwdEpi {
     }
 };
 
+// The coarse stage of render_rays as ONE launch (reference NeRF/render.py:235-262): stratified depths and points in
+// the network kernel's prologue, alpha compositing in its epilogue.  64 samples per ray = two wave tiles, so a
+// workgroup holds two whole rays: their raw outputs and depths meet in LDS and one wave per ray runs the same
+// compositing code as composite_fwd_kernel (ray_stage.h), bit for bit.
+struct CoarseStage {
+    const float* rays; int ray_stride; int n_rays;
+    const float* t_vals; const float* t_rand; int lindisp;     // t_rand [n_rays, 64] or nullptr (no jitter)
+    float* z; float* pts;                                      // out: [n_rays, 64], [n_rays, 64, 3]
+    const float* noise; int white_bkgd;                        // density noise [n_rays, 64] or nullptr
+    float* rgb; float* disp; float* acc; float* depth; float* weights;   // out: compositing
+};
+constexpr int kCoarseSamples = 64;
+
 // TRAIN: also leave the activations / encodings / ReLU masks in `save` for the dgrad and wgrad kernels
-template <int PD, bool TRAIN>
+// COARSE: points come from `cs` (PD == 3, 64 samples per ray), `pts` is unused
+template <int PD, bool TRAIN, bool COARSE = false>
 __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     const float* __restrict__ pts, const float* __restrict__ viewdirs, int vd_stride, int samples_per_ray,
-    const float* __restrict__ wpk, float* __restrict__ raw, float* __restrict__ save_arg, long P) {
+    const float* __restrict__ wpk, float* __restrict__ raw, float* __restrict__ save_arg, long P, CoarseStage cs) {
     float* const save = TRAIN ? save_arg : nullptr;
     const int lane = lane_id();
     const int m = lane & 31, h = lane >> 5;
@@ -108,8 +123,27 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     ws.g = reinterpret_cast<const f32x4*>(wpk);
     stream_prime<8>(ws);   // first chunk of E0 (8 tiles x 16 steps)
 
-    const float px = pts[pc * PD + 0], py = pts[pc * PD + 1], pz = pts[pc * PD + 2];
-    const float pw = PD == 4 ? pts[pc * PD + (PD - 1)] : 0.f;
+    float px, py, pz, pw = 0.f;
+    auto coarse_depth_of_sample = [&]() {          // this lane's stratified depth (COARSE only; cheap to redo)
+        const float* r = cs.rays + (pc >> 6) * cs.ray_stride;
+        return ray::coarse_z(r[6], r[7], cs.t_vals, (int)(pc & 63), kCoarseSamples, cs.lindisp, cs.t_rand != nullptr,
+                             cs.t_rand ? cs.t_rand[pc] : 0.f);
+    };
+    if constexpr (COARSE) {
+        static_assert(PD == 3, "the coarse stage samples 3-D points");
+        const float* r = cs.rays + (pc >> 6) * cs.ray_stride;
+        const float z = coarse_depth_of_sample();
+        px = r[0] + r[3] * z;
+        py = r[1] + r[4] * z;
+        pz = r[2] + r[5] * z;
+        if (live && h == 0) {
+            cs.z[p] = z;
+            cs.pts[p * 3 + 0] = px; cs.pts[p * 3 + 1] = py; cs.pts[p * 3 + 2] = pz;
+        }
+    } else {
+        px = pts[pc * PD + 0]; py = pts[pc * PD + 1]; pz = pts[pc * PD + 2];
+        if constexpr (PD == 4) pw = pts[pc * PD + (PD - 1)];
+    }
 
     float hreg[256 / 2];           // this lane's 128 of the 256 trunk features
     f32x16 acc[8];
@@ -193,10 +227,33 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     mfma_part<64, 1, 64, 0>(hv, accc, ws, TRAIN ? tile_ptr(save + (long)kSaveHv * Ppad, wave_tile, 128, lane) : nullptr);
 
     const float sigma = sigma_part + shfl_xor(sigma_part, 32) + wpk[V::kFwdAlphaB];
-    if (live && h == 0) {
-        // rows 0,1,2 of the single tile are registers 0,1,2 of the h == 0 half
-        f32x4 o = {accc[0][0], accc[0][1], accc[0][2], sigma};
-        *reinterpret_cast<f32x4*>(raw + p * 4) = o;
+    // rows 0,1,2 of the single tile are registers 0,1,2 of the h == 0 half
+    const f32x4 o = {accc[0][0], accc[0][1], accc[0][2], sigma};
+    if (live && h == 0) *reinterpret_cast<f32x4*>(raw + p * 4) = o;
+    if constexpr (COARSE) {
+        // the parked-encoding area of the LDS is free (last read in layer 5, many chunk barriers ago)
+        float* sraw = dynamic_lds<float>() + kStreamBufs * kMaxChunkFwd;      // [128 samples][4]
+        float* sz = sraw + kSamplesPerBlock * 4;                              // [128]
+        const int local = wave_id() * kSamplesPerWave + m;
+        if (h == 0) {
+            *reinterpret_cast<f32x4*>(sraw + local * 4) = o;
+            sz[local] = coarse_depth_of_sample();
+        }
+        block_sync();
+        if (wave_id() < kSamplesPerBlock / kCoarseSamples) {                  // one wave per ray, lane = sample
+            const int slot = wave_id();
+            long ray = (long)blockIdx.x * (kSamplesPerBlock / kCoarseSamples) + slot;
+            const bool ray_live = ray < cs.n_rays;
+            if (!ray_live) ray = cs.n_rays - 1;
+            const float norm = ray::ray_norm(cs.rays + ray * cs.ray_stride + 3);
+            auto fetch = [&](int i, f32x4* rw, float* zi) {
+                *rw = *reinterpret_cast<const f32x4*>(sraw + (slot * kCoarseSamples + i) * 4);
+                *zi = sz[slot * kCoarseSamples + i];
+            };
+            ray::composite_ray(fetch, kCoarseSamples, norm, cs.noise ? cs.noise + ray * kCoarseSamples : nullptr,
+                               cs.white_bkgd, ray_live, lane, cs.rgb + ray * 3, cs.disp + ray, cs.acc + ray,
+                               cs.depth ? cs.depth + ray : nullptr, cs.weights ? cs.weights + ray * kCoarseSamples : nullptr);
+        }
     }
 }
 
@@ -250,8 +307,33 @@ static int launch_fwd(const float* pts, const float* viewdirs, int vd_stride, in
     const size_t lds = (size_t)(kStreamBufs * kMaxChunkFwd + Var<PD>::kES * kThreads) * sizeof(float);
     SCN_LDS_OPT_IN((mlp_fwd_kernel<PD, TRAIN>), lds);
     hipLaunchKernelGGL((mlp_fwd_kernel<PD, TRAIN>), dim3(scn_ceil_div(n_samples, kSamplesPerBlock)), dim3(kThreads), lds,
-                       st, pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, (long)n_samples);
+                       st, pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, (long)n_samples, CoarseStage{});
     return scn_launch_status();
+}
+
+template <bool TRAIN>
+static int launch_coarse_stage(const CoarseStage& cs, const float* wpacked, float* raw, float* save, hipStream_t st) {
+    const size_t lds = (size_t)(kStreamBufs * kMaxChunkFwd + Var<3>::kES * kThreads) * sizeof(float);
+    const long P = (long)cs.n_rays * kCoarseSamples;
+    SCN_LDS_OPT_IN((mlp_fwd_kernel<3, TRAIN, true>), lds);
+    hipLaunchKernelGGL((mlp_fwd_kernel<3, TRAIN, true>), dim3(scn_ceil_div(P, kSamplesPerBlock)), dim3(kThreads), lds, st,
+                       (const float*)nullptr, cs.rays + 8, cs.ray_stride, kCoarseSamples, wpacked, raw, save, P, cs);
+    return scn_launch_status();
+}
+
+extern "C" int scnerf_coarse_stage_fwd(const float* rays, int ray_stride, const float* t_vals, const float* t_rand,
+                                       int lindisp, const float* wpacked, float* save, const float* noise,
+                                       int white_bkgd, float* z, float* pts, float* raw, float* rgb_map,
+                                       float* disp_map, float* acc_map, float* depth_map, float* weights, int n_rays,
+                                       int n_samples, void* stream) {
+    SCN_RETURN_IF(!rays || !t_vals || !wpacked || !z || !pts || !raw || !rgb_map || !disp_map || !acc_map, SCN_EINVAL);
+    SCN_RETURN_IF(n_rays < 0 || ray_stride < 11, SCN_EINVAL);
+    SCN_RETURN_IF(n_samples != kCoarseSamples, SCN_ENOSUP);           // two wave tiles per ray is what the fusion rests on
+    if (n_rays == 0) return 0;
+    const CoarseStage cs{rays, ray_stride, n_rays, t_vals, t_rand, lindisp, z, pts, noise, white_bkgd,
+                         rgb_map, disp_map, acc_map, depth_map, weights};
+    hipStream_t st = (hipStream_t)stream;
+    return save ? launch_coarse_stage<true>(cs, wpacked, raw, save, st) : launch_coarse_stage<false>(cs, wpacked, raw, save, st);
 }
 
 extern "C" int scnerf_mlp_fwd(int pt_dims, const float* pts, const float* viewdirs, int vd_stride,

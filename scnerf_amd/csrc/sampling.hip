@@ -11,6 +11,7 @@
 
 #include "aten_sum.h"
 #include "launch.h"
+#include "ray_stage.h"
 #include "scnerf_hip.h"
 
 namespace {
@@ -132,11 +133,6 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(
     }
 }
 
-__device__ __forceinline__ float coarse_depth(float near, float far, float t, int lindisp) {
-    if (!lindisp) return near * (1.f - t) + far * t;
-    return 1.f / (1.f / near * (1.f - t) + 1.f / far * t);
-}
-
 __global__ __launch_bounds__(256) void coarse_sample_kernel(
     const float* __restrict__ rays, int ray_stride, const float* __restrict__ t_vals,
     const float* __restrict__ t_rand, float* __restrict__ z_out, float* __restrict__ pts, int n,
@@ -145,14 +141,7 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(
     if (idx >= (long long)n * s) return;
     const int ray = (int)(idx / s), i = (int)(idx - (long long)ray * s);
     const float* r = rays + (size_t)ray * ray_stride;
-    const float near = r[6], far = r[7];
-    float z = coarse_depth(near, far, t_vals[i], lindisp);
-    if (t_rand) {
-        float lower = z, upper = z;
-        if (i > 0) lower = 0.5f * (z + coarse_depth(near, far, t_vals[i - 1], lindisp));
-        if (i < s - 1) upper = 0.5f * (coarse_depth(near, far, t_vals[i + 1], lindisp) + z);
-        z = lower + (upper - lower) * t_rand[idx];
-    }
+    const float z = ray::coarse_z(r[6], r[7], t_vals, i, s, lindisp, t_rand != nullptr, t_rand ? t_rand[idx] : 0.f);
     z_out[idx] = z;
     float* p = pts + idx * 3;
     p[0] = r[0] + r[3] * z;

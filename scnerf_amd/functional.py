@@ -69,10 +69,15 @@ class RenderRaysFunction(torch.autograd.Function):
         net_c.require_standard()
         flat_c = net_c.flat_parameters()
         wf_c = ops.pack_weights(flat_c, "fwd")
-        z_c, pts_c = ops.coarse_sample(rays, host_linspace(sc, dev), _c(t_rand), cfg.lindisp)
         save_c = ops.save_workspace(n * sc, dev) if train else None
-        raw_c = ops.mlp_fwd(pts_c, viewdirs, sc, wf_c, save_c).view(n, sc, 4)
-        rgb_c, disp_c, acc_c, w_c, depth_c = ops.composite_fwd(raw_c, z_c, rays, _c(noise_c), cfg.white_bkgd)
+        if sc == ops.COARSE_STAGE_SAMPLES and n > 0:
+            # the whole coarse stage -- stratified depths, network, compositing -- is one launch
+            z_c, pts_c, raw_c, rgb_c, disp_c, acc_c, w_c, depth_c = ops.coarse_stage_fwd(
+                rays, host_linspace(sc, dev), _c(t_rand), cfg.lindisp, wf_c, save_c, _c(noise_c), cfg.white_bkgd)
+        else:
+            z_c, pts_c = ops.coarse_sample(rays, host_linspace(sc, dev), _c(t_rand), cfg.lindisp)
+            raw_c = ops.mlp_fwd(pts_c, viewdirs, sc, wf_c, save_c).view(n, sc, 4)
+            rgb_c, disp_c, acc_c, w_c, depth_c = ops.composite_fwd(raw_c, z_c, rays, _c(noise_c), cfg.white_bkgd)
 
         ctx.cfg, ctx.train, ctx.n = cfg, train, n
         ctx.net_c, ctx.net_f = net_c, net_f

@@ -228,6 +228,43 @@ def mlp_fwd(pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked: Tensor
     return raw
 
 
+COARSE_STAGE_SAMPLES = 64        # the fused coarse stage exists for two wave tiles per ray (csrc/mlp_fwd.hip)
+
+
+def coarse_stage_fwd(rays: Tensor, t_vals: Tensor, t_rand: Optional[Tensor], lindisp: bool, wpacked: Tensor,
+                     save: Optional[Tensor], noise: Optional[Tensor], white_bkgd: bool):
+    """coarse_sample + mlp_fwd + composite_fwd of the coarse stage as one launch (64 samples per ray):
+    -> (z [n,64], pts [n,64,3], raw [n,64,4], rgb [n,3], disp [n], acc [n], weights [n,64], depth [n])."""
+    _f(rays, "rays"), _f(t_vals, "t_vals"), _f(wpacked, "wpacked")
+    for name, t_ in (("t_rand", t_rand), ("noise", noise), ("save", save)):
+        if t_ is not None:
+            _f(t_, name)
+    n, s = rays.shape[0], t_vals.shape[0]
+    if s != COARSE_STAGE_SAMPLES or rays.shape[1] < 11:
+        raise ValueError("the fused coarse stage takes 64 samples per ray and an 11-column ray batch")
+    lay = ML.layout(3)
+    if wpacked.numel() != lay.fwd_total:
+        raise ValueError("wpacked has the wrong size")
+    if save is not None and save.numel() < lay.save_floats(n * s):
+        raise ValueError("activation workspace too small")
+    dev = rays.device
+    z = torch.empty((n, s), dtype=torch.float32, device=dev)
+    pts = torch.empty((n, s, 3), dtype=torch.float32, device=dev)
+    raw = torch.empty((n, s, 4), dtype=torch.float32, device=dev)
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    disp = torch.empty((n,), dtype=torch.float32, device=dev)
+    acc = torch.empty((n,), dtype=torch.float32, device=dev)
+    depth = torch.empty((n,), dtype=torch.float32, device=dev)
+    w = torch.empty((n, s), dtype=torch.float32, device=dev)
+    P = n * s
+    with PROFILE.region("mlp_fwd_kernel/P=%d/%s" % (P, "train" if save is not None else "infer"), 2 * _MAC_PER_SAMPLE[3] * P):
+        st = _capi.load().scnerf_coarse_stage_fwd(_p(rays), rays.shape[1], _p(t_vals), _p(t_rand), int(bool(lindisp)),
+                                                  _p(wpacked), _p(save), _p(noise), int(bool(white_bkgd)), _p(z), _p(pts),
+                                                  _p(raw), _p(rgb), _p(disp), _p(acc), _p(depth), _p(w), n, s, _stream())
+    _capi.check(st, "scnerf_coarse_stage_fwd")
+    return z, pts, raw, rgb, disp, acc, w, depth
+
+
 def save_workspace(P: int, device, pd: int = 3) -> Tensor:
     return torch.empty(ML.layout(pd).save_floats(P), dtype=torch.float32, device=device)
 
