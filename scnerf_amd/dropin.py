@@ -31,6 +31,10 @@ _MAP = {
 
 # the NeRF++ scripts import these as top-level modules of nerfplusplus/ (ddp_train_nerf.py:8-25)
 _MAP_NERFPP = {
+    # nerfplusplus/ddp_train_nerf.py:16 `from create_nerf import create_nerf`: the reference's wraps the networks in
+    # DistributedDataParallel and builds torch optimizers; the mirror builds the fused optimizer and attaches ONE
+    # all-reduce of its gradient arena to step() instead (same signature and return values)
+    "create_nerf": "scnerf_amd.nerfplusplus.create_nerf",
     "nerf_network": "scnerf_amd.nerfplusplus.nerf_network",
     "ddp_model": "scnerf_amd.nerfplusplus.ddp_model",
     "nerf_sample_ray_split": "scnerf_amd.nerfplusplus.nerf_sample_ray_split",

@@ -95,6 +95,10 @@ def install_stubs(force=()):
         _module("piqa.ssim", SSIM=_ZeroMetric)
         _module("piqa.lpips", LPIPS=_ZeroMetric)
         made.append("piqa")
+    if need("wandb"):                       # scripts that `import wandb` themselves get the package's offline stand-in
+        from scnerf_amd.camera_model import wandb as offline
+        sys.modules["wandb"] = offline
+        made.append("wandb")
     if need("torchvision"):
         _module("torchvision")
         _module("torchvision.transforms", ToPILImage=lambda: (lambda t: t))

@@ -222,3 +222,39 @@ def test_gpu_unmodified_train(tmp_path, monkeypatch):
             mod.train()
     finally:
         torch.set_default_tensor_type('torch.FloatTensor')
+
+
+@needs_reference
+def test_unmodified_nerfplusplus_training_script_imports_on_the_mirrors():
+    """nerfplusplus/ddp_train_nerf.py, unmodified, under `dropin.install_nerfplusplus()`: the network, the model
+    factory, the ray generator and the PRD loss it imports resolve to this package; every global it loads exists.
+    (The script keeps its own copies of intersect_sphere / perturb_samples / sample_pdf / render_single_image --
+    torch code that runs as it is; their HIP twins live in scnerf_amd.nerfplusplus.ddp_train_nerf.)"""
+    import importlib
+    import scnerf_amd.dropin as dropin
+    S.install_stubs()
+    for n in ("ddp_train_nerf", "create_nerf", "ddp_model", "nerf_network", "nerf_sample_ray_split", "utils",
+              "data_loader_split", "config_argparser", "model", "model.reprojection", "model.lookup"):
+        sys.modules.pop(n, None)
+    root = os.path.join(S.REF_ROOT, "nerfplusplus")
+    saved_path, cwd = list(sys.path), os.getcwd()
+    sys.path.insert(0, root)
+    os.chdir(root)
+    try:
+        dropin.install_nerfplusplus()
+        mod = importlib.import_module("ddp_train_nerf")
+    finally:
+        os.chdir(cwd)
+        sys.path[:] = saved_path
+    try:
+        assert mod.__file__ == os.path.join(root, "ddp_train_nerf.py")
+        assert mod.create_nerf.__module__ == "scnerf_amd.nerfplusplus.create_nerf"
+        assert mod.render_ray_from_camera.__module__ == "scnerf_amd.nerfplusplus.nerf_sample_ray_split"
+        assert mod.proj_ray_dist_loss_single.__module__ == "scnerf_amd.ray_dist_loss"
+        assert mod.load_data_split.__module__ == "data_loader_split"            # host-side data handling: the reference's
+        assert S.undefined_globals(mod) == []
+    finally:
+        for n in ("ddp_train_nerf", "create_nerf", "ddp_model", "nerf_network", "nerf_sample_ray_split", "utils",
+                  "data_loader_split", "config_argparser", "camera_model", "model.camera_model", "model.camera_utils",
+                  "model.ray_dist_loss"):
+            sys.modules.pop(n, None)
