@@ -18,6 +18,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long-running CPU test")
 
 
+def pytest_sessionfinish(session, exitstatus):
+    try:
+        from tests import parity_attribution
+        parity_attribution.write_report()
+    except Exception:            # reporting must never turn a green run red
+        pass
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False))
 

@@ -10,8 +10,37 @@ two places:
 Two implementations whose coarse weights differ in the last bit therefore place a few samples differently, and
 the rays owning those samples legitimately differ by more than the 1e-4 bar downstream.  `classify` finds, per
 ray, whether one of its samples is in that situation, from the cdf / indices BOTH sides expose."""
+import json
+import os
+
 import numpy as np
 import torch
+
+# everything the parity tests measured; tests/conftest.py writes it at the end of the session to
+# gpurun_out/parity_r02.json (travels back from the GPU box; the copy committed under profiles/ is this file)
+# and to profiles/ in the tree the tests ran in
+REPORT = {}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def write_report():
+    """entries of this session replace the same-named ones of the committed report; the others stay"""
+    if not REPORT:
+        return
+    merged = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "parity_r02.json")) as f:
+            merged = json.load(f)
+    except (OSError, ValueError):
+        pass
+    merged.update(REPORT)
+    for d in ("gpurun_out", "profiles"):
+        try:
+            os.makedirs(os.path.join(ROOT, d), exist_ok=True)
+            with open(os.path.join(ROOT, d, "parity_r02.json"), "w") as f:
+                json.dump(merged, f, indent=1, sort_keys=True)
+        except OSError:
+            pass
 
 
 def _gather(t, idx):

@@ -18,24 +18,7 @@ from tests import parity_attribution as PA
 
 pytestmark = pytest.mark.gpu
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REPORT = {}
-
-
-@pytest.fixture(scope="module", autouse=True)
-def parity_report():
-    """Everything the parity tests measured goes to one JSON: gpurun_out/ (travels back from the GPU box; the
-    copy committed as profiles/parity_r02.json is this file) and profiles/ in the tree the tests ran in."""
-    yield
-    if not REPORT:
-        return
-    for d in ("gpurun_out", "profiles"):
-        try:
-            os.makedirs(os.path.join(ROOT, d), exist_ok=True)
-            with open(os.path.join(ROOT, d, "parity_r02.json"), "w") as f:
-                json.dump(REPORT, f, indent=1, sort_keys=True)
-        except OSError:
-            pass
+REPORT = PA.REPORT          # written by tests/conftest.py at the end of the session
 
 CASES = ["c64_f0_det", "c64_f0_pert", "c64_f128_pert", "c64_f128_det", "c64_f64_lindisp"]
 
