@@ -233,6 +233,13 @@ int scnerf_vecmat(const float* x_tiled256, const float* vec, int vec_stride, lon
  * scnerf_mlp_fwd (save) and scnerf_mlp_bwd (grads) and d_raw [n_samples, 4].  workspace:
  * scnerf_nerf_wgrad_workspace_floats(n_chunks) floats. */
 int scnerf_nerf_param_count(int pt_dims);
+/* Arithmetic of the 256 x 256 weight-gradient GEMMs (87 % of the weight-gradient FLOPs).  mode 1 (default):
+ * bf16 matrix pipe, every fp32 operand cut exactly into three bf16 numbers, six partial products per product,
+ * fp32 accumulation -- the error against fp64 equals the exact-fp32 kernel's; mode 0: v_mfma_f32_32x32x2_f32.
+ * Any other value only queries.  Returns the mode in force.  Environment preset:
+ * SCNERF_WGRAD_ARITHMETIC=fp32 | split.  (No reference counterpart: torch.autograd computes these GEMMs with
+ * whatever sgemm the build links.) */
+int scnerf_wgrad_arithmetic(int mode);
 long long scnerf_nerf_wgrad_workspace_floats(int n_chunks);
  /* accumulate != 0: flat_grad += the gradients (autograd's accumulation into an attached flat .grad
  * buffer without 48 separate add kernels); 0: overwrite. */

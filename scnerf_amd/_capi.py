@@ -66,6 +66,7 @@ PROTOTYPES = {
     "scnerf_nerf_wgrad": [I, P, P, P, LL, I, P, P, I, P],
     "scnerf_wgrad": [P, I, I, I, I, P, I, I, I, I, LL, I, P, P, I, I, P, P],
     "scnerf_vecmat": [P, P, I, LL, I, P, P, P, P],
+    "scnerf_wgrad_arithmetic": [I],
 }
 
 

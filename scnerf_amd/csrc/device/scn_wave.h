@@ -24,6 +24,28 @@ __device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// D[32x32] += A[32x16] * B[16x32], bf16 operands (raw bits in shorts), fp32 accumulate, 32 cycles/SIMD:
+// 16x the rate of the exact-fp32 form above.  Lane l supplies A[i = l&31][k = 8 (l>>5) .. +7] and
+// B[k = 8 (l>>5) .. +7][j = l&31]; C/D layout as mfma_32x32x2.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// ds_read_b64_tr_b16: every lane names 8 bytes of LDS (4 x 16 bit, 8-byte aligned); the 16 lanes of a group
+// together name a [4 rows][16 columns] block (lane c: row c >> 2, columns 4 (c & 3) .. +3) and lane c
+// receives column c, rows 0 .. 3 -- the transpose an MFMA operand needs when the LDS image is k-major.
+__device__ __forceinline__ s16x4 lds_read_tr16(const short* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+// {bits 31..16 of lo_word, bits 31..16 of hi_word} as one dword (v_perm_b32): two truncated bf16
+__device__ __forceinline__ unsigned high_halves(unsigned lo_word, unsigned hi_word) {
+    return __builtin_amdgcn_perm(hi_word, lo_word, 0x07060302u);
+}
+// 16-byte global load that does not displace what the caches hold (streamed-once operands)
+__device__ __forceinline__ f32x4 load_stream(const f32x4* p) { return __builtin_nontemporal_load(p); }
+
 __device__ __forceinline__ float shfl(float v, int src_lane) { return __shfl(v, src_lane, 64); }
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float shfl_up(float v, int delta) { return __shfl_up(v, delta, 64); }

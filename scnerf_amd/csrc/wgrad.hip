@@ -12,6 +12,7 @@
 // whole [BN x BK] output for a contiguous chunk of samples, staging 16 samples at a time through
 // double-buffered LDS; partial results go to a workspace and a second kernel reduces them in a
 // fixed order (deterministic; 64 MB per 256x256 layer at 256 chunks is ~25 us of HBM time).
+#include <cstdlib>
 #include <type_traits>
 
 #include <scn_wave.h>
@@ -20,6 +21,7 @@
 #include "mlp_common.h"
 #include "scnerf_hip.h"
 #include "wgrad256.h"
+#include "wgrad256_split.h"
 #include "wgrad_tiles.h"
 
 namespace {
@@ -356,8 +358,26 @@ int launch_wgrad(const WgradArgs& a, int G, hipStream_t stream) {
 
 
 
-// the 256 x 256 tile-native GEMMs of a pass in one launch, grid (chunks, jobs) (wgrad256.h)
+// How the 256 x 256 GEMMs multiply: 1 = on the bf16 matrix pipe with every fp32 operand cut exactly into
+// three bf16 numbers and six of the nine partial products kept (wgrad256_split.h; error vs fp64 equal to the
+// exact-fp32 MFMA kernel's, ~1.5x faster), 0 = v_mfma_f32_32x32x2_f32 (wgrad256.h).  Process-wide;
+// SCNERF_WGRAD_ARITHMETIC=fp32 | split presets it, scnerf_wgrad_arithmetic() changes it.
+int& wgrad_arithmetic() {
+    static int mode = [] {
+        const char* e = getenv("SCNERF_WGRAD_ARITHMETIC");
+        return (e && (e[0] == 'f' || e[0] == '0')) ? 0 : 1;
+    }();
+    return mode;
+}
+
+// the 256 x 256 tile-native GEMMs of a pass in one launch, grid (chunks, jobs)
 int launch_wgrad256(const wg256::Args& a, int G, hipStream_t stream) {
+    if (wgrad_arithmetic() == 1) {
+        SCN_LDS_OPT_IN((wg256s::wgrad256_split_kernel<0>), wg256s::kLdsBytes);
+        hipLaunchKernelGGL((wg256s::wgrad256_split_kernel<0>), dim3(G, a.n_jobs), dim3(wg256s::kThreads),
+                           wg256s::kLdsBytes, stream, a);
+        return scn_launch_status();
+    }
     constexpr int F = wg256::kSpread;
     SCN_LDS_OPT_IN((wg256::wgrad256_kernel<F>), wg256::kLdsBytes);
     hipLaunchKernelGGL((wg256::wgrad256_kernel<F>), dim3(G, a.n_jobs), dim3(wg256::kThreads), wg256::kLdsBytes, stream, a);
@@ -564,7 +584,12 @@ extern "C" int scnerf_nerf_wgrad(int pt_dims, const float* save, const float* gr
     return nerf_wgrad<4>(save, grads, d_raw, n_samples, n_chunks, workspace, flat_grad, accumulate, stream);
 }
 
-extern "C" long long scnerf_nerf_wgrad_workspace_floats(int n_chunks) {
+extern "C" int scnerf_wgrad_arithmetic(int mode) {
+    if (mode == 0 || mode == 1) wgrad_arithmetic() = mode;
+    return wgrad_arithmetic();
+}
+
+long long scnerf_nerf_wgrad_workspace_floats(int n_chunks) {
     // every GEMM keeps its partials until the single reduction launch: 9 x (256 x 256), 2 x (256 x 128 | 64),
     // (128 x 256), (128 x 64), (64 x 128) blocks + the vecmat partials
     const long long G = n_chunks;

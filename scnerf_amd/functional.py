@@ -108,22 +108,24 @@ class RenderRaysFunction(torch.autograd.Function):
         return (rgb_f, disp_f, acc_f, depth_f, raw_f, rgb_c, disp_c, acc_c, depth_c, z_std, z_f, z_s)
 
     @staticmethod
-    def _stage_backward(stage, rays, spr, wbk, white_bkgd, g_rgb, g_disp, g_acc, g_depth, g_raw, d_rays,
-                        accumulate, into=None):
-        """`into`: the network's attached flat .grad buffer -- the weight gradients are ADDED to it and
-        None is returned (nothing for autograd to accumulate); otherwise a fresh flat gradient."""
+    def _stage_dgrad(stage, rays, spr, wbk, white_bkgd, g_rgb, g_disp, g_acc, g_depth, g_raw, d_rays, accumulate):
+        """Data gradients of one stage (compositing, network, rays); -> what its weight gradients need."""
         z, pts, raw, noise, save = stage
-        n = z.shape[0]
         d_raw, d_rd = ops.composite_bwd(raw, z, rays, noise, white_bkgd, _c(g_rgb), _c(g_disp), _c(g_acc),
                                         _c(g_depth), _c(g_raw))
         grads, d_pts, d_views = ops.mlp_bwd(d_raw, pts, rays[:, 8:11], spr, wbk, save)
-        if into is not None:
-            ops.nerf_wgrad(save, grads, d_raw, n * spr, flat_grad=into, accumulate=True)
-            flat_grad = None
-        else:
-            flat_grad = ops.nerf_wgrad(save, grads, d_raw, n * spr)
         ops.ray_reduce(d_pts, d_views, z, d_rd, d_rays, accumulate)
-        return flat_grad
+        return save, grads, d_raw, z.shape[0] * spr
+
+    @staticmethod
+    def _stage_wgrad(pending, into=None):
+        """`into`: the network's attached flat .grad buffer -- the weight gradients are ADDED to it and
+        None is returned (nothing for autograd to accumulate); otherwise a fresh flat gradient."""
+        save, grads, d_raw, P = pending
+        if into is not None:
+            ops.nerf_wgrad(save, grads, d_raw, P, flat_grad=into, accumulate=True)
+            return None
+        return ops.nerf_wgrad(save, grads, d_raw, P)
 
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, g_depth, g_raw, g_rgb0, g_disp0, g_acc0, g_depth0, *_unused):
@@ -140,18 +142,25 @@ class RenderRaysFunction(torch.autograd.Function):
         need = ctx.needs_input_grad[8:]
         into_c = ctx.net_c.attached_flat_grad() if all(need[:n_pc]) else None
         into_f = into_c if ctx.net_f is None else (ctx.net_f.attached_flat_grad() if all(need[n_pc:]) else None)
+        # Both stages' data gradients first, then both stages' weight gradients: the 256 x 256 weight-gradient
+        # GEMMs run on the bf16 matrix pipe at a lower shader clock, and the kernel that follows them inherits
+        # that clock for ~0.3 ms -- adjacent, the two passes cost one such recovery per step instead of two.
+        pend_f = pend_c = None
         if sf > 0:
             if any(g is not None for g in (g_rgb, g_disp, g_acc, g_depth, g_raw)):
-                fg_f = RenderRaysFunction._stage_backward(ctx.fine, rays, sc + sf, ctx.wb_f, cfg.white_bkgd,
-                                                          g_rgb, g_disp, g_acc, g_depth, g_raw, d_rays, wrote,
-                                                          into=into_f)
+                pend_f = RenderRaysFunction._stage_dgrad(ctx.fine, rays, sc + sf, ctx.wb_f, cfg.white_bkgd,
+                                                         g_rgb, g_disp, g_acc, g_depth, g_raw, d_rays, wrote)
                 wrote = True
             coarse_g = (g_rgb0, g_disp0, g_acc0, g_depth0, None)
         else:
             coarse_g = (g_rgb, g_disp, g_acc, g_depth, g_raw)
         if any(g is not None for g in coarse_g):
-            fg_c = RenderRaysFunction._stage_backward(ctx.coarse, rays, sc, ctx.wb_c, cfg.white_bkgd,
-                                                      *coarse_g, d_rays, wrote, into=into_c)
+            pend_c = RenderRaysFunction._stage_dgrad(ctx.coarse, rays, sc, ctx.wb_c, cfg.white_bkgd,
+                                                     *coarse_g, d_rays, wrote)
+        if pend_f is not None:
+            fg_f = RenderRaysFunction._stage_wgrad(pend_f, into=into_f)
+        if pend_c is not None:
+            fg_c = RenderRaysFunction._stage_wgrad(pend_c, into=into_c)
         if sf > 0 and ctx.net_f is None and fg_f is not None:
             # one network serves both stages (reference :279): its gradient is the sum
             fg_c = fg_f if fg_c is None else fg_c + fg_f

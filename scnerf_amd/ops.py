@@ -297,6 +297,13 @@ def wgrad_chunks(P: int) -> int:
 _wgrad_ws = {}
 
 
+def wgrad_arithmetic(mode: Optional[str] = None) -> str:
+    """"split" (default): the 256 x 256 weight-gradient GEMMs run on the bf16 matrix pipe with exactly cut fp32
+    operands (csrc/wgrad256_split.h); "fp32": on the exact-fp32 MFMA.  Without an argument: the mode in force."""
+    code = {None: -1, "fp32": 0, "split": 1}[mode]
+    return ("fp32", "split")[_capi.load().scnerf_wgrad_arithmetic(code)]
+
+
 def nerf_wgrad(save: Tensor, grads: Tensor, d_raw: Tensor, P: int, flat_grad: Optional[Tensor] = None,
                pd: int = 3, accumulate: bool = False) -> Tensor:
     """All parameter gradients of one network -> flat buffer (mlp_layout.Layout parameter order);

@@ -55,6 +55,8 @@ static inline long min(long a, long b) { return a < b ? a : b; }
 static inline long max(long a, long b) { return a > b ? a : b; }
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+static inline float __uint_as_float(unsigned i) { float f; std::memcpy(&f, &i, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned i; std::memcpy(&i, &f, 4); return i; }
 using std::pow;
 using std::sqrt;
 struct alignas(16) float4 { float x, y, z, w; };

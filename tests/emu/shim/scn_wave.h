@@ -36,6 +36,53 @@ inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
     return c;
 }
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+inline float bf16_bits_to_float(short h) {
+    const uint32_t u = (uint32_t)(uint16_t)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+// v_mfma_f32_32x32x16_bf16: lane l gives A[l&31][8 (l>>5) .. +7], B[8 (l>>5) .. +7][l&31]; the sixteen
+// products (exact in fp32) are summed here in double and added to C with one rounding.
+inline f32x16 mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
+    uint64_t mine[4];
+    std::memcpy(&mine[0], &a, 16);
+    std::memcpy(&mine[2], &b, 16);
+    uint64_t all[4][64];
+    for (int w = 0; w < 4; ++w) {
+        const uint64_t* x = simt::wave_exchange(mine[w]);
+        std::memcpy(all[w], x, sizeof(all[w]));
+    }
+    auto elem = [&](int word0, int lane, int k) {          // element k (0..7) of lane's operand
+        const uint64_t u = all[word0 + (k >> 2)][lane];
+        return bf16_bits_to_float((short)(uint16_t)(u >> (16 * (k & 3))));
+    };
+    const int l = simt::cur_lane();
+    const int j = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        double sum = 0.0;
+        for (int k = 0; k < 16; ++k) sum += (double)elem(0, i + 32 * (k >> 3), k & 7) * (double)elem(2, j + 32 * (k >> 3), k & 7);
+        c[r] = (float)((double)c[r] + sum);
+    }
+    return c;
+}
+// ds_read_b64_tr_b16: lane c of a 16-lane group names row c >> 2, columns 4 (c & 3) .. +3 of the group's
+// [4][16] block and receives column c
+inline s16x4 lds_read_tr16(const short* p) {
+    uint64_t mine;
+    std::memcpy(&mine, p, 8);
+    const uint64_t* x = simt::wave_exchange(mine);
+    const int l = simt::cur_lane(), base = l & ~15, c = l & 15;
+    s16x4 out;
+    for (int row = 0; row < 4; ++row) out[row] = (short)(uint16_t)(x[base + 4 * row + (c >> 2)] >> (16 * (c & 3)));
+    return out;
+}
+inline unsigned high_halves(unsigned lo_word, unsigned hi_word) { return (lo_word >> 16) | (hi_word & 0xffff0000u); }
+inline f32x4 load_stream(const f32x4* p) { return *p; }
+
 template <typename T>
 inline T exchange_read(T v, int src) {
     static_assert(sizeof(T) <= 8, "");

@@ -167,3 +167,47 @@ def test_mlp_backward_and_weight_gradients_match_autograd(ops, pd):
     for name, shape in lay.param_shapes:
         o = lay.param_offsets[name]
         grad_close(fg[o:o + int(np.prod(shape))].reshape(shape), p[name].grad.numpy(), name, q=0.99, tol_q=2e-3)
+
+
+def test_split_weight_gradient_gemm_is_fp32_grade(ops):
+    """The 256 x 256 weight-gradient GEMM on the bf16 matrix pipe (operands cut exactly into three bf16 numbers, six
+    partial products; csrc/wgrad256_split.h) against fp64, beside the exact-fp32 MFMA kernel on the same
+    operands: full 24-bit significands, magnitudes spread over 2^8, half of X zero (post-ReLU).  The split
+    kernel's error must be the fp32 kernel's (accumulation-order noise), not a reduced-precision one
+    (a plain bf16 product would be at 4e-3, a two-term split at 1e-5 of sum |a b|)."""
+    from scnerf_amd import _capi
+    from tests import parity_attribution as PA
+    lib = _capi.load()
+    P, chunks = 65536, 256
+    g = torch.Generator(device="cuda").manual_seed(3)
+    def operand(relu):
+        v = torch.randn(P, 256, device="cuda", generator=g) * torch.exp2(torch.randint(-4, 4, (P, 256), device="cuda", generator=g).float())
+        if relu:
+            v = v * (torch.rand(P, 256, device="cuda", generator=g) < 0.5)
+        return v.contiguous()
+    A, B = operand(False), operand(True)
+    tiled = lambda m: m.reshape(P // 32, 32, 8, 4, 2, 4).permute(0, 2, 3, 4, 1, 5).contiguous().reshape(-1)
+    At, Bt = tiled(A), tiled(B)
+    ref = A.double().T @ B.double()
+    scale = A.double().abs().T @ B.double().abs()
+    ws = torch.empty(lib.scnerf_wgrad_workspace_floats(256, 256, chunks), device="cuda")
+    err, out = {}, {}
+    try:
+        for mode in ("fp32", "split"):
+            assert ops.wgrad_arithmetic(mode) == mode
+            dW = torch.full((256, 256), float("nan"), device="cuda")
+            db = torch.full((256,), float("nan"), device="cuda")
+            _capi.check(lib.scnerf_wgrad(ops._p(At), 256, 256, 256, 1, ops._p(Bt), 256, 256, 256, 1, P, chunks, ops._p(ws),
+                                         ops._p(dW), 256, 0, ops._p(db), ops._stream()), "scnerf_wgrad")
+            e = (dW.double() - ref).abs() / scale
+            err[mode] = {"max": float(e.max()), "rms": float((e * e).mean().sqrt())}
+            out[mode] = dW
+            np.testing.assert_allclose(db.cpu().numpy(), A.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    finally:
+        ops.wgrad_arithmetic("split")
+    assert ops.wgrad_arithmetic() == "split"
+    PA.REPORT["wgrad256_arithmetic_65536_samples"] = {
+        "error_over_sum_abs_products_vs_fp64": err,
+        "max_difference_between_the_two_over_sum_abs_products": float(((out["split"] - out["fp32"]).double().abs() / scale).max())}
+    assert err["split"]["max"] <= 1.5 * err["fp32"]["max"] + 1e-9 and err["split"]["max"] < 2e-7, err
+    assert err["split"]["rms"] <= 2.0 * err["fp32"]["rms"], err

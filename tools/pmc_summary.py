@@ -30,7 +30,7 @@ def main():
           "FETCH_SIZE / WRITE_SIZE are KB; FETCH_SIZE under-reports wide coalesced reads by 2x;")
     print("# GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles per XCD = value / 8.")
     for k in sorted(agg):
-        if not any(x in k for x in KEEP):
+        if not os.environ.get("KEEP_ALL") and not any(x in k for x in KEEP):
             continue
         du = dur[k]
         print("\n== %s   dispatches seen: %d   duration us: mean %.1f min %.1f max %.1f" % (
