@@ -29,6 +29,9 @@ sys.path.insert(0, ROOT)
 FLOP_PER_SAMPLE_FWD = 2 * 593408
 S_C, S_F = 64, 128
 PEAK_F32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0            # ibid., dense bf16
+# the weight-gradient GEMMs in "split" arithmetic spend 6 bf16 MFMA products per fp32 product
+PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
 
 def cpu_baseline(n_rays, iters=3):
@@ -95,9 +98,20 @@ IMG_H, IMG_W, N_CAMS = 378, 504, 17      # LLFF 'fern' at factor 8: the image si
 
 
 def _kernel_table(kern, steps):
-    return {k: {"avg_ms": v["avg_ms"], "launches_per_step": v["launches"] / steps,
-                "tflops": v["flop_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12 if v["flop_per_launch"] else None}
-            for k, v in kern.items()}
+    """tflops = algorithmic fp32 FLOP / time; `peak` names the matrix-pipe ceiling of the arithmetic the entry
+    runs in (the wgrad group: 8 of its 12 GEMMs, 87 % of its FLOPs, are the 256 x 256 ones)"""
+    from scnerf_amd import ops
+    split = ops.wgrad_arithmetic() == "split"
+    out = {}
+    for k, v in kern.items():
+        e = {"avg_ms": v["avg_ms"], "launches_per_step": v["launches"] / steps,
+             "tflops": v["flop_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12 if v["flop_per_launch"] else None}
+        if e["tflops"]:
+            on_split = split and k.startswith("wgrad(")
+            e["peak"] = PEAK_SPLIT_TFLOPS if on_split else PEAK_F32_MFMA_TFLOPS
+            e["pipe"] = "bf16 MFMA x6 (fp32 operands cut into 3 bf16, fp32 accumulate)" if on_split else "fp32 MFMA"
+        out[k] = e
+    return out
 
 
 def _timed(step, steps, warmup, sync, profile=True):
@@ -237,6 +251,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=512)
     ap.add_argument("--camera", action="store_true", help="rays from the learnable camera model also at N = 1")
+    ap.add_argument("--wgrad-arithmetic", choices=("split", "fp32"), default=None,
+                    help="256 x 256 weight-gradient GEMMs: bf16 matrix pipe with exactly cut fp32 operands (default) "
+                         "or the exact-fp32 MFMA")
     ap.add_argument("--backend", default=os.environ.get("SCNERF_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend (nccl = RCCL; gloo for a functional check of N ranks on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0 (functional check, with --backend gloo)")
@@ -261,6 +278,8 @@ def main():
     from scnerf_amd import ops
     from scnerf_amd.parallel import FlatGradAllReduce
     ops.check_layout()
+    if a.wgrad_arithmetic:
+        ops.wgrad_arithmetic(a.wgrad_arithmetic)
     n = a.rays
     w = build_world(dev, rank, n)
     with_camera = a.camera or world > 1
@@ -317,6 +336,13 @@ def main():
             "metric": "rays/sec (64+128 samples/ray) train-step", "value": n * world / (ms * 1e-3),
             "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "arithmetic": {
+                "forward, data gradients, narrow weight gradients": "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32",
+                "256x256 weight gradients": (
+                    "fp32 operands cut EXACTLY into 3 bf16 numbers each, 6 of the 9 partial products on "
+                    "v_mfma_f32_32x32x16_bf16, fp32 accumulate; error vs fp64 = the fp32 MFMA kernel's "
+                    "(profiles/parity_r02.json wgrad256_arithmetic_*; --wgrad-arithmetic fp32 selects the latter)")
+                if ops.wgrad_arithmetic() == "split" else "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32"},
             "data": "synthetic",
             "config": {"workload": "configs[1]: %d rays x (64 coarse + 128 fine), coarse+fine NeRF (D=8, W=256), "
                                    "fwd+bwd of render_rays per GPU, perturb=1, raw_noise_std=1; %s" % (n, source),

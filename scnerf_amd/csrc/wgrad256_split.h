@@ -16,18 +16,33 @@
 // piece (t, q, lane = m + 32 h) = features 32 t + 8 q + 4 h .. +3 of sample m).  A workgroup (2 x 2 waves, one per
 // SIMD) owns the 256 x 256 output of one job for a contiguous chunk of samples and walks it in slabs of 16
 // samples.  Staging: a thread loads 16-byte pieces (8 consecutive lanes = 8 samples of one piece column = one
-// 128-byte line), cuts them (4 VALU per float + 1 v_perm per pair) and writes the three planes with
-// ds_write_b64 into a row-major LDS image [16 samples][Ah Am Al Bh Bm Bl, 256 bf16 each | 32 pad].  The MFMA
-// wants, per lane, 8 SAMPLES of one feature: the transpose is the LDS read, ds_read_b64_tr_b16 (each 16-lane
-// group fetches a [4 samples][16 features] block and hands lane c column c).  The row stride of 3136 bytes
-// = 64 (mod 256) puts the 4 rows x 64 bytes a 32-lane half reads on 64 distinct banks; the staging writes of a
-// wave (8 samples x 8 pieces) fall on 2 x 16 banks four deep, the floor for 512 bytes.
+// 128-byte line), cuts them (and / sub / and / sub per float, one v_perm per pair and plane) and writes the three
+// planes with ds_write_b64 into an LDS image [16 samples][Ah Am Al Bh Bm Bl, 256 bf16 each].  The MFMA wants, per
+// lane, 8 SAMPLES of one feature: the transpose is the LDS read, ds_read_b64_tr_b16 (each 16-lane group
+// fetches a [4 samples][16 features] block and hands lane c column c).
 //
-// Schedule of one slab (96 MFMAs): products in the order (Ah Bh)(Am Bh)(Al Bh)(Ah Bm)(Ah Bl)(Am Bm); the
-// operand planes not yet in registers are read in the phase before they are needed; the NEXT slab is cut and
-// committed to the other LDS buffer during phases 0-3, one barrier, and its Bh / Ah are read in phases 4-5,
-// where the global loads for the slab three ahead are issued too (two staging register sets: a load has
-// eight phases = 4096 cycles to land).  ~3 non-MFMA instructions per 32-cycle MFMA.
+// LDS image, chosen so that both access patterns are conflict-free (SQ_LDS_BANK_CONFLICT: 60 % of the LDS
+// cycles with a plain padded [16][1536 + 32] image):
+//   row (sample) m at m * 3104 bytes, +16 bytes for m & 4: 3104 = 32 (mod 256), so the 4 rows of a transposing
+//   read sit 32 bytes apart modulo 256;
+//   inside a plane the 16-feature block b = f >> 4 sits at ((b >> 1) & 3) * 32 + (b >> 3) * 256 + (b & 1) * 128
+//   bytes: the two halves of a 32-feature tile, read by the two 16-lane groups of a lane half, are 128 bytes
+//   apart -- a 32-lane half touches 8 distinct 32-byte bank groups;
+//   a staging write of 16 lanes (8 samples x 2 pieces) covers {0,32,64,96} + {0,16} + {0,8}: all 32 write banks.
+//
+// Schedule.  One slab = 96 MFMA slots, products in the order (Ah Bh)(Am Bh)(Al Bh)(Ah Bm)(Ah Bl)(Am Bm) so that
+// Bh is free after the third and Ah after the fifth: the next slab's Bh / Ah are read under the last two
+// products.  Fillers by slot g (r = g mod 12): the 56 cut steps (8 pieces x 7) of the slab TWO ahead, written
+// into LDS buffer (s + 2) mod 3, on r = 0 1 3 5 6 8 10; the 48 operand reads on r = 2 3 4 7 9 11 (8 per product =
+// the plane the next product needs); the reload of the piece just cut (slab s + 4, two staging register sets:
+// 2 slabs = ~6000 cycles to land) on r = 8: at most 5 instructions between two MFMAs, one barrier per slab.
+//
+// Measured (tools/ubench/wgrad_split_lab.hip, P = 786 432, per GEMM): 0.48 ms against 0.72 ms for wgrad256.h
+// (1.5x; 215 "fp32 TFLOP/s").  The kernel is POWER-bound, not issue-bound: the matrix pipe is busy 83-90 % of
+// the cycles, but the shader clock drops from 2.37 GHz (fp32 MFMA) to 1.65-1.9 GHz under bf16 MFMAs at this
+// density (profiles/r02c_split_lab_pmc.txt), and neither removing the LDS conflicts nor a burstier / smoother
+// filler schedule moved the time; MFMAs + operand reads alone take 0.35 ms.  v_pk_add_f32 for the cut's
+// subtractions: 3 % slower.  All nine products instead of six: same error, 0.64 ms.
 #pragma once
 #include <type_traits>
 
