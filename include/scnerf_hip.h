@@ -233,6 +233,21 @@ int scnerf_vecmat(const float* x_tiled256, const float* vec, int vec_stride, lon
  * scnerf_mlp_fwd (save) and scnerf_mlp_bwd (grads) and d_raw [n_samples, 4].  workspace:
  * scnerf_nerf_wgrad_workspace_floats(n_chunks) floats. */
 int scnerf_nerf_param_count(int pt_dims);
+/* The 256 -> 256 trunk layers of the network (layers 1 .. 7 and feature_linear = 8; layer 5 with the skip input
+ * [encoded point | h]: NeRF/run_nerf_helpers.py:92-103, :105-128) as per-layer GEMMs over all samples on the bf16
+ * matrix pipe in the "split" arithmetic of scnerf_wgrad_arithmetic (every fp32 number cut exactly into three bf16,
+ * six partial products, fp32 accumulate).
+ * scnerf_pack_split_planes: flat parameters (reference order) -> the bf16 planes of those layers' weights in MFMA
+ *   fragment order, scnerf_split_planes_shorts(pt_dims) 16-bit words; once per optimizer step.
+ * scnerf_layer_split: act_out = act(W_layer act_in + b) for tile-native sections of width 256 (the layout of the
+ *   scnerf_mlp_fwd save workspace), epts = the saved encoded points [padded samples][64 | 128] (layer 5 only),
+ *   bias_table = the layer's lane-vector bias table inside the packed forward weights, mask = the layer's ReLU
+ *   bit section or NULL; layers < 8 apply ReLU. */
+long long scnerf_split_planes_shorts(int pt_dims);
+int scnerf_pack_split_planes(int pt_dims, const float* flat_params, short* planes, void* stream);
+int scnerf_layer_split(int pt_dims, int layer, const short* planes, const float* bias_table, const float* act_in,
+                       const float* epts, float* act_out, unsigned* mask, long long n_samples, void* stream);
+
 /* Arithmetic of the 256 x 256 weight-gradient GEMMs (87 % of the weight-gradient FLOPs).  mode 1 (default):
  * bf16 matrix pipe, every fp32 operand cut exactly into three bf16 numbers, six partial products per product,
  * fp32 accumulation -- the error against fp64 equals the exact-fp32 kernel's; mode 0: v_mfma_f32_32x32x2_f32.

@@ -67,6 +67,8 @@ PROTOTYPES = {
     "scnerf_wgrad": [P, I, I, I, I, P, I, I, I, I, LL, I, P, P, I, I, P, P],
     "scnerf_vecmat": [P, P, I, LL, I, P, P, P, P],
     "scnerf_wgrad_arithmetic": [I],
+    "scnerf_pack_split_planes": [I, P, P, P],
+    "scnerf_layer_split": [I, I, P, P, P, P, P, P, LL, P],
 }
 
 
@@ -74,6 +76,7 @@ PROTOTYPES = {
 SIZE_FUNCS = {"scnerf_mlp_save_floats": [I, LL], "scnerf_mlp_grad_floats": [LL],
               "scnerf_wgrad_workspace_floats": [I, I, I],
               "scnerf_nerf_wgrad_workspace_floats": [I],
+              "scnerf_split_planes_shorts": [I],
               "scnerf_camera_bwd_workspace_floats": [I]}
 
 

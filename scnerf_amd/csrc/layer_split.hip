@@ -1,0 +1,129 @@
+// layer_split.hip -- the 256-wide trunk layers of the network as per-layer GEMMs on the bf16 matrix pipe at fp32
+// accuracy (layer_split.h), and the packing of their weights into bf16 planes.
+//
+// What it computes is nn.Linear (+ ReLU) of the reference network's trunk, layers 1 .. 7 and feature_linear
+// (/root/reference NeRF/run_nerf_helpers.py:92-103, :105-128), layer 5 with the skip input [encoded point | h].
+#include <scn_wave.h>
+
+#include "launch.h"
+#include "layer_split.h"
+#include "mlp_common.h"
+#include "scnerf_hip.h"
+
+namespace {
+
+using namespace scn;
+using namespace scn::mlp;
+
+// Plane buffer: the K slabs of layers l = 1 .. 8 (8 = feature_linear) one after the other; layer 5 has
+// 16 + kEW / 16 slabs (h part first, then the encoded point in torch column order, zero beyond kInCh).
+template <int PD>
+__host__ __device__ constexpr int skip_slabs() { return Var<PD>::kEW / 16; }
+template <int PD>
+__host__ __device__ constexpr int slab_offset(int l) {
+    return l <= 5 ? (l - 1) * 16 : 16 * (l - 1) + skip_slabs<PD>();
+}
+template <int PD>
+__host__ __device__ constexpr int total_slabs() { return slab_offset<PD>(8) + 16; }
+
+// one thread per (slab, feature tile T, lane, element e): the three planes of one weight
+template <int PD>
+__global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restrict__ params, short* __restrict__ out) {
+    using V = Var<PD>;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)total_slabs<PD>() * 8 * 64 * 8) return;
+    const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63), T = (int)((idx >> 9) & 7);
+    const int slab = (int)(idx >> 12);
+    int l = 1;
+#pragma unroll
+    for (int c = 2; c <= 8; ++c)
+        if (slab >= slab_offset<PD>(c)) l = c;
+    const int s = slab - slab_offset<PD>(l);
+    const int n = 32 * T + (lane & 31);
+    const int k = 16 * (s & 15) + 8 * (lane >> 5) + e;        // column inside the part
+    float w;
+    if (l == 8) {
+        w = params[V::kWF + n * 256 + k];
+    } else if (l == 5) {
+        // torch column order of the skip layer's input: [encoded point (kInCh) | h (256)]
+        if (s < 16) w = params[V::trunk_w(5) + n * V::kSkipLd + V::kInCh + k];
+        else {
+            const int c = 16 * (s - 16) + 8 * (lane >> 5) + e;
+            w = c < V::kInCh ? params[V::trunk_w(5) + n * V::kSkipLd + c] : 0.f;
+        }
+    } else {
+        w = params[V::trunk_w(l) + n * 256 + k];
+    }
+    const unsigned u = __float_as_uint(w);
+    const float d1 = w - __uint_as_float(u & 0xffff0000u);
+    const unsigned u1 = __float_as_uint(d1);
+    const float d2 = d1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned u2 = __float_as_uint(d2);
+    const long base = (((long)slab * 3) * 8 + T) * 64 * 8 + lane * 8 + e;
+    out[base] = (short)(u >> 16);
+    out[base + 8 * 64 * 8] = (short)(u1 >> 16);
+    out[base + 2 * 8 * 64 * 8] = (short)(u2 >> 16);
+}
+
+}  // namespace
+
+namespace scn {
+namespace lsp {
+
+int launch_layer(const Args& a, hipStream_t stream) {
+    SCN_LDS_OPT_IN((layer_split_kernel<0>), kLdsBytes);
+    const long n_blocks = (a.Ppad / 32 + 7) / 8;
+    constexpr long kCUs = 256;                 // MI355X: one persistent workgroup per CU (the kernel owns a SIMD per wave)
+    const unsigned G = (unsigned)(n_blocks < kCUs ? n_blocks : kCUs);
+    hipLaunchKernelGGL((layer_split_kernel<0>), dim3(G), dim3(kThreads), kLdsBytes, stream, a);
+    return scn_launch_status();
+}
+
+// layer l = 1 .. 8 of the network out of the plane buffer; act_in / act_out tile-native sections
+template <int PD>
+int launch_network_layer(int l, const short* planes, const float* bias_table, const float* act_in, const float* epts,
+                         float* act_out, unsigned* mask, long Ppad, hipStream_t stream) {
+    Args a;
+    a.X = act_in;
+    a.X2 = l == 5 ? epts : act_in;          // (a valid pointer either way: the select in load_x forms both addresses)
+    a.x2_ld = Var<PD>::kEW;
+    a.n_k = l == 5 ? 16 + skip_slabs<PD>() : 16;
+    a.W = planes + (long)slab_offset<PD>(l) * kSlabShorts;
+    a.bias = bias_table;
+    a.Z = act_out;
+    a.mask = mask;
+    a.Ppad = Ppad;
+    a.relu = l < 8;
+    return launch_layer(a, stream);
+}
+template int launch_network_layer<3>(int, const short*, const float*, const float*, const float*, float*, unsigned*, long, hipStream_t);
+template int launch_network_layer<4>(int, const short*, const float*, const float*, const float*, float*, unsigned*, long, hipStream_t);
+
+}  // namespace lsp
+}  // namespace scn
+
+extern "C" long long scnerf_split_planes_shorts(int pt_dims) {
+    if (pt_dims != 3 && pt_dims != 4) return -1;
+    return (long long)(pt_dims == 3 ? total_slabs<3>() : total_slabs<4>()) * scn::lsp::kSlabShorts;
+}
+
+extern "C" int scnerf_pack_split_planes(int pt_dims, const float* flat_params, short* planes, void* stream) {
+    SCN_RETURN_IF(!flat_params || !planes || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
+    const long n = (long)(pt_dims == 3 ? total_slabs<3>() : total_slabs<4>()) * 8 * 64 * 8;
+    if (pt_dims == 3)
+        hipLaunchKernelGGL(pack_planes_kernel<3>, dim3(scn_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, flat_params, planes);
+    else
+        hipLaunchKernelGGL(pack_planes_kernel<4>, dim3(scn_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, flat_params, planes);
+    return scn_launch_status();
+}
+
+extern "C" int scnerf_layer_split(int pt_dims, int layer, const short* planes, const float* bias_table, const float* act_in,
+                                  const float* epts, float* act_out, unsigned* mask, long long n_samples, void* stream) {
+    SCN_RETURN_IF(!planes || !bias_table || !act_in || !act_out || n_samples < 0, SCN_EINVAL);
+    SCN_RETURN_IF((pt_dims != 3 && pt_dims != 4) || layer < 1 || layer > 8 || (layer == 5 && !epts), SCN_EINVAL);
+    if (n_samples == 0) return 0;
+    const long Ppad = padded_samples(n_samples);
+    hipStream_t st = (hipStream_t)stream;
+    return pt_dims == 3 ? scn::lsp::launch_network_layer<3>(layer, planes, bias_table, act_in, epts, act_out, mask, Ppad, st)
+                        : scn::lsp::launch_network_layer<4>(layer, planes, bias_table, act_in, epts, act_out, mask, Ppad, st);
+}

@@ -1,0 +1,74 @@
+"""The per-layer split-arithmetic GEMM (csrc/layer_split.h, under the CPU SIMT interpreter) against the fused
+forward kernel's own saved activations: for every trunk layer 1 .. 7 and feature_linear, feeding the activation
+section the fused kernel saved for layer l - 1 must reproduce the section it saved for layer l (and its ReLU bit
+words, wherever the pre-activation is not within rounding of zero)."""
+import numpy as np
+import pytest
+import torch
+
+from scnerf_amd import mlp_layout as ML
+from tests.emu import harness as H
+from tests.emu_mlp_util import flat_params, network_params, pack_forward, save_views
+
+pytestmark = pytest.mark.emu
+
+
+def _forward_with_save(pd, P, n_rays, spr, seed):
+    p = network_params(seed, pd)
+    wpk = pack_forward(p, pd)
+    g = torch.Generator().manual_seed(seed)
+    pts = (torch.rand(P, pd, generator=g) * 2.4 - 1.2).numpy()
+    vd = torch.randn(n_rays, 3, generator=g)
+    vd = (vd / vd.norm(dim=-1, keepdim=True)).numpy()
+    raw = np.zeros((P, 4), np.float32)
+    save = np.full(ML.layout(pd).save_floats(P), np.nan, np.float32)
+    H.call("scnerf_mlp_fwd", pd, pts, vd, 3, spr, wpk, raw, save, P, None)
+    return p, wpk, save
+
+
+@pytest.mark.parametrize("pd,n_rays,spr", [(3, 3, 50), (4, 2, 70), (3, 9, 40)])
+def test_layers_reproduce_the_fused_kernels_activations(pd, n_rays, spr):
+    lay = ML.layout(pd)
+    P = n_rays * spr
+    p, wpk, save = _forward_with_save(pd, P, n_rays, spr, 11 + pd)
+    Pp = ML.padded_samples(P)
+    off, total = ML.section_offsets(lay.save_sections, P)
+    n_planes = H.lib().scnerf_split_planes_shorts(pd)
+    assert n_planes > 0 and H.lib().scnerf_split_planes_shorts(5) < 0
+    planes = np.zeros(n_planes, np.int16)
+    H.call("scnerf_pack_split_planes", pd, flat_params(p, pd), planes, None)
+    views = save_views(save, P, pd)
+    names = ["act%d" % l for l in range(8)] + ["feat"]
+    epts = save[off["epts"]: off["epts"] + lay.e_width * Pp]
+    for l in range(1, 9):
+        src = save[off[names[l - 1]]: off[names[l - 1]] + 256 * Pp].copy()
+        src[np.isnan(src)] = 0.0                              # pad samples the fused kernel never wrote
+        out = np.full(256 * Pp, np.nan, np.float32)
+        mask = np.zeros((Pp // 32) * 256, np.uint32)
+        bias = wpk[(lay.fwd_bias + 256 * l) if l < 8 else lay.fwd_bias_f:][:256].copy()
+        ep = epts.copy()
+        ep[np.isnan(ep)] = 0.0
+        H.call("scnerf_layer_split", pd, l, planes, bias, src, ep, out, mask if l < 8 else None, P, None)
+        got = ML.untile(out, 256, P)
+        ref = views[names[l]]
+        np.testing.assert_allclose(got, ref, rtol=2e-6, atol=2e-6, err_msg="layer %d" % l)
+        if l < 8:
+            # bits: element i = 16 t + r of a lane sits in word i >> 5 at bit 31 - (i & 31); compare where the
+            # activation is clearly off zero on both sides
+            tiles = (P + 31) // 32
+            want = views["mask"][l].reshape(-1)[: tiles * 256].reshape(tiles, 64, 4)
+            have = mask[: tiles * 256].reshape(tiles, 64, 4)
+            sample = np.arange(tiles)[:, None] * 32 + (np.arange(64)[None, :] & 31)
+            live = sample < P                                  # (pad lanes carry whatever their inputs were)
+            differ = np.unpackbits((have ^ want)[live].view(np.uint8)).sum()
+            near_zero = int((np.abs(ref) < 1e-6).sum() - (ref == 0).sum())
+            assert differ <= near_zero, (l, differ, near_zero)
+
+
+def test_layer_split_rejects_bad_arguments():
+    z = np.zeros(8, np.float32)
+    s = np.zeros(8, np.int16)
+    lib = H.lib()
+    assert lib.scnerf_layer_split(3, 0, H.ptr(s), H.ptr(z), H.ptr(z), None, H.ptr(z), None, 32, None) < 0
+    assert lib.scnerf_layer_split(3, 5, H.ptr(s), H.ptr(z), H.ptr(z), None, H.ptr(z), None, 32, None) < 0     # skip layer needs epts
+    assert lib.scnerf_layer_split(3, 2, H.ptr(s), H.ptr(z), H.ptr(z), None, H.ptr(z), None, 0, None) == 0      # nothing to do
