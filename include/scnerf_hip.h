@@ -243,7 +243,18 @@ int scnerf_nerf_param_count(int pt_dims);
  *   scnerf_mlp_fwd save workspace), epts = the saved encoded points [padded samples][64 | 128] (layer 5 only),
  *   bias_table = the layer's lane-vector bias table inside the packed forward weights, mask = the layer's ReLU
  *   bit section or NULL; layers < 8 apply ReLU. */
+/* scnerf_mlp_fwd_split / scnerf_coarse_stage_fwd_split: the training forward (save != NULL) of scnerf_mlp_fwd /
+ * scnerf_coarse_stage_fwd with the eight 256-wide layers run as such GEMMs between the encoding + layer 0 and the
+ * heads, which stay on the fused fp32-MFMA kernel; same arguments plus `planes`, same outputs, same workspace. */
 long long scnerf_split_planes_shorts(int pt_dims);
+int scnerf_mlp_fwd_split(int pt_dims, const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
+                         const float* wpacked, const short* planes, float* raw, float* save, long long n_samples,
+                         void* stream);
+int scnerf_coarse_stage_fwd_split(const float* rays, int ray_stride, const float* t_vals, const float* t_rand,
+                                  int lindisp, const float* wpacked, const short* planes, float* save,
+                                  const float* noise, int white_bkgd, float* z, float* pts, float* raw,
+                                  float* rgb_map, float* disp_map, float* acc_map, float* depth_map, float* weights,
+                                  int n_rays, int n_samples, void* stream);
 int scnerf_pack_split_planes(int pt_dims, const float* flat_params, short* planes, void* stream);
 int scnerf_layer_split(int pt_dims, int layer, const short* planes, const float* bias_table, const float* act_in,
                        const float* epts, float* act_out, unsigned* mask, long long n_samples, void* stream);

@@ -70,13 +70,17 @@ class RenderRaysFunction(torch.autograd.Function):
         flat_c = net_c.flat_parameters()
         wf_c = ops.pack_weights(flat_c, "fwd")
         save_c = ops.save_workspace(n * sc, dev) if train else None
+        # training forward with the 256-wide layers as split-arithmetic GEMMs (ops.mlp_arithmetic)
+        split = train and n > 0 and ops.mlp_arithmetic() == "split"
+        pl_c = ops.pack_planes(flat_c) if split else None
         if sc == ops.COARSE_STAGE_SAMPLES and n > 0:
             # the whole coarse stage -- stratified depths, network, compositing -- is one launch
             z_c, pts_c, raw_c, rgb_c, disp_c, acc_c, w_c, depth_c = ops.coarse_stage_fwd(
-                rays, host_linspace(sc, dev), _c(t_rand), cfg.lindisp, wf_c, save_c, _c(noise_c), cfg.white_bkgd)
+                rays, host_linspace(sc, dev), _c(t_rand), cfg.lindisp, wf_c, save_c, _c(noise_c), cfg.white_bkgd,
+                planes=pl_c)
         else:
             z_c, pts_c = ops.coarse_sample(rays, host_linspace(sc, dev), _c(t_rand), cfg.lindisp)
-            raw_c = ops.mlp_fwd(pts_c, viewdirs, sc, wf_c, save_c).view(n, sc, 4)
+            raw_c = ops.mlp_fwd(pts_c, viewdirs, sc, wf_c, save_c, planes=pl_c).view(n, sc, 4)
             rgb_c, disp_c, acc_c, w_c, depth_c = ops.composite_fwd(raw_c, z_c, rays, _c(noise_c), cfg.white_bkgd)
 
         ctx.cfg, ctx.train, ctx.n = cfg, train, n
@@ -99,7 +103,8 @@ class RenderRaysFunction(torch.autograd.Function):
         flat_f = fine_net.flat_parameters()
         wf_f = wf_c if fine_net is net_c else ops.pack_weights(flat_f, "fwd")
         save_f = ops.save_workspace(n * tot, dev) if train else None
-        raw_f = ops.mlp_fwd(pts_f, viewdirs, tot, wf_f, save_f).view(n, tot, 4)
+        pl_f = (pl_c if fine_net is net_c else ops.pack_planes(flat_f)) if split else None
+        raw_f = ops.mlp_fwd(pts_f, viewdirs, tot, wf_f, save_f, planes=pl_f).view(n, tot, 4)
         rgb_f, disp_f, acc_f, _, depth_f = ops.composite_fwd(raw_f, z_f, rays, _c(noise_f), cfg.white_bkgd,
                                                              want_weights=False)
         ctx.fine = (z_f, pts_f, raw_f, _c(noise_f), save_f)

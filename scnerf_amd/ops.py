@@ -6,6 +6,8 @@ from __future__ import annotations
 from typing import Optional
 
 import numpy as np
+import os
+
 import torch
 
 from . import _capi
@@ -192,6 +194,36 @@ def pack_weights(flat_params: Tensor, kind: str = "fwd", out: Optional[Tensor] =
     return out
 
 
+_MLP_ARITHMETIC = [os.environ.get("SCNERF_MLP_ARITHMETIC", "fp32")]
+
+
+def mlp_arithmetic(mode: Optional[str] = None) -> str:
+    """How the TRAINING forward runs the eight 256-wide layers (trunk 1 .. 7, feature_linear): "fp32" -- inside the
+    fused kernel on the exact-fp32 MFMA; "split" -- as per-layer GEMMs on the bf16 matrix pipe with exactly cut
+    fp32 operands (csrc/layer_split.h), between the fused kernel's first stage (encoding, layer 0) and its heads.
+    Without an argument: the mode in force.  Environment preset: SCNERF_MLP_ARITHMETIC."""
+    if mode is not None:
+        if mode not in ("fp32", "split"):
+            raise ValueError("mlp_arithmetic is 'fp32' or 'split'")
+        _MLP_ARITHMETIC[0] = mode
+    return _MLP_ARITHMETIC[0]
+
+
+def pack_planes(flat_params: Tensor, pd: int = 3, out: Optional[Tensor] = None) -> Tensor:
+    """flat parameter buffer (reference order) -> bf16 planes of the 256-wide layers in MFMA fragment order
+    (int16 tensor, scnerf_split_planes_shorts(pd) words); once per optimizer step."""
+    _f(flat_params, "flat_params")
+    lay = ML.layout(pd)
+    if flat_params.numel() != lay.n_params:
+        raise ValueError("expected %d parameters, got %d" % (lay.n_params, flat_params.numel()))
+    lib = _capi.load()
+    n = lib.scnerf_split_planes_shorts(pd)
+    if out is None:
+        out = torch.empty(n, dtype=torch.int16, device=flat_params.device)
+    _capi.check(lib.scnerf_pack_split_planes(pd, _p(flat_params), _p(out), _stream()), "scnerf_pack_split_planes")
+    return out
+
+
 def _vd(viewdirs: Tensor):
     """(pointer, row stride) of a [n,3] fp32 view-direction tensor that may be a column slice
     of the packed ray batch (ray_batch[:, 8:11])."""
@@ -206,8 +238,9 @@ _MAC_PER_SAMPLE = {3: 593408, 4: 593408 + 2 * 256 * 21}       # layer 0 and the 
 
 
 def mlp_fwd(pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked: Tensor,
-            save: Optional[Tensor] = None, pd: int = 3) -> Tensor:
-    """pts [P, pd] (pd = 3: x y z; pd = 4: x y z 1/r) -> raw [P, 4] (rgb logits, sigma pre-activation)."""
+            save: Optional[Tensor] = None, pd: int = 3, planes: Optional[Tensor] = None) -> Tensor:
+    """pts [P, pd] (pd = 3: x y z; pd = 4: x y z 1/r) -> raw [P, 4] (rgb logits, sigma pre-activation).
+    `planes` (pack_planes; training only): the 256-wide layers run as split-arithmetic GEMMs."""
     _f(pts, "pts"), _f(wpacked, "wpacked")
     vptr, vstride = _vd(viewdirs)
     lay = ML.layout(pd)
@@ -220,6 +253,14 @@ def mlp_fwd(pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked: Tensor
             raise ValueError("activation workspace too small")
     raw = torch.empty((P, 4), dtype=torch.float32, device=pts.device)
     tag = "" if pd == 3 else "/pd4"
+    if planes is not None:
+        if save is None:
+            raise ValueError("the split-arithmetic forward runs through the activation workspace (training mode)")
+        with PROFILE.region("mlp_fwd(stages + 8 layer GEMMs)%s/P=%d/train" % (tag, P), 2 * _MAC_PER_SAMPLE[pd] * P, group=True):
+            st = _capi.load().scnerf_mlp_fwd_split(pd, _p(pts), vptr, vstride, int(samples_per_ray), _p(wpacked),
+                                                   _p(planes), _p(raw), _p(save), P, _stream())
+        _capi.check(st, "scnerf_mlp_fwd_split")
+        return raw
     with PROFILE.region("mlp_fwd_kernel%s/P=%d/%s" % (tag, P, "train" if save is not None else "infer"),
                         2 * _MAC_PER_SAMPLE[pd] * P):
         st = _capi.load().scnerf_mlp_fwd(pd, _p(pts), vptr, vstride, int(samples_per_ray), _p(wpacked), _p(raw),
@@ -232,7 +273,7 @@ COARSE_STAGE_SAMPLES = 64        # the fused coarse stage exists for two wave ti
 
 
 def coarse_stage_fwd(rays: Tensor, t_vals: Tensor, t_rand: Optional[Tensor], lindisp: bool, wpacked: Tensor,
-                     save: Optional[Tensor], noise: Optional[Tensor], white_bkgd: bool):
+                     save: Optional[Tensor], noise: Optional[Tensor], white_bkgd: bool, planes: Optional[Tensor] = None):
     """coarse_sample + mlp_fwd + composite_fwd of the coarse stage as one launch (64 samples per ray):
     -> (z [n,64], pts [n,64,3], raw [n,64,4], rgb [n,3], disp [n], acc [n], weights [n,64], depth [n])."""
     _f(rays, "rays"), _f(t_vals, "t_vals"), _f(wpacked, "wpacked")
@@ -257,6 +298,16 @@ def coarse_stage_fwd(rays: Tensor, t_vals: Tensor, t_rand: Optional[Tensor], lin
     depth = torch.empty((n,), dtype=torch.float32, device=dev)
     w = torch.empty((n, s), dtype=torch.float32, device=dev)
     P = n * s
+    if planes is not None:
+        if save is None:
+            raise ValueError("the split-arithmetic forward runs through the activation workspace (training mode)")
+        with PROFILE.region("mlp_fwd(stages + 8 layer GEMMs)/P=%d/train" % P, 2 * _MAC_PER_SAMPLE[3] * P, group=True):
+            st = _capi.load().scnerf_coarse_stage_fwd_split(
+                _p(rays), rays.shape[1], _p(t_vals), _p(t_rand), int(bool(lindisp)), _p(wpacked), _p(planes), _p(save),
+                _p(noise), int(bool(white_bkgd)), _p(z), _p(pts), _p(raw), _p(rgb), _p(disp), _p(acc), _p(depth), _p(w),
+                n, s, _stream())
+        _capi.check(st, "scnerf_coarse_stage_fwd_split")
+        return z, pts, raw, rgb, disp, acc, w, depth
     with PROFILE.region("mlp_fwd_kernel/P=%d/%s" % (P, "train" if save is not None else "infer"), 2 * _MAC_PER_SAMPLE[3] * P):
         st = _capi.load().scnerf_coarse_stage_fwd(_p(rays), rays.shape[1], _p(t_vals), _p(t_rand), int(bool(lindisp)),
                                                   _p(wpacked), _p(save), _p(noise), int(bool(white_bkgd)), _p(z), _p(pts),

@@ -72,3 +72,27 @@ def test_layer_split_rejects_bad_arguments():
     assert lib.scnerf_layer_split(3, 0, H.ptr(s), H.ptr(z), H.ptr(z), None, H.ptr(z), None, 32, None) < 0
     assert lib.scnerf_layer_split(3, 5, H.ptr(s), H.ptr(z), H.ptr(z), None, H.ptr(z), None, 32, None) < 0     # skip layer needs epts
     assert lib.scnerf_layer_split(3, 2, H.ptr(s), H.ptr(z), H.ptr(z), None, H.ptr(z), None, 0, None) == 0      # nothing to do
+
+
+@pytest.mark.parametrize("pd,n_rays,spr", [(3, 3, 50), (4, 2, 70)])
+def test_staged_forward_equals_the_fused_forward(pd, n_rays, spr):
+    """scnerf_mlp_fwd_split (stage 1, eight layer GEMMs, stage 2) against scnerf_mlp_fwd: raw outputs and every
+    saved section the backward kernels read."""
+    lay = ML.layout(pd)
+    P = n_rays * spr
+    p, wpk, save = _forward_with_save(pd, P, n_rays, spr, 21 + pd)
+    g = torch.Generator().manual_seed(21 + pd)
+    pts = (torch.rand(P, pd, generator=g) * 2.4 - 1.2).numpy()
+    vd = torch.randn(n_rays, 3, generator=g)
+    vd = (vd / vd.norm(dim=-1, keepdim=True)).numpy()
+    raw_ref = np.zeros((P, 4), np.float32)
+    H.call("scnerf_mlp_fwd", pd, pts, vd, 3, spr, wpk, raw_ref, save, P, None)
+    planes = np.zeros(H.lib().scnerf_split_planes_shorts(pd), np.int16)
+    H.call("scnerf_pack_split_planes", pd, flat_params(p, pd), planes, None)
+    raw = np.full((P, 4), np.nan, np.float32)
+    save2 = np.full(lay.save_floats(P), np.nan, np.float32)
+    H.call("scnerf_mlp_fwd_split", pd, pts, vd, 3, spr, wpk, planes, raw, save2, P, None)
+    np.testing.assert_allclose(raw, raw_ref, rtol=1e-5, atol=1e-5)
+    a, b = save_views(save, P, pd), save_views(save2, P, pd)
+    for name, _ in lay.save_sections:
+        np.testing.assert_allclose(b[name], a[name], rtol=1e-5, atol=1e-5, err_msg=name)

@@ -211,3 +211,46 @@ def test_split_weight_gradient_gemm_is_fp32_grade(ops):
         "max_difference_between_the_two_over_sum_abs_products": float(((out["split"] - out["fp32"]).double().abs() / scale).max())}
     assert err["split"]["max"] <= 1.5 * err["fp32"]["max"] + 1e-9 and err["split"]["max"] < 2e-7, err
     assert err["split"]["rms"] <= 2.0 * err["fp32"]["rms"], err
+
+
+@pytest.mark.parametrize("pd,n_rays,spr", [(3, 21, 50), (4, 17, 70), (3, 1024, 192)])
+def test_staged_split_forward_equals_the_fused_forward(ops, pd, n_rays, spr):
+    """Training forward with the eight 256-wide layers as split-arithmetic GEMMs (scnerf_mlp_fwd_split) against the
+    fused fp32-MFMA kernel: raw outputs and every saved section the backward kernels read, to accumulation-order
+    rounding; ReLU bit words may differ only where a pre-activation is within rounding of zero."""
+    from tests.emu_mlp_util import network_params
+    lay = ML.layout(pd)
+    p = network_params(4 if pd == 3 else 779, pd)
+    flat = dev(_flat(p, pd))
+    P = n_rays * spr
+    g = torch.Generator().manual_seed(5)
+    pts = dev(torch.rand(P, pd, generator=g) * 2.4 - 1.2)
+    vd = torch.randn(n_rays, 3, generator=g)
+    vd = dev(vd / vd.norm(dim=-1, keepdim=True))
+    wf = ops.pack_weights(flat, "fwd", pd=pd)
+    planes = ops.pack_planes(flat, pd)
+    save_a, save_b = ops.save_workspace(P, "cuda", pd).zero_(), ops.save_workspace(P, "cuda", pd).zero_()
+    raw_a = ops.mlp_fwd(pts, vd, spr, wf, save_a, pd=pd)
+    raw_b = ops.mlp_fwd(pts, vd, spr, wf, save_b, pd=pd, planes=planes)
+    scale = float(raw_a.abs().max())
+    assert float((raw_a - raw_b).abs().max()) <= 2e-5 * max(scale, 1.0)
+    Pp = ML.padded_samples(P)
+    off, total = ML.section_offsets(lay.save_sections, P)
+
+    def rows(save, name, w):            # live samples of a section as [P, w] (pad lanes carry whatever fed them)
+        blk = save[off[name]: off[name] + w * Pp]
+        if name in ML.TILED_SECTIONS:
+            blk = blk.view(Pp // 32, w // 32, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(Pp, w)
+        else:
+            blk = blk.view(Pp, w)
+        return blk[:P]
+    for name, w in lay.save_sections:
+        a, b = rows(save_a, name, w), rows(save_b, name, w)
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1.0), name
+    tiles = (P + 31) // 32
+    ma = save_a[total:].view(torch.int32).view(9, Pp // 32, 64, 4)[:, :tiles]
+    mb = save_b[total:].view(torch.int32).view(9, Pp // 32, 64, 4)[:, :tiles]
+    sample = torch.arange(tiles, device="cuda")[:, None] * 32 + (torch.arange(64, device="cuda")[None, :] & 31)
+    live = (sample < P)[None, :, :, None]
+    flipped = int(torch.count_nonzero((ma ^ mb) * live))
+    assert flipped <= max(4, P // 200), flipped          # words with a flipped bit: pre-activations within rounding of zero
