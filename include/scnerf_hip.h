@@ -246,7 +246,13 @@ int scnerf_nerf_param_count(int pt_dims);
 /* scnerf_mlp_fwd_split / scnerf_coarse_stage_fwd_split: the training forward (save != NULL) of scnerf_mlp_fwd /
  * scnerf_coarse_stage_fwd with the eight 256-wide layers run as such GEMMs between the encoding + layer 0 and the
  * heads, which stay on the fused fp32-MFMA kernel; same arguments plus `planes`, same outputs, same workspace. */
+/* scnerf_mlp_bwd_split: scnerf_mlp_bwd with the eight 256-wide transposed layers (feature_linear^T + the density
+ * head, layers 7 .. 1) as such GEMMs between the heads and the encoded-point end of the fused kernel; same arguments
+ * plus `planes` (the buffer holds the transposed planes too), same outputs. */
 long long scnerf_split_planes_shorts(int pt_dims);
+int scnerf_mlp_bwd_split(int pt_dims, const float* d_raw, const float* pts, const float* viewdirs, int vd_stride,
+                         int samples_per_ray, const float* wpacked_bwd, const short* planes, const float* save,
+                         float* grads, float* d_pts, float* d_views, long long n_samples, void* stream);
 int scnerf_mlp_fwd_split(int pt_dims, const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
                          const float* wpacked, const short* planes, float* raw, float* save, long long n_samples,
                          void* stream);

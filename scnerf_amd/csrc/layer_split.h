@@ -45,6 +45,13 @@ struct Args {
     unsigned* mask;        // ReLU bits [wave tile][64 lanes][4 words] or nullptr
     long Ppad;             // samples covered (multiple of 128)
     int relu;
+    // mode 1 (data gradients): Z = select(mask_in, W X + bias[n] * vec[p]) -- the ReLU gate of the layer below and
+    // the rank-1 density-head term (bias = alpha_linear's weights, vec = d sigma); no bias add, no bits written
+    int mode;
+    const unsigned* mask_in;   // [wave tile][64 lanes][4 words]
+    const float* vec;          // per-sample scalar, element p * vec_stride (p < n_vec), or nullptr
+    int vec_stride;
+    long n_vec;
 };
 
 enum : int {
@@ -248,6 +255,40 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
                     *reinterpret_cast<u32x2*>(a.mask + t * 256 + lane * 4 + 2 * wn) = u32x2{bits[0], bits[1]};
                 }
             };
+            // data-gradient form: gate by the ReLU bits of the layer below (element 16 t + r of a lane: word t >> 1,
+            // bit 31 - (16 (t & 1) + r)), after adding the density head's rank-1 term
+            auto tile_bwd = [&](auto j_tag) {
+                constexpr int j = decltype(j_tag)::value;
+                const long t = tile0 + j;
+                if (t >= n_tiles) return;
+                float* zt = a.Z + t * 8192 + wn * 4096 + lane * 4;
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 gate = *reinterpret_cast<const u32x2*>(a.mask_in + t * 256 + lane * 4 + 2 * wn);
+                const long p = t * 32 + m;
+                const float vs = (a.vec && p < a.n_vec) ? a.vec[p * a.vec_stride] : 0.f;
+                auto row = [&](auto i_tag) {
+                    constexpr int i = decltype(i_tag)::value;
+                    auto piece = [&](auto q_tag) {
+                        constexpr int q = decltype(q_tag)::value;
+                        sched_fence();
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(lds_bias + ((4 * (4 * wn + i) + q) * 2 + g) * 4);
+                        constexpr int bit0 = 31 - (16 * (i & 1) + 4 * q);
+                        const unsigned word = gate[i >> 1];
+                        f32x4 v;
+                        v[0] = keep_if_bit<bit0 - 0>(fmaf(b[0], vs, acc[i][j][4 * q + 0]), word);
+                        v[1] = keep_if_bit<bit0 - 1>(fmaf(b[1], vs, acc[i][j][4 * q + 1]), word);
+                        v[2] = keep_if_bit<bit0 - 2>(fmaf(b[2], vs, acc[i][j][4 * q + 2]), word);
+                        v[3] = keep_if_bit<bit0 - 3>(fmaf(b[3], vs, acc[i][j][4 * q + 3]), word);
+                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(zt + (4 * i + q) * 256));
+                    };
+                    piece(I<0>{}); piece(I<1>{}); piece(I<2>{}); piece(I<3>{});
+                };
+                row(I<0>{}); row(I<1>{}); row(I<2>{}); row(I<3>{});
+            };
+            if (a.mode == 1) {
+                tile_bwd(I<0>{}); tile_bwd(I<1>{}); tile_bwd(I<2>{}); tile_bwd(I<3>{});
+                return;
+            }
             tile(I<0>{}); tile(I<1>{}); tile(I<2>{}); tile(I<3>{});
         }
     };

@@ -24,7 +24,11 @@ __host__ __device__ constexpr int slab_offset(int l) {
     return l <= 5 ? (l - 1) * 16 : 16 * (l - 1) + skip_slabs<PD>();
 }
 template <int PD>
-__host__ __device__ constexpr int total_slabs() { return slab_offset<PD>(8) + 16; }
+__host__ __device__ constexpr int fwd_slabs() { return slab_offset<PD>(8) + 16; }
+// then the TRANSPOSED weights of the data-gradient chain, 16 slabs each: entry 0 = feature_linear^T, entry e = 1 .. 7
+// = layer (8 - e)^T (layer 5: its h columns; the encoded-point columns stay with the fused kernel's last stage)
+template <int PD>
+__host__ __device__ constexpr int total_slabs() { return fwd_slabs<PD>() + 8 * 16; }
 
 // one thread per (slab, feature tile T, lane, element e): the three planes of one weight
 template <int PD>
@@ -34,6 +38,25 @@ __global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restric
     if (idx >= (long)total_slabs<PD>() * 8 * 64 * 8) return;
     const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63), T = (int)((idx >> 9) & 7);
     const int slab = (int)(idx >> 12);
+    if (slab >= fwd_slabs<PD>()) {
+        const int entry = (slab - fwd_slabs<PD>()) >> 4, s = (slab - fwd_slabs<PD>()) & 15;
+        const int row = 32 * T + (lane & 31);                   // output of the transposed layer = input feature k
+        const int col = 16 * s + 8 * (lane >> 5) + e;           // contraction = output feature n of the layer
+        const int l = 8 - entry;
+        const float w = entry == 0 ? params[V::kWF + col * 256 + row]
+                      : l == 5   ? params[V::trunk_w(5) + col * V::kSkipLd + V::kInCh + row]
+                                 : params[V::trunk_w(l) + col * 256 + row];
+        const unsigned u = __float_as_uint(w);
+        const float d1 = w - __uint_as_float(u & 0xffff0000u);
+        const unsigned u1 = __float_as_uint(d1);
+        const float d2 = d1 - __uint_as_float(u1 & 0xffff0000u);
+        const unsigned u2 = __float_as_uint(d2);
+        const long base = (((long)slab * 3) * 8 + T) * 64 * 8 + lane * 8 + e;
+        out[base] = (short)(u >> 16);
+        out[base + 8 * 64 * 8] = (short)(u1 >> 16);
+        out[base + 2 * 8 * 64 * 8] = (short)(u2 >> 16);
+        return;
+    }
     int l = 1;
 #pragma unroll
     for (int c = 2; c <= 8; ++c)
@@ -94,8 +117,41 @@ int launch_network_layer(int l, const short* planes, const float* bias_table, co
     a.mask = mask;
     a.Ppad = Ppad;
     a.relu = l < 8;
+    a.mode = 0;
+    a.mask_in = nullptr;
+    a.vec = nullptr;
+    a.vec_stride = 0;
+    a.n_vec = 0;
     return launch_layer(a, stream);
 }
+
+// data-gradient layer `entry` (0: feature_linear^T + the density head's rank-1 term; e = 1 .. 7: layer (8 - e)^T):
+// grad_out = gate(mask_in, W^T grad_in [+ alpha_table[n] * vec[p]])
+template <int PD>
+int launch_network_layer_bwd(int entry, const short* planes, const float* alpha_table, const float* grad_in,
+                             float* grad_out, const unsigned* mask_in, const float* vec, int vec_stride, long n_vec,
+                             long Ppad, hipStream_t stream) {
+    Args a;
+    a.X = grad_in;
+    a.X2 = grad_in;
+    a.x2_ld = 0;
+    a.n_k = 16;
+    a.W = planes + (long)(fwd_slabs<PD>() + 16 * entry) * kSlabShorts;
+    a.bias = alpha_table;                    // read into LDS whether used or not: must be a valid table
+    a.Z = grad_out;
+    a.mask = nullptr;
+    a.Ppad = Ppad;
+    a.relu = 0;
+    a.mode = 1;
+    a.mask_in = mask_in;
+    a.vec = entry == 0 ? vec : nullptr;
+    a.vec_stride = vec_stride;
+    a.n_vec = n_vec;
+    return launch_layer(a, stream);
+}
+template int launch_network_layer_bwd<3>(int, const short*, const float*, const float*, float*, const unsigned*, const float*, int, long, long, hipStream_t);
+template int launch_network_layer_bwd<4>(int, const short*, const float*, const float*, float*, const unsigned*, const float*, int, long, long, hipStream_t);
+
 template int launch_network_layer<3>(int, const short*, const float*, const float*, const float*, float*, unsigned*, long, hipStream_t);
 template int launch_network_layer<4>(int, const short*, const float*, const float*, const float*, float*, unsigned*, long, hipStream_t);
 

@@ -12,5 +12,13 @@ template <int PD>
 int launch_network_layer(int l, const short* planes, const float* bias_table, const float* act_in, const float* epts,
                          float* act_out, unsigned* mask, long Ppad, hipStream_t stream);
 
+// data-gradient layer `entry` (0: feature_linear^T + alpha_table[n] * vec[p * vec_stride], p < n_vec; e = 1 .. 7:
+// trunk layer (8 - e)^T): grad_out = gate(mask_in, W^T grad_in [+ rank-1 term]); alpha_table must be a valid
+// 256-float lane-vector table in either case
+template <int PD>
+int launch_network_layer_bwd(int entry, const short* planes, const float* alpha_table, const float* grad_in,
+                             float* grad_out, const unsigned* mask_in, const float* vec, int vec_stride, long n_vec,
+                             long Ppad, hipStream_t stream);
+
 }  // namespace lsp
 }  // namespace scn

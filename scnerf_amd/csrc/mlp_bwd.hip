@@ -15,6 +15,7 @@
 #include <scn_wave.h>
 
 #include "launch.h"
+#include "layer_split_api.h"
 #include "mlp_common.h"
 #include "scnerf_hip.h"
 
@@ -79,7 +80,11 @@ __device__ __forceinline__ void pe_backward(float x, float y, float z, float w, 
     }
 }
 
-template <int PD>
+// STAGE: 0 = the whole chain; 1 = the heads only (rgb^T, views^T: d feature and dZ of the views layer go to the
+// workspace, d viewdirs is final); 2 = the encoded-point end only (the skip columns of layer 5 and layer 0 on the
+// dZ_5 / dZ_0 found in the workspace, then the encoding's gradient -> d pts).  1 and 2 bracket the per-layer
+// split-arithmetic GEMMs of layer_split.h.
+template <int PD, int STAGE = 0>
 __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
     const float* __restrict__ d_raw, const float* __restrict__ pts, const float* __restrict__ viewdirs,
     int vd_stride, int samples_per_ray, const float* __restrict__ wbk, const float* __restrict__ save,
@@ -95,6 +100,40 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
     constexpr int ET = V::kET, ECS = V::kECS, ES = V::kES;
 
     WStream ws;
+    // stream order: rgb^T, views^T (8 tiles), its encoded-direction tile, feature^T, 7, 6, 5 main, 5 skip, 4 .. 1, 0
+    constexpr int kSkipStream = 1024 + 64 * 9 * 64 + 4 * 65536;
+    constexpr int kLayer0Stream = V::kBwdStream - 128 * ET * 64;
+    float dz[128];
+    float de[ES];
+#pragma unroll
+    for (int s = 0; s < ES; ++s) de[s] = 0.f;
+    auto load_section = [&](int offset) {               // dz <- this wave tile of a width-256 gradient section
+        const float* tile = tile_ptr(grads + (long)offset * Ppad, wave_tile, 256, lane);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(tile + (t * 4 + q) * 256);
+                dz[16 * t + 4 * q + 0] = v[0]; dz[16 * t + 4 * q + 1] = v[1];
+                dz[16 * t + 4 * q + 2] = v[2]; dz[16 * t + 4 * q + 3] = v[3];
+            }
+    };
+    if constexpr (STAGE == 2) {
+        ws.g = reinterpret_cast<const f32x4*>(wbk + kSkipStream);
+        stream_prime<8>(ws);
+        load_section(kGradDz + 5 * 256);
+        f32x16 acce[ET];
+        zero_acc<ET>(acce);
+        mfma_part<128, ET, ECS, 0>(dz, acce, ws);
+#pragma unroll
+        for (int t = 0; t < ES / 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) de[16 * t + r] = acce[t][r];
+        block_sync();                                   // every wave is done with the LDS chunks of the skip part
+        ws.g = reinterpret_cast<const f32x4*>(wbk + kLayer0Stream);
+        stream_prime<8>(ws);
+        load_section(kGradDz);
+    } else {
     ws.g = reinterpret_cast<const f32x4*>(wbk);
     stream_prime<1>(ws);           // RGBT: 4 tiles x 4 steps = 1024 floats
 
@@ -119,8 +158,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
     mfma_part<64, 8, 16, 4>(dzv, acc, ws, tile_ptr(grads + (long)kGradDzv * Ppad, wave_tile, 128, lane));
     f32x16 acce1[1];
     zero_acc<1>(acce1);
-    mfma_part<64, 1, 64, 8>(dzv, acce1, ws);
-    float dz[128];
+    mfma_part<64, 1, 64, STAGE == 1 ? 0 : 8>(dzv, acce1, ws);
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -139,6 +177,10 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
             d_views[p * 3 + 2] = gz + oz;
         }
     }
+    if constexpr (STAGE == 1) {
+        store_tiles<0, 8, 128>(dz, tile_ptr(grads + (long)kGradDfeat * Ppad, wave_tile, 256, lane));
+        return;
+    }
 
     // ---- feature_linear^T + alpha_linear^T : d h8 = W_f^T d feature + w_alpha d sigma -----
     {
@@ -156,9 +198,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
     mask_to_regs<8>(acc, load_mask<PD>(save, P, 7, wave_tile, lane), dz);      // dZ of trunk layer 7
 
     // ---- trunk layers 7..1 : d h_{l-1} = W_l^T dZ_l, then the ReLU mask of layer l-1 ------
-    float de[ES];
-#pragma unroll
-    for (int s = 0; s < ES; ++s) de[s] = 0.f;
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {
         zero_acc<8>(acc);
@@ -176,12 +215,14 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
         }
         mask_to_regs<8>(acc, load_mask<PD>(save, P, l - 1, wave_tile, lane), dz);
     }
+    }
 
     // ---- layer 0^T : d encoded point, then the encoding's own gradient -> d pts ------------
     {
         f32x16 acce[ET];
         zero_acc<ET>(acce);
-        mfma_part<128, ET, ECS, 0>(dz, acce, ws, tile_ptr(grads + (long)kGradDz * Ppad, wave_tile, 256, lane));
+        mfma_part<128, ET, ECS, 0>(dz, acce, ws,
+                                   STAGE == 2 ? nullptr : tile_ptr(grads + (long)kGradDz * Ppad, wave_tile, 256, lane));
 #pragma unroll
         for (int t = 0; t < ES / 16; ++t)
 #pragma unroll
@@ -205,6 +246,39 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
 
 }  // namespace
 
+template <int PD, int STAGE>
+static int launch_bwd(const float* d_raw, const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
+                      const float* wpacked_bwd, const float* save, float* grads, float* d_pts, float* d_views,
+                      long long n_samples, hipStream_t st) {
+    const size_t lds = (size_t)kStreamBufs * kMaxChunkBwd * sizeof(float);      // 96 KB: needs the opt-in
+    SCN_LDS_OPT_IN((mlp_bwd_kernel<PD, STAGE>), lds);
+    hipLaunchKernelGGL((mlp_bwd_kernel<PD, STAGE>), dim3(scn_ceil_div(n_samples, kSamplesPerBlock)), dim3(kThreads), lds, st,
+                       d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views,
+                       (long)n_samples);
+    return scn_launch_status();
+}
+
+template <int PD>
+static int bwd_split(const float* d_raw, const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
+                     const float* wpacked_bwd, const short* planes, const float* save, float* grads, float* d_pts,
+                     float* d_views, long long n_samples, hipStream_t st) {
+    using V = Var<PD>;
+    const long P = (long)n_samples, Ppad = padded_samples(P);
+    int rc = launch_bwd<PD, 1>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st);
+    if (rc) return rc;
+    const unsigned* masks = reinterpret_cast<const unsigned*>(save + (long)V::kSavePerSample * Ppad);
+    const float* alpha = wpacked_bwd + V::kBwdAlphaW;
+    // entry 0: d feature -> dZ_7 (feature_linear^T + the density head, gate 7); entry e: dZ_{8-e} -> dZ_{7-e}
+    for (int e = 0; e < 8; ++e) {
+        const float* in = grads + (long)(e == 0 ? kGradDfeat : kGradDz + (8 - e) * 256) * Ppad;
+        float* out = grads + (long)(kGradDz + (7 - e) * 256) * Ppad;
+        rc = scn::lsp::launch_network_layer_bwd<PD>(e, planes, alpha, in, out, masks + (long)(7 - e) * (Ppad / 32) * 256,
+                                                    d_raw + 3, 4, P, Ppad, st);
+        if (rc) return rc;
+    }
+    return launch_bwd<PD, 2>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st);
+}
+
 extern "C" int scnerf_mlp_bwd(int pt_dims, const float* d_raw, const float* pts, const float* viewdirs,
                               int vd_stride, int samples_per_ray, const float* wpacked_bwd, const float* save,
                               float* grads, float* d_pts, float* d_views, long long n_samples,
@@ -212,15 +286,19 @@ extern "C" int scnerf_mlp_bwd(int pt_dims, const float* d_raw, const float* pts,
     SCN_RETURN_IF(!d_raw || !pts || !viewdirs || !wpacked_bwd || !save || !grads || !d_pts || !d_views, SCN_EINVAL);
     SCN_RETURN_IF(samples_per_ray < 1 || vd_stride < 3 || n_samples < 0 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
     if (n_samples == 0) return 0;
-    const size_t lds = (size_t)kStreamBufs * kMaxChunkBwd * sizeof(float);      // 96 KB: needs the opt-in
-    SCN_LDS_OPT_IN(mlp_bwd_kernel<3>, lds);
-    SCN_LDS_OPT_IN(mlp_bwd_kernel<4>, lds);
-    const dim3 grid(scn_ceil_div(n_samples, kSamplesPerBlock));
-    if (pt_dims == 3)
-        hipLaunchKernelGGL(mlp_bwd_kernel<3>, grid, dim3(kThreads), lds, (hipStream_t)stream, d_raw, pts, viewdirs,
-                           vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, (long)n_samples);
-    else
-        hipLaunchKernelGGL(mlp_bwd_kernel<4>, grid, dim3(kThreads), lds, (hipStream_t)stream, d_raw, pts, viewdirs,
-                           vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, (long)n_samples);
-    return scn_launch_status();
+    hipStream_t st = (hipStream_t)stream;
+    return pt_dims == 3 ? launch_bwd<3, 0>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st)
+                        : launch_bwd<4, 0>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st);
+}
+
+extern "C" int scnerf_mlp_bwd_split(int pt_dims, const float* d_raw, const float* pts, const float* viewdirs,
+                                    int vd_stride, int samples_per_ray, const float* wpacked_bwd, const short* planes,
+                                    const float* save, float* grads, float* d_pts, float* d_views, long long n_samples,
+                                    void* stream) {
+    SCN_RETURN_IF(!d_raw || !pts || !viewdirs || !wpacked_bwd || !planes || !save || !grads || !d_pts || !d_views, SCN_EINVAL);
+    SCN_RETURN_IF(samples_per_ray < 1 || vd_stride < 3 || n_samples < 0 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
+    if (n_samples == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    return pt_dims == 3 ? bwd_split<3>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, planes, save, grads, d_pts, d_views, n_samples, st)
+                        : bwd_split<4>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, planes, save, grads, d_pts, d_views, n_samples, st);
 }

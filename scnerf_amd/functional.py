@@ -87,6 +87,7 @@ class RenderRaysFunction(torch.autograd.Function):
         ctx.net_c, ctx.net_f = net_c, net_f
         ctx.n_params_c = len(net_c.ordered_parameters())
         ctx.coarse = (z_c, pts_c, raw_c, _c(noise_c), save_c)
+        ctx.pl_c = pl_c
         ctx.rays = rays
         ctx.wb_c = ops.pack_weights(flat_c, "bwd") if train else None
         ctx.fine = None
@@ -108,17 +109,19 @@ class RenderRaysFunction(torch.autograd.Function):
         rgb_f, disp_f, acc_f, _, depth_f = ops.composite_fwd(raw_f, z_f, rays, _c(noise_f), cfg.white_bkgd,
                                                              want_weights=False)
         ctx.fine = (z_f, pts_f, raw_f, _c(noise_f), save_f)
+        ctx.pl_f = pl_f
         ctx.wb_f = (ctx.wb_c if fine_net is net_c else ops.pack_weights(flat_f, "bwd")) if train else None
         ctx.mark_non_differentiable(z_std, z_f, z_s)
         return (rgb_f, disp_f, acc_f, depth_f, raw_f, rgb_c, disp_c, acc_c, depth_c, z_std, z_f, z_s)
 
     @staticmethod
-    def _stage_dgrad(stage, rays, spr, wbk, white_bkgd, g_rgb, g_disp, g_acc, g_depth, g_raw, d_rays, accumulate):
+    def _stage_dgrad(stage, rays, spr, wbk, white_bkgd, g_rgb, g_disp, g_acc, g_depth, g_raw, d_rays, accumulate,
+                     planes=None):
         """Data gradients of one stage (compositing, network, rays); -> what its weight gradients need."""
         z, pts, raw, noise, save = stage
         d_raw, d_rd = ops.composite_bwd(raw, z, rays, noise, white_bkgd, _c(g_rgb), _c(g_disp), _c(g_acc),
                                         _c(g_depth), _c(g_raw))
-        grads, d_pts, d_views = ops.mlp_bwd(d_raw, pts, rays[:, 8:11], spr, wbk, save)
+        grads, d_pts, d_views = ops.mlp_bwd(d_raw, pts, rays[:, 8:11], spr, wbk, save, planes=planes)
         ops.ray_reduce(d_pts, d_views, z, d_rd, d_rays, accumulate)
         return save, grads, d_raw, z.shape[0] * spr
 
@@ -154,14 +157,15 @@ class RenderRaysFunction(torch.autograd.Function):
         if sf > 0:
             if any(g is not None for g in (g_rgb, g_disp, g_acc, g_depth, g_raw)):
                 pend_f = RenderRaysFunction._stage_dgrad(ctx.fine, rays, sc + sf, ctx.wb_f, cfg.white_bkgd,
-                                                         g_rgb, g_disp, g_acc, g_depth, g_raw, d_rays, wrote)
+                                                         g_rgb, g_disp, g_acc, g_depth, g_raw, d_rays, wrote,
+                                                         planes=ctx.pl_f)
                 wrote = True
             coarse_g = (g_rgb0, g_disp0, g_acc0, g_depth0, None)
         else:
             coarse_g = (g_rgb, g_disp, g_acc, g_depth, g_raw)
         if any(g is not None for g in coarse_g):
             pend_c = RenderRaysFunction._stage_dgrad(ctx.coarse, rays, sc, ctx.wb_c, cfg.white_bkgd,
-                                                     *coarse_g, d_rays, wrote)
+                                                     *coarse_g, d_rays, wrote, planes=ctx.pl_c)
         if pend_f is not None:
             fg_f = RenderRaysFunction._stage_wgrad(pend_f, into=into_f)
         if pend_c is not None:

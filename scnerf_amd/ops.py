@@ -198,9 +198,10 @@ _MLP_ARITHMETIC = [os.environ.get("SCNERF_MLP_ARITHMETIC", "fp32")]
 
 
 def mlp_arithmetic(mode: Optional[str] = None) -> str:
-    """How the TRAINING forward runs the eight 256-wide layers (trunk 1 .. 7, feature_linear): "fp32" -- inside the
-    fused kernel on the exact-fp32 MFMA; "split" -- as per-layer GEMMs on the bf16 matrix pipe with exactly cut
-    fp32 operands (csrc/layer_split.h), between the fused kernel's first stage (encoding, layer 0) and its heads.
+    """How the TRAINING forward and the data-gradient chain run the eight 256-wide layers (trunk 1 .. 7,
+    feature_linear): "fp32" -- inside the fused kernels on the exact-fp32 MFMA; "split" -- as per-layer GEMMs on the
+    bf16 matrix pipe with exactly cut fp32 operands (csrc/layer_split.h), between the fused kernels' end stages
+    (encoding + layer 0 / heads; heads / encoded-point end).
     Without an argument: the mode in force.  Environment preset: SCNERF_MLP_ARITHMETIC."""
     if mode is not None:
         if mode not in ("fp32", "split"):
@@ -321,8 +322,9 @@ def save_workspace(P: int, device, pd: int = 3) -> Tensor:
 
 
 def mlp_bwd(d_raw: Tensor, pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked_bwd: Tensor,
-            save: Tensor, pd: int = 3):
-    """-> (grads workspace, d_pts [P,pd], d_views [P,3])."""
+            save: Tensor, pd: int = 3, planes: Optional[Tensor] = None):
+    """-> (grads workspace, d_pts [P,pd], d_views [P,3]).  `planes` (pack_planes): the 256-wide transposed layers
+    run as split-arithmetic GEMMs."""
     _f(d_raw, "d_raw"), _f(pts, "pts"), _f(wpacked_bwd, "wpacked_bwd"), _f(save, "save")
     vptr, vstride = _vd(viewdirs)
     lay = ML.layout(pd)
@@ -333,6 +335,14 @@ def mlp_bwd(d_raw: Tensor, pts: Tensor, viewdirs: Tensor, samples_per_ray: int, 
     grads = torch.empty(ML.grad_floats(P), dtype=torch.float32, device=dev)
     d_pts = torch.empty((P, pd), dtype=torch.float32, device=dev)
     d_views = torch.empty((P, 3), dtype=torch.float32, device=dev)
+    if planes is not None:
+        with PROFILE.region("mlp_bwd(stages + 8 layer GEMMs)%s/P=%d" % ("" if pd == 3 else "/pd4", P),
+                            2 * _MAC_PER_SAMPLE[pd] * P, group=True):
+            st = _capi.load().scnerf_mlp_bwd_split(pd, _p(d_raw), _p(pts), vptr, vstride, int(samples_per_ray),
+                                                   _p(wpacked_bwd), _p(planes), _p(save), _p(grads), _p(d_pts),
+                                                   _p(d_views), P, _stream())
+        _capi.check(st, "scnerf_mlp_bwd_split")
+        return grads, d_pts, d_views
     with PROFILE.region("mlp_bwd_kernel%s/P=%d" % ("" if pd == 3 else "/pd4", P), 2 * _MAC_PER_SAMPLE[pd] * P):
         st = _capi.load().scnerf_mlp_bwd(pd, _p(d_raw), _p(pts), vptr, vstride, int(samples_per_ray),
                                          _p(wpacked_bwd), _p(save), _p(grads), _p(d_pts), _p(d_views), P, _stream())

@@ -97,7 +97,13 @@ def gpu_sampling_state(ops, host_linspace, rays, net_c, t_rand, u, noise_c, sc, 
     with torch.no_grad():
         dev = rays.device
         z_c, pts_c = ops.coarse_sample(rays, host_linspace(sc, dev), t_rand, lindisp)
-        raw_c = ops.mlp_fwd(pts_c, rays[:, 8:11], sc, ops.pack_weights(net_c.flat_parameters(), "fwd"), None)
+        flat = net_c.flat_parameters()
+        # the same arithmetic the training forward under test used (ops.mlp_arithmetic): the coarse weights decide
+        # where the fine samples go
+        split = ops.mlp_arithmetic() == "split"
+        save = ops.save_workspace(rays.shape[0] * sc, dev) if split else None
+        raw_c = ops.mlp_fwd(pts_c, rays[:, 8:11], sc, ops.pack_weights(flat, "fwd"), save,
+                            planes=ops.pack_planes(flat) if split else None)
         rgb0, _, _, w_c, _ = ops.composite_fwd(raw_c.view(rays.shape[0], sc, 4), z_c, rays, noise_c, white_bkgd)
         z_f, _, z_s, _, inds, cdf = ops.fine_sample(rays, z_c, w_c, u, True, True)
     return dict(z_c=z_c, w_c=w_c, rgb0=rgb0, inds=inds, cdf=cdf, z_s=z_s, z_f=z_f)

@@ -96,3 +96,34 @@ def test_staged_forward_equals_the_fused_forward(pd, n_rays, spr):
     a, b = save_views(save, P, pd), save_views(save2, P, pd)
     for name, _ in lay.save_sections:
         np.testing.assert_allclose(b[name], a[name], rtol=1e-5, atol=1e-5, err_msg=name)
+
+
+@pytest.mark.parametrize("pd,n_rays,spr", [(3, 3, 50), (4, 2, 70)])
+def test_staged_data_gradients_equal_the_fused_chain(pd, n_rays, spr):
+    """scnerf_mlp_bwd_split (heads, eight transposed layer GEMMs, encoded-point end) against scnerf_mlp_bwd on the
+    same forward workspace: every gradient section the weight-gradient GEMMs read, d pts, d viewdirs."""
+    from tests.emu_mlp_util import grad_views, pack_backward
+    P = n_rays * spr
+    p, wpk, save = _forward_with_save(pd, P, n_rays, spr, 31 + pd)
+    wbk = pack_backward(p, pd)
+    planes = np.zeros(H.lib().scnerf_split_planes_shorts(pd), np.int16)
+    H.call("scnerf_pack_split_planes", pd, flat_params(p, pd), planes, None)
+    g = torch.Generator().manual_seed(31 + pd)
+    pts = (torch.rand(P, pd, generator=g) * 2.4 - 1.2).numpy()          # (same draws as _forward_with_save)
+    vd = torch.randn(n_rays, 3, generator=g)
+    vd = (vd / vd.norm(dim=-1, keepdim=True)).numpy()
+    d_raw = torch.randn(P, 4, generator=g).numpy()
+    out = {}
+    for name in ("scnerf_mlp_bwd", "scnerf_mlp_bwd_split"):
+        grads = np.full(ML.grad_floats(P), np.nan, np.float32)
+        d_pts = np.zeros((P, pd), np.float32)
+        d_views = np.zeros((P, 3), np.float32)
+        args = [pd, d_raw, pts, vd, 3, spr, wbk] + ([planes] if name.endswith("split") else []) + [save, grads, d_pts, d_views, P, None]
+        H.call(name, *args)
+        out[name] = (grad_views(grads, P), d_pts, d_views)
+    (ga, pa, va), (gb, pb, vb) = out["scnerf_mlp_bwd"], out["scnerf_mlp_bwd_split"]
+    for name in ga:
+        scale = float(np.abs(ga[name]).max()) + 1e-30
+        assert float(np.abs(ga[name] - gb[name]).max()) <= 1e-5 * scale, name
+    assert float(np.abs(pa - pb).max()) <= 2e-5 * float(np.abs(pa).max())
+    assert float(np.abs(va - vb).max()) <= 2e-5 * float(np.abs(va).max())

@@ -254,3 +254,31 @@ def test_staged_split_forward_equals_the_fused_forward(ops, pd, n_rays, spr):
     live = (sample < P)[None, :, :, None]
     flipped = int(torch.count_nonzero((ma ^ mb) * live))
     assert flipped <= max(4, P // 200), flipped          # words with a flipped bit: pre-activations within rounding of zero
+
+
+@pytest.mark.parametrize("pd,n_rays,spr", [(3, 21, 50), (4, 17, 70), (3, 1024, 192)])
+def test_staged_split_data_gradients_equal_the_fused_chain(ops, pd, n_rays, spr):
+    """scnerf_mlp_bwd_split (heads, eight transposed split-arithmetic layer GEMMs, encoded-point end) against the
+    fused fp32-MFMA data-gradient kernel on the same forward workspace: every gradient section the weight-gradient
+    GEMMs read, d pts and d viewdirs, to accumulation-order rounding."""
+    from tests.emu_mlp_util import network_params
+    p = network_params(4 if pd == 3 else 779, pd)
+    flat = dev(_flat(p, pd))
+    P = n_rays * spr
+    g = torch.Generator().manual_seed(6)
+    pts = dev(torch.rand(P, pd, generator=g) * 2.4 - 1.2)
+    vd = torch.randn(n_rays, 3, generator=g)
+    vd = dev(vd / vd.norm(dim=-1, keepdim=True))
+    d_raw = dev(torch.randn(P, 4, generator=g))
+    save = ops.save_workspace(P, "cuda", pd).zero_()
+    ops.mlp_fwd(pts, vd, spr, ops.pack_weights(flat, "fwd", pd=pd), save, pd=pd)
+    wb = ops.pack_weights(flat, "bwd", pd=pd)
+    ga, pa, va = ops.mlp_bwd(d_raw, pts, vd, spr, wb, save, pd=pd)
+    gb, pb, vb = ops.mlp_bwd(d_raw, pts, vd, spr, wb, save, pd=pd, planes=ops.pack_planes(flat, pd))
+    Pp = ML.padded_samples(P)
+    off, _ = ML.section_offsets(ML.GRAD_SECTIONS, P)
+    for name, w in ML.GRAD_SECTIONS:
+        a, b = ga[off[name]: off[name] + w * Pp], gb[off[name]: off[name] + w * Pp]
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), name
+    assert float((pa - pb).abs().max()) <= 5e-5 * float(pa.abs().max())
+    assert float((va - vb).abs().max()) <= 5e-5 * float(va.abs().max())

@@ -134,11 +134,13 @@ def test_render_rays_vs_reference_golden(R, golden, tag):
     tq = 2e-3 if sf > 0 else 1e-3
     ge = np.abs(rays.grad[:, cols].cpu().numpy() - g[k + "g_rays"][:, cols]).max(1) / np.abs(g[k + "g_rays"]).max()
     # rays whose samples sit where the reference places them: the ray gradient holds to 1e-3 of the largest entry
-    # but for single ReLU-flip rays (<= 10 %); rays with a moved sample are only bounded
+    # but for single ReLU-flip rays -- at most 3 of the 24, and those within 5e-3 (a flipped gate changes one
+    # sample's contribution, not the ray); rays with a moved sample are only bounded
     REPORT.setdefault("golden/" + tag, {})["d_ray_batch"] = dict(
         clean_rays=int(clean.sum()), clean_within_1e3=float((ge[clean] < 1e-3).mean()), clean_max=float(ge[clean].max()),
         all_max=float(ge.max()))
-    assert (ge[clean] < 1e-3).mean() >= 0.9 and ge.max() < 0.1, ("d ray_batch", float((ge[clean] < 1e-3).mean()), float(ge.max()))
+    assert (ge[clean] >= 1e-3).sum() <= 3 and ge[clean].max(initial=0.0) < 5e-3 and ge.max() < 0.1, (
+        "d ray_batch", int((ge[clean] >= 1e-3).sum()), float(ge[clean].max(initial=0.0)), float(ge.max()))
     assert float(rays.grad[:, 6:8].abs().max()) == 0.0
     nets = {"coarse": net_c, "fine": net_f}
     for key in g:

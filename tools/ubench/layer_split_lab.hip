@@ -108,7 +108,7 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(bias_table_kernel, dim3(1), dim3(256), 0, 0, b, table);
     CK(hipMemset(Z, 0xff, (size_t)Ppad * 256 * 4));
     CK(hipDeviceSynchronize());
-    Args a{X, nullptr, 0, 16, Wp, table, Z, mask, Ppad, 1};
+    Args a{X, nullptr, 0, 16, Wp, table, Z, mask, Ppad, 1, 0, nullptr, nullptr, 0, 0};
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kNoEpilogue>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kNoCut>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
