@@ -20,6 +20,16 @@
 // A slab of 16 k = 4 sample tiles x 6 products x 4 feature tiles = 96 MFMAs; the fillers (the cut of the NEXT
 // sample tile's fragment, the loads two slabs ahead, the weight copy one slab ahead, the weight fragment reads
 // as their registers fall free) sit between the MFMAs, at most 4 per slot; one barrier per slab.
+//
+// Measured (tools/ubench/layer_split_lab.hip, P = 786 432): 0.56-0.58 ms per layer against 0.80 ms for a layer inside
+// the fused fp32-MFMA kernel; MFMAs + weight stream alone 0.30-0.32 ms, + activation loads and cuts 0.44, + epilogue
+// 0.57.  Like wgrad256_split.h the kernel is POWER-bound (shader clock ~1.7 GHz), so what counts is the number of
+// instructions, not where they sit: spreading the epilogue's 1400 instructions per block over the 144 MFMA slots
+// around the block seam instead of issuing them as a burst changed nothing (0.573 vs 0.558 ms); staggering the
+// workgroups' block boundaries neither.  What did matter: a bias read from global memory inside the epilogue
+// waits on vmcnt, which also counts the stores just issued -- one store round trip per 16-byte piece, 20 us per
+// block (the table is read from LDS instead); accumulator reads hoisted out of their pieces spill, and a scratch
+// reload waits on vmcnt just the same.
 #pragma once
 #include <type_traits>
 

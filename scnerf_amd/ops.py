@@ -194,7 +194,7 @@ def pack_weights(flat_params: Tensor, kind: str = "fwd", out: Optional[Tensor] =
     return out
 
 
-_MLP_ARITHMETIC = [os.environ.get("SCNERF_MLP_ARITHMETIC", "fp32")]
+_MLP_ARITHMETIC = [os.environ.get("SCNERF_MLP_ARITHMETIC", "split")]
 
 
 def mlp_arithmetic(mode: Optional[str] = None) -> str:

@@ -282,3 +282,47 @@ def test_staged_split_data_gradients_equal_the_fused_chain(ops, pd, n_rays, spr)
         assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), name
     assert float((pa - pb).abs().max()) <= 5e-5 * float(pa.abs().max())
     assert float((va - vb).abs().max()) <= 5e-5 * float(va.abs().max())
+
+
+def test_split_layer_gemm_is_fp32_grade(ops):
+    """One trunk layer over 131 072 samples three ways -- the split-arithmetic GEMM (csrc/layer_split.h), the fused
+    fp32-MFMA kernel (both read from their training workspaces) and torch's fp32 matmul -- against fp64 on the same
+    inputs.  The split kernel's error must be that of the exact-fp32 paths (accumulation-order noise), nowhere near a
+    reduced-precision product (bf16: 4e-3, two-term split: 1e-5 of sum |w x|)."""
+    from tests import parity_attribution as PA
+    from tests.emu_mlp_util import network_params
+    lay = ML.layout(3)
+    p = network_params(4, 3)
+    flat = dev(_flat(p, 3))
+    n_rays, spr = 2048, 64
+    P = n_rays * spr
+    g = torch.Generator().manual_seed(8)
+    pts = dev(torch.rand(P, 3, generator=g) * 2.4 - 1.2)
+    vd = torch.randn(n_rays, 3, generator=g)
+    vd = dev(vd / vd.norm(dim=-1, keepdim=True))
+    wf = ops.pack_weights(flat, "fwd")
+    saves = {}
+    for mode, planes in (("fp32", None), ("split", ops.pack_planes(flat))):
+        saves[mode] = ops.save_workspace(P, "cuda").zero_()
+        ops.mlp_fwd(pts, vd, spr, wf, saves[mode], planes=planes)
+    Pp = ML.padded_samples(P)
+    off, _ = ML.section_offsets(lay.save_sections, P)
+    rows = lambda save, name: save[off[name]: off[name] + 256 * Pp].view(Pp // 32, 8, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(Pp, 256)[:P]
+    report = {}
+    for layer in (2, 7):
+        W, b = dev(p["pts_linears.%d.weight" % layer]), dev(p["pts_linears.%d.bias" % layer])
+        for mode in ("fp32", "split"):
+            x = rows(saves[mode], "act%d" % (layer - 1))              # each path judged on ITS OWN input
+            z = rows(saves[mode], "act%d" % layer)
+            ref = torch.relu(x.double() @ W.double().T + b.double())
+            scale = x.double().abs() @ W.double().abs().T + b.double().abs()
+            e = (z.double() - ref).abs() / scale
+            report.setdefault("layer%d" % layer, {})[mode] = {"max": float(e.max()), "rms": float((e * e).mean().sqrt())}
+            if mode == "split":
+                zt = torch.relu(x @ W.T + b)
+                et = (zt.double() - ref).abs() / scale
+                report["layer%d" % layer]["torch_fp32_matmul"] = {"max": float(et.max()), "rms": float((et * et).mean().sqrt())}
+    PA.REPORT["layer_gemm_arithmetic_131072_samples_error_over_sum_abs_products_vs_fp64"] = report
+    for layer, r in report.items():
+        assert r["split"]["rms"] <= 2.0 * r["fp32"]["rms"] and r["split"]["max"] <= 3.0 * r["fp32"]["max"] + 1e-9, (layer, r)
+        assert r["split"]["max"] < 1e-6, (layer, r)
