@@ -107,9 +107,10 @@ def _kernel_table(kern, steps):
         e = {"avg_ms": v["avg_ms"], "launches_per_step": v["launches"] / steps,
              "tflops": v["flop_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12 if v["flop_per_launch"] else None}
         if e["tflops"]:
-            on_split = split and k.startswith("wgrad(")
+            on_split = (split and k.startswith("wgrad(")) or "layer GEMMs" in k or k.startswith("layer_split_kernel")
             e["peak"] = PEAK_SPLIT_TFLOPS if on_split else PEAK_F32_MFMA_TFLOPS
-            e["pipe"] = "bf16 MFMA x6 (fp32 operands cut into 3 bf16, fp32 accumulate)" if on_split else "fp32 MFMA"
+            e["pipe"] = ("bf16 MFMA x6 (fp32 operands cut into 3 bf16, fp32 accumulate)" +
+                         ("; encoding + layer 0 and the heads on the fp32 MFMA" if "layer GEMMs" in k else "")) if on_split else "fp32 MFMA"
         out[k] = e
     return out
 
@@ -128,6 +129,32 @@ def _timed(step, steps, warmup, sync, profile=True):
     dt = time.perf_counter() - t0
     ops.PROFILE.enabled = False
     return dt / steps * 1e3, (_kernel_table(ops.PROFILE.summary(), steps) if profile else None)
+
+
+def time_layer_kernel(P, dev, iters=20):
+    """ms per launch of the split-arithmetic layer GEMM at P samples (HIP events on the current stream)"""
+    from scnerf_amd import _capi, mlp_layout as ML, ops, synthetic as synth
+    lay = ML.layout(3)
+    p = synth.network_params(seed=0)
+    flat = torch.cat([p[name].reshape(-1) for name, _ in ML.PARAM_SHAPES]).to(dev)
+    wf, planes = ops.pack_weights(flat, "fwd"), ops.pack_planes(flat)
+    save = ops.save_workspace(P, dev).zero_()
+    Pp = ML.padded_samples(P)
+    off, total = ML.section_offsets(lay.save_sections, P)
+    lib = _capi.load()
+    esz = save.element_size()
+    base = save.data_ptr()
+    args = (3, 2, planes.data_ptr(), wf.data_ptr() + (lay.fwd_bias + 512) * 4, base + off["act1"] * esz, base + off["epts"] * esz,
+            base + off["act2"] * esz, base + (total + 2 * (Pp // 32) * 256) * esz, P, ops._stream())
+    for _ in range(3):
+        _capi.check(lib.scnerf_layer_split(*args), "scnerf_layer_split")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        lib.scnerf_layer_split(*args)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
 
 
 def build_world(dev, rank, n):
@@ -251,6 +278,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=512)
     ap.add_argument("--camera", action="store_true", help="rays from the learnable camera model also at N = 1")
+    ap.add_argument("--mlp-arithmetic", choices=("split", "fp32"), default=None,
+                    help="the eight 256-wide layers of the training forward and of the data-gradient chain: per-layer GEMMs on "
+                         "the bf16 matrix pipe with exactly cut fp32 operands (default) or inside the fused fp32-MFMA kernels")
     ap.add_argument("--wgrad-arithmetic", choices=("split", "fp32"), default=None,
                     help="256 x 256 weight-gradient GEMMs: bf16 matrix pipe with exactly cut fp32 operands (default) "
                          "or the exact-fp32 MFMA")
@@ -280,6 +310,8 @@ def main():
     ops.check_layout()
     if a.wgrad_arithmetic:
         ops.wgrad_arithmetic(a.wgrad_arithmetic)
+    if a.mlp_arithmetic:
+        ops.mlp_arithmetic(a.mlp_arithmetic)
     n = a.rays
     w = build_world(dev, rank, n)
     with_camera = a.camera or world > 1
@@ -311,13 +343,38 @@ def main():
         dt = float(tt.item())
     ms = dt / a.steps * 1e3
 
+    layer_ms = None
+    if rank == 0 and ops.mlp_arithmetic() == "split":
+        layer_ms = time_layer_kernel(n * (S_C + S_F), dev)
     if rank == 0:
         kern = ops.PROFILE.summary()
         # dominant kernel family by total time
         single = {k: v for k, v in kern.items() if not v["group"]}
         dom = max(single, key=lambda k: single[k]["total_ms"]) if single else None
         roof = None
-        if dom:
+        if layer_ms is not None:
+            # split mode: the dominant kernel is the per-layer GEMM (16 launches per step at the fine pass's size, 16 at
+            # the coarse pass's), issued from inside one C call per pass; timed here launch by launch
+            P_f = n * (S_C + S_F)
+            flop = 2.0 * 256 * 256 * P_f
+            ach = flop / (layer_ms * 1e-3) / 1e12
+            dom = "layer_split_kernel/P=%d" % P_f
+            roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_SPLIT_TFLOPS,
+                    "unit": "TFLOP/s (fp32 products; peak = dense bf16 MFMA rate / 6 partial products)",
+                    "frac": ach / PEAK_SPLIT_TFLOPS, "traffic": None, "avg_launch_ms": layer_ms,
+                    "launches_per_step": 16.0, "flop_per_launch": flop,
+                    "achieved_over_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
+                    "measured": "HIP events around 20 back-to-back launches of scnerf_layer_split (layer 2) on a workspace of "
+                                "the fine pass's size, after the timed region; in the step these launches sit inside the "
+                                "mlp_fwd / mlp_bwd calls of `kernels` (profiles/*kernel_trace* has their in-step average)",
+                    "note": "power-bound: the shader clock falls to ~1.7 GHz under bf16 MFMAs at this density "
+                            "(profiles/r02d_pmc_kernels.txt), so the pipe's busy fraction is higher than frac"}
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.isfile(pmc):
+                rec = json.load(open(pmc))
+                roof["traffic"] = rec.get(dom)
+                roof["traffic_source"] = rec.get("_source")
+        elif dom:
             k = kern[dom]
             ach = k["flop_per_launch"] / (k["avg_ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
@@ -337,7 +394,13 @@ def main():
             "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "arithmetic": {
-                "forward, data gradients, narrow weight gradients": "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32",
+                "training forward and data gradients, the eight 256-wide layers": (
+                    "per-layer GEMMs, fp32 operands cut EXACTLY into 3 bf16 numbers each (weights once per step, "
+                    "activations / gradients in registers), 6 of the 9 partial products on v_mfma_f32_32x32x16_bf16, fp32 "
+                    "accumulate; per-layer error vs fp64 1.3x the fp32 MFMA's rms (profiles/parity_r02.json "
+                    "layer_gemm_arithmetic_*; --mlp-arithmetic fp32 keeps them inside the fused fp32-MFMA kernels)")
+                if ops.mlp_arithmetic() == "split" else "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32 (fused kernels)",
+                "encoding + layer 0, heads, inference forward, narrow weight gradients": "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32",
                 "256x256 weight gradients": (
                     "fp32 operands cut EXACTLY into 3 bf16 numbers each, 6 of the 9 partial products on "
                     "v_mfma_f32_32x32x16_bf16, fp32 accumulate; error vs fp64 = the fp32 MFMA kernel's "

@@ -30,6 +30,16 @@
 // waits on vmcnt, which also counts the stores just issued -- one store round trip per 16-byte piece, 20 us per
 // block (the table is read from LDS instead); accumulator reads hoisted out of their pieces spill, and a scratch
 // reload waits on vmcnt just the same.
+// Open (profiles/r02d_layer_lab_pmc.txt): the matrix pipe is busy 46 % of the cycles at 2.04 GHz, 36 % of the wave
+// cycles sit in s_waitcnt, so this kernel -- unlike wgrad256_split -- is stall-bound, not power-bound.  The ISA shows
+// why: every activation / weight load carries ~20 VALU of 64-bit address arithmetic (tile clamp, 64-bit multiply,
+// selects), and the compiler recycles landed staging registers for those address temporaries behind an
+// `s_waitcnt vmcnt(0)` once per two slabs, which drains the whole prefetch queue.  Tried and measured, none kept:
+// two independent dependency chains per cut step (no change); weight loads issued before the slab's activation
+// loads so that their in-order wait does not cover young activation loads (no change); buffer-descriptor loads
+// with 32-bit offsets (removes the address VALU and the spills but the code grows to 11 k lines through loop
+// unswitching and the weight stream alone gets slower: 0.345 vs 0.30 ms).  The next step is a hand-managed wait
+// (inline-asm s_waitcnt with counted vmcnt) and a single flat slab loop as in wgrad256_split.h.
 #pragma once
 #include <type_traits>
 
@@ -276,24 +286,32 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
                 const u32x2 gate = *reinterpret_cast<const u32x2*>(a.mask_in + t * 256 + lane * 4 + 2 * wn);
                 const long p = t * 32 + m;
                 const float vs = (a.vec && p < a.n_vec) ? a.vec[p * a.vec_stride] : 0.f;
-                auto row = [&](auto i_tag) {
-                    constexpr int i = decltype(i_tag)::value;
-                    auto piece = [&](auto q_tag) {
-                        constexpr int q = decltype(q_tag)::value;
-                        sched_fence();
-                        const f32x4 b = *reinterpret_cast<const f32x4*>(lds_bias + ((4 * (4 * wn + i) + q) * 2 + g) * 4);
-                        constexpr int bit0 = 31 - (16 * (i & 1) + 4 * q);
-                        const unsigned word = gate[i >> 1];
-                        f32x4 v;
-                        v[0] = keep_if_bit<bit0 - 0>(fmaf(b[0], vs, acc[i][j][4 * q + 0]), word);
-                        v[1] = keep_if_bit<bit0 - 1>(fmaf(b[1], vs, acc[i][j][4 * q + 1]), word);
-                        v[2] = keep_if_bit<bit0 - 2>(fmaf(b[2], vs, acc[i][j][4 * q + 2]), word);
-                        v[3] = keep_if_bit<bit0 - 3>(fmaf(b[3], vs, acc[i][j][4 * q + 3]), word);
-                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(zt + (4 * i + q) * 256));
+                // RANK1: the density head's term (feature_linear^T only); the other seven layers skip the FMA and
+                // the LDS read of the table
+                auto tile_rows = [&](auto rank1_tag) {
+                    constexpr bool RANK1 = decltype(rank1_tag)::value;
+                    auto row = [&](auto i_tag) {
+                        constexpr int i = decltype(i_tag)::value;
+                        auto piece = [&](auto q_tag) {
+                            constexpr int q = decltype(q_tag)::value;
+                            sched_fence();
+                            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                            if constexpr (RANK1) b = *reinterpret_cast<const f32x4*>(lds_bias + ((4 * (4 * wn + i) + q) * 2 + g) * 4);
+                            constexpr int bit0 = 31 - (16 * (i & 1) + 4 * q);
+                            const unsigned word = gate[i >> 1];
+                            auto val = [&](int e) { return RANK1 ? fmaf(b[e], vs, acc[i][j][4 * q + e]) : acc[i][j][4 * q + e]; };
+                            f32x4 v;
+                            v[0] = keep_if_bit<bit0 - 0>(val(0), word);
+                            v[1] = keep_if_bit<bit0 - 1>(val(1), word);
+                            v[2] = keep_if_bit<bit0 - 2>(val(2), word);
+                            v[3] = keep_if_bit<bit0 - 3>(val(3), word);
+                            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(zt + (4 * i + q) * 256));
+                        };
+                        piece(I<0>{}); piece(I<1>{}); piece(I<2>{}); piece(I<3>{});
                     };
-                    piece(I<0>{}); piece(I<1>{}); piece(I<2>{}); piece(I<3>{});
+                    row(I<0>{}); row(I<1>{}); row(I<2>{}); row(I<3>{});
                 };
-                row(I<0>{}); row(I<1>{}); row(I<2>{}); row(I<3>{});
+                if (a.vec) tile_rows(std::true_type{}); else tile_rows(std::false_type{});
             };
             if (a.mode == 1) {
                 tile_bwd(I<0>{}); tile_bwd(I<1>{}); tile_bwd(I<2>{}); tile_bwd(I<3>{});

@@ -9,7 +9,7 @@ import glob
 import os
 import sys
 
-KEEP = ("mlp_fwd_kernel", "mlp_bwd_kernel", "wgrad256_kernel", "wgrad256_split_kernel", "wgrad_tiles_kernel", "wgrad_reduce_multi_kernel")
+KEEP = ("mlp_fwd_kernel", "mlp_bwd_kernel", "wgrad256_kernel", "wgrad256_split_kernel", "layer_split_kernel", "wgrad_tiles_kernel", "wgrad_reduce_multi_kernel")
 
 
 def main():

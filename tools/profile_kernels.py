@@ -27,6 +27,12 @@ def main():
         grads, d_pts, d_views = ops.mlp_bwd(d_raw, pts, vd, 192, wb, save)
     for _ in range(reps):
         ops.nerf_wgrad(save, grads, d_raw, P)
+    # the same passes with the 256-wide layers as split-arithmetic GEMMs (the default of the training step)
+    planes = ops.pack_planes(flat)
+    for _ in range(reps):
+        ops.mlp_fwd(pts, vd, 192, wf, save, planes=planes)
+    for _ in range(reps):
+        grads, d_pts, d_views = ops.mlp_bwd(d_raw, pts, vd, 192, wb, save, planes=planes)
     torch.cuda.synchronize()
 
 
