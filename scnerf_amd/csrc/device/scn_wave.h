@@ -43,6 +43,25 @@ __device__ __forceinline__ s16x4 lds_read_tr16(const short* p) {
 __device__ __forceinline__ unsigned high_halves(unsigned lo_word, unsigned hi_word) {
     return __builtin_amdgcn_perm(hi_word, lo_word, 0x07060302u);
 }
+// A global pointer known to be the same in every lane, made OPAQUE to the compiler (an empty asm on its two SGPR halves): base of
+// `global_load v, v_off, s[base]`.  Without it the compiler folds loop-invariant per-lane offsets into 64-bit VGPR
+// pointers (2 VGPRs per distinct offset, hoisted out of the loop, spilled).  The pointer stays in the global address
+// space (rebuilt from integers as a generic pointer it would produce flat loads).
+typedef const __attribute__((address_space(1))) char* global_bytes;
+__device__ __forceinline__ global_bytes uniform_global(const void* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    asm("" : "+s"(lo), "+s"(hi));            // (readfirstlane of an already-scalar value folds away; this does not)
+    return reinterpret_cast<global_bytes>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ f32x4 load_f32x4(global_bytes base, unsigned lane_off) {
+    return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(base + lane_off);
+}
+// the same for data read once (does not displace what the caches hold)
+__device__ __forceinline__ f32x4 load_stream_f32x4(global_bytes base, unsigned lane_off) {
+    return __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(base + lane_off));
+}
 // 16-byte global load that does not displace what the caches hold (streamed-once operands)
 __device__ __forceinline__ f32x4 load_stream(const f32x4* p) { return __builtin_nontemporal_load(p); }
 

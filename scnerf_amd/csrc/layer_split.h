@@ -30,16 +30,17 @@
 // waits on vmcnt, which also counts the stores just issued -- one store round trip per 16-byte piece, 20 us per
 // block (the table is read from LDS instead); accumulator reads hoisted out of their pieces spill, and a scratch
 // reload waits on vmcnt just the same.
-// Open (profiles/r02d_layer_lab_pmc.txt): the matrix pipe is busy 46 % of the cycles at 2.04 GHz, 36 % of the wave
-// cycles sit in s_waitcnt, so this kernel -- unlike wgrad256_split -- is stall-bound, not power-bound.  The ISA shows
-// why: every activation / weight load carries ~20 VALU of 64-bit address arithmetic (tile clamp, 64-bit multiply,
-// selects), and the compiler recycles landed staging registers for those address temporaries behind an
-// `s_waitcnt vmcnt(0)` once per two slabs, which drains the whole prefetch queue.  Tried and measured, none kept:
-// two independent dependency chains per cut step (no change); weight loads issued before the slab's activation
-// loads so that their in-order wait does not cover young activation loads (no change); buffer-descriptor loads
-// with 32-bit offsets (removes the address VALU and the spills but the code grows to 11 k lines through loop
-// unswitching and the weight stream alone gets slower: 0.345 vs 0.30 ms).  The next step is a hand-managed wait
-// (inline-asm s_waitcnt with counted vmcnt) and a single flat slab loop as in wgrad256_split.h.
+// Open (profiles/r02d_layer_lab_pmc.txt): the matrix pipe is busy 46-50 % of the cycles at 2.04 GHz, 36 % of the wave
+// cycles sit in s_waitcnt, so this kernel -- unlike wgrad256_split -- is stall-bound, not power-bound.  Ablations
+// (lab, one box): MFMAs + weight stream 0.32 ms; + activation LOADS 0.45 (the cut's VALU on top: +0.005, i.e. hidden);
+// + epilogue 0.54.  Kept from the hunt: wave-uniform load bases made opaque to the compiler (uniform_global) -- with
+// 64-bit per-lane pointers every load carried ~20 VALU of address arithmetic and the compiler recycled landed
+// staging registers for the temporaries behind an `s_waitcnt vmcnt(0)` once per two slabs (0.575 -> 0.54 ms); the
+// weight loads issued BEFORE the slab's activation loads and waited for three iterations later (vmcnt counts in
+// order: a weight wait covers every older activation load; neutral by itself).  Tried, no effect: two independent
+// dependency chains per cut step; non-temporal activation loads; buffer-descriptor loads (they bloat the code to
+// 11 k lines through loop unswitching and slow the weight stream).  What the activation loads cost is not yet
+// explained (they are issued two slabs = 4 us ahead and the waits are counted, vmcnt(19)).
 #pragma once
 #include <type_traits>
 
@@ -77,6 +78,7 @@ struct Args {
 enum : int {
     kNoEpilogue = 1,      // timing experiment: only the last block is stored
     kNoCut = 2,           // timing experiment: no loads / cuts of X (planes hold garbage)
+    kNoCutMath = 8,       // timing experiment: X is loaded but not cut (the raw words serve as planes)
     kPlainStore = 4,      // experiment: default-policy stores instead of non-temporal ones (no difference)
     kNoZStore = 16,       // experiment: the epilogue computes but stores only the mask words
 };
@@ -99,10 +101,15 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
     f32x16 acc[4][4];       // written by MFMAs only: a block's first product starts from the constant 0
 
     // ---- X: lane (m, g) of sample tile j, slab s: pieces ((2 s + g) * 64 + m + 32 h') * 4 floats, h' = 0, 1
-    const unsigned xoff = (g * 64 + m) * 4;
+    // Every load is `global_load v, v_off, s[base]`: a wave-uniform base (uniform_global: opaque to the compiler) + a
+    // 32-bit per-lane byte offset.  With 64-bit per-lane pointers each load cost ~20 VALU of address arithmetic and the
+    // compiler recycled landed staging registers for the temporaries behind an `s_waitcnt vmcnt(0)`.
+    const int wp_u = uniform(wp);
+    const unsigned xoff_a = (unsigned)((g * 64 + m) * 16);                                   // main operand, piece h' = 0
+    const unsigned xoff_b = (unsigned)((m * a.x2_ld + 8 * g) * 4);                           // second operand
     auto tile_of = [&](int b, int j) {             // sample tile j of this workgroup's b-th block, clamped into the tensor
         const long blk = blockIdx.x + (long)(b < my_blocks ? b : my_blocks - 1) * gridDim.x;
-        const long t = blk * 8 + wp * 4 + j;
+        const long t = blk * 8 + wp_u * 4 + j;
         return t < n_tiles ? t : n_tiles - 1;
     };
     f32x4 raw[2][4][2];                             // [set = slab parity][sample tile][h']
@@ -113,12 +120,13 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
             const long t = tile_of(b, j);
             // (selects, not a branch: control flow here would cut the MFMA stream into scheduling regions)
             const bool main_part = s < 16;
-            const float* p1 = a.X + t * 8192 + s * 512 + xoff;
-            const float* p2 = a.X2 + (t * 32 + m) * a.x2_ld + (s - 16) * 16 + 8 * g;
-            const float* p = main_part ? p1 : p2;
-            const int second = main_part ? 128 : 4;
-            raw[SET][j][0] = *reinterpret_cast<const f32x4*>(p);
-            raw[SET][j][1] = *reinterpret_cast<const f32x4*>(p + second);
+            const float* p1 = a.X + t * 8192 + s * 512;
+            const float* p2 = a.X2 + t * 32 * a.x2_ld + (s - 16) * 16;
+            const global_bytes base = uniform_global(main_part ? p1 : p2);
+            const unsigned off0 = main_part ? xoff_a : xoff_b;
+            const unsigned off1 = off0 + (main_part ? 512u : 16u);
+            raw[SET][j][0] = load_f32x4(base, off0);      // (non-temporal loads: no difference; the two waves that
+            raw[SET][j][1] = load_f32x4(base, off1);      // share a sample tile meet in L1 either way)
         }
     };
     // planes of the fragment being used / being cut: [ping-pong][plane]
@@ -128,7 +136,13 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
     auto cut_step = [&](auto set_tag, auto j_tag, auto dst_tag, auto step_tag) {
         constexpr int SET = decltype(set_tag)::value, j = decltype(j_tag)::value, D = decltype(dst_tag)::value,
                       STEP = decltype(step_tag)::value;
-        if constexpr (!(FLAGS & kNoCut)) {
+        if constexpr (FLAGS & kNoCutMath) {
+            if constexpr (STEP == 8) {
+                xp[D][0] = __builtin_bit_cast(s16x8, raw[SET][j][0]);
+                xp[D][1] = __builtin_bit_cast(s16x8, raw[SET][j][1]);
+                xp[D][2] = __builtin_bit_cast(s16x8, raw[SET][j][0]);
+            }
+        } else if constexpr (!(FLAGS & kNoCut)) {
             if constexpr (STEP < 8) {
                 const float x = raw[SET][j][STEP >> 2][STEP & 3];
                 cu[STEP] = __float_as_uint(x);
@@ -152,9 +166,10 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
 
     // ---- W: slab image copy (6 x 16 bytes per thread) and fragment reads
     f32x4 wst[6];
+    const unsigned woff = (unsigned)tid * 16u;
     auto load_w = [&](int s, auto x_tag) {
         constexpr int x = decltype(x_tag)::value;
-        wst[x] = *(reinterpret_cast<const f32x4*>(a.W + (long)s * kSlabShorts) + x * kThreads + tid);
+        wst[x] = load_f32x4(uniform_global(a.W + (long)s * kSlabShorts) + x * (kThreads * 16), woff);
     };
     auto write_w = [&](int buf, auto x_tag) {
         constexpr int x = decltype(x_tag)::value;
@@ -193,11 +208,15 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
 
     // slab u out of LDS buffer BUF (= u & 1 = raw set): per sample tile j
     //   slots 0-10   cut the next fragment ((u, j + 1), or (u + 1, 0) out of the other raw set)
-    //   slot 11      (load_x: both pieces) reload raw fragment j for the slab two ahead
-    //   j = 0: slots 13-16 read Wl(u);        slots 17-19 write W(u + 1) pieces 0-2
-    //   j = 1: slots 13-15 write W(u + 1) pieces 3-5
-    //   j = 2: slots 13-15 load W(u + 2) pieces 0-2;      barrier at the end (buffer of slab u + 1 complete)
-    //   j = 3: slots 12-15 read Wh(u + 1);    slots 16-18 load W(u + 2) pieces 3-5;    slots 20-23 read Wm(u + 1)
+    //   slot 11 (j = 0: slot 23)   reload raw fragment j for the slab two ahead (load_x: both pieces)
+    //   j = 0: slots 13-16 read Wl(u);   slots 17-22 load W(u + 2) into the staging registers
+    //   j = 2: barrier at the end (every wave is done with W(u): its buffer is free; W(u + 1), written during slab
+    //          u - 1, is visible)
+    //   j = 3: slots 0-5 write W(u + 2) into buffer BUF;   slots 12-15 read Wh(u + 1);   slots 20-23 read Wm(u + 1)
+    // vmcnt counts loads IN ORDER: waiting for a weight piece also waits for every activation load issued before it.
+    // The weight loads therefore go out BEFORE slab u's activation loads and are waited for three iterations later,
+    // when the youngest activation load ahead of them is a whole slab old (with the weight loads in iterations 2-3
+    // and their writes right after, every slab waited twice for activation loads two iterations old).
     auto slab = [&](auto buf_tag, auto first_tag, int b, int s) {
         constexpr int BUF = decltype(buf_tag)::value;
         using Set = I<BUF>;
@@ -207,21 +226,17 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
         auto fill = [&](auto j_tag) {
             return [&](auto slot_tag) {
                 constexpr int j = decltype(j_tag)::value, S = decltype(slot_tag)::value;
+                if constexpr (j == 3 && S <= 5) write_w(BUF, I<S>{});
                 if constexpr (S <= 10) {
                     if constexpr (j < 3) cut_step(Set{}, I<j + 1>{}, I<(j + 1) & 1>{}, I<S>{});
                     else cut_step(Other{}, I<0>{}, I<0>{}, I<S>{});
                 }
-                if constexpr (S == 11) load_x(Set{}, b2, s2, I<j>{});
+                if constexpr (S == (j == 0 ? 23 : 11)) load_x(Set{}, b2, s2, I<j>{});
                 if constexpr (j == 0) {
                     if constexpr (S >= 13 && S <= 16) read_w(BUF, I<2>{}, I<S - 13>{});
-                    if constexpr (S >= 17 && S <= 19) write_w(BUF ^ 1, I<S - 17>{});
-                } else if constexpr (j == 1) {
-                    if constexpr (S >= 13 && S <= 15) write_w(BUF ^ 1, I<S - 13 + 3>{});
-                } else if constexpr (j == 2) {
-                    if constexpr (S >= 13 && S <= 15) load_w(s2, I<S - 13>{});
-                } else {
+                    if constexpr (S >= 17 && S <= 22) load_w(s2, I<S - 17>{});
+                } else if constexpr (j == 3) {
                     if constexpr (S >= 12 && S <= 15) read_w(BUF ^ 1, I<0>{}, I<S - 12>{});
-                    if constexpr (S >= 16 && S <= 18) load_w(s2, I<S - 16 + 3>{});
                     if constexpr (S >= 20) read_w(BUF ^ 1, I<1>{}, I<S - 20>{});
                 }
             };
@@ -322,12 +337,13 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
     };
 
     lds_bias[tid] = a.bias[tid];
-    // ---- prologue: W slab 0 -> buffer 0, slab 1 in flight; X raw of slabs 0 and 1; first fragment cut
+    // ---- prologue: W slabs 0 and 1 -> buffers 0 and 1; X raw of slabs 0 and 1; first fragment cut
     load_w(0, I<0>{}); load_w(0, I<1>{}); load_w(0, I<2>{}); load_w(0, I<3>{}); load_w(0, I<4>{}); load_w(0, I<5>{});
     load_x(I<0>{}, 0, 0, I<0>{}); load_x(I<0>{}, 0, 0, I<1>{}); load_x(I<0>{}, 0, 0, I<2>{}); load_x(I<0>{}, 0, 0, I<3>{});
     load_x(I<1>{}, 0, 1, I<0>{}); load_x(I<1>{}, 0, 1, I<1>{}); load_x(I<1>{}, 0, 1, I<2>{}); load_x(I<1>{}, 0, 1, I<3>{});
     write_w(0, I<0>{}); write_w(0, I<1>{}); write_w(0, I<2>{}); write_w(0, I<3>{}); write_w(0, I<4>{}); write_w(0, I<5>{});
     load_w(1, I<0>{}); load_w(1, I<1>{}); load_w(1, I<2>{}); load_w(1, I<3>{}); load_w(1, I<4>{}); load_w(1, I<5>{});
+    write_w(1, I<0>{}); write_w(1, I<1>{}); write_w(1, I<2>{}); write_w(1, I<3>{}); write_w(1, I<4>{}); write_w(1, I<5>{});
     sync();
     read_w(0, I<0>{}, I<0>{}); read_w(0, I<0>{}, I<1>{}); read_w(0, I<0>{}, I<2>{}); read_w(0, I<0>{}, I<3>{});
     read_w(0, I<1>{}, I<0>{}); read_w(0, I<1>{}, I<1>{}); read_w(0, I<1>{}, I<2>{}); read_w(0, I<1>{}, I<3>{});

@@ -82,6 +82,18 @@ inline s16x4 lds_read_tr16(const short* p) {
 }
 inline unsigned high_halves(unsigned lo_word, unsigned hi_word) { return (lo_word >> 16) | (hi_word & 0xffff0000u); }
 inline f32x4 load_stream(const f32x4* p) { return *p; }
+typedef const char* global_bytes;
+inline global_bytes uniform_global(const void* p) { return static_cast<const char*>(p); }
+inline f32x4 load_stream_f32x4(global_bytes base, unsigned lane_off) {
+    f32x4 v;
+    std::memcpy(&v, base + lane_off, 16);
+    return v;
+}
+inline f32x4 load_f32x4(global_bytes base, unsigned lane_off) {
+    f32x4 v;
+    std::memcpy(&v, base + lane_off, 16);
+    return v;
+}
 
 template <typename T>
 inline T exchange_read(T v, int src) {
