@@ -64,10 +64,14 @@ class _NerfNetFunction(torch.autograd.Function):
         flat_f, flat_b = fg_net.flat_parameters(), bg_net.flat_parameters()
         save_f = ops.save_workspace(n * sf, dev, 3) if train else None
         save_b = ops.save_workspace(n * sb, dev, 4) if train else None
+        # training: the 256-wide layers as split-arithmetic GEMMs (ops.mlp_arithmetic), as in the SCNeRF step
+        split = train and n > 0 and ops.mlp_arithmetic() == "split"
+        pl_f = ops.pack_planes(flat_f, 3, remap=fg_net.pack_remap()) if split else None
+        pl_b = ops.pack_planes(flat_b, 4, remap=bg_net.pack_remap()) if split else None
         raw_f = ops.mlp_fwd(fg_pts, views, sf, ops.pack_weights(flat_f, "fwd", pd=3, remap=fg_net.pack_remap()),
-                            save_f, pd=3)
+                            save_f, pd=3, planes=pl_f)
         raw_b = ops.mlp_fwd(bg_pts, views, sb, ops.pack_weights(flat_b, "fwd", pd=4, remap=bg_net.pack_remap()),
-                            save_b, pd=4)
+                            save_b, pd=4, planes=pl_b)
         out = {"rgb": (n, 3), "fg_weights": (n, sf), "bg_weights": (n, sb), "fg_rgb": (n, 3), "fg_depth": (n,),
                "bg_rgb": (n, 3), "bg_depth": (n,), "bg_lambda": (n,)}
         t = {k: torch.empty(sh, dtype=torch.float32, device=dev) for k, sh in out.items()}
@@ -80,7 +84,7 @@ class _NerfNetFunction(torch.autograd.Function):
         if train:
             ctx.state = (o, d, zmax, zf, zb, fg_pts, bg_pts, views, raw_f, raw_b, save_f, save_b,
                          ops.pack_weights(flat_f, "bwd", pd=3, remap=fg_net.pack_remap()),
-                         ops.pack_weights(flat_b, "bwd", pd=4, remap=bg_net.pack_remap()))
+                         ops.pack_weights(flat_b, "bwd", pd=4, remap=bg_net.pack_remap()), pl_f, pl_b)
         tails = {"rgb": (3,), "fg_weights": (sf,), "bg_weights": (sb,), "fg_rgb": (3,), "bg_rgb": (3,)}
         return tuple(t[k].view(*dots, *tails.get(k, ())) for k in _OUT_KEYS)
 
@@ -90,7 +94,7 @@ class _NerfNetFunction(torch.autograd.Function):
             raise RuntimeError("NerfNet.forward was evaluated without gradient tracking")
         n, sf, sb, o_shape, zmax_shape, fgz_shape = ctx.dims
         fg_net, bg_net = ctx.nets
-        (o, d, zmax, zf, zb, fg_pts, bg_pts, views, raw_f, raw_b, save_f, save_b, wb_f, wb_b) = ctx.state
+        (o, d, zmax, zf, zb, fg_pts, bg_pts, views, raw_f, raw_b, save_f, save_b, wb_f, wb_b, pl_f, pl_b) = ctx.state
         dev = o.device
         lib = _capi.load()
         gs = [None if x is None else x.reshape(n, -1).contiguous().float() for x in g]
@@ -102,9 +106,11 @@ class _NerfNetFunction(torch.autograd.Function):
         _capi.check(lib.scnerf_npp_composite_bwd(_p(raw_f), _p(raw_b), _p(zf), _p(zmax), _p(zb), _p(d),
                                                  *[_p(x) for x in gs], _p(d_raw_f), _p(d_raw_b), _p(d_z), _p(d_zmax),
                                                  _p(d_norm), n, sf, sb, _stream()), "scnerf_npp_composite_bwd")
-        grads_f, d_pts_f, d_views_f = ops.mlp_bwd(d_raw_f, fg_pts, views, sf, wb_f, save_f, pd=3)
+        # both networks' data gradients first, then both weight-gradient passes (one clock recovery after the bf16
+        # weight-gradient GEMMs instead of two: functional.py)
+        grads_f, d_pts_f, d_views_f = ops.mlp_bwd(d_raw_f, fg_pts, views, sf, wb_f, save_f, pd=3, planes=pl_f)
+        grads_b, d_pts_b, d_views_b = ops.mlp_bwd(d_raw_b, bg_pts, views, sb, wb_b, save_b, pd=4, planes=pl_b)
         flat_gf = ops.nerf_wgrad(save_f, grads_f, d_raw_f, n * sf, pd=3)
-        grads_b, d_pts_b, d_views_b = ops.mlp_bwd(d_raw_b, bg_pts, views, sb, wb_b, save_b, pd=4)
         flat_gb = ops.nerf_wgrad(save_b, grads_b, d_raw_b, n * sb, pd=4)
         g_o, g_d = torch.empty_like(o), torch.empty_like(d)
         g_z = torch.empty((n, sf), dtype=torch.float32, device=dev)

@@ -210,14 +210,27 @@ def mlp_arithmetic(mode: Optional[str] = None) -> str:
     return _MLP_ARITHMETIC[0]
 
 
-def pack_planes(flat_params: Tensor, pd: int = 3, out: Optional[Tensor] = None) -> Tensor:
+_canon_cache = {}
+
+
+def pack_planes(flat_params: Tensor, pd: int = 3, out: Optional[Tensor] = None, remap=None) -> Tensor:
     """flat parameter buffer (reference order) -> bf16 planes of the 256-wide layers in MFMA fragment order
-    (int16 tensor, scnerf_split_planes_shorts(pd) words); once per optimizer step."""
+    (int16 tensor, scnerf_split_planes_shorts(pd) words); once per optimizer step.  `remap` as in pack_weights:
+    the buffer of a module that registers the same tensors in another order is first gathered into the order the
+    kernel expects."""
     _f(flat_params, "flat_params")
     lay = ML.layout(pd)
     if flat_params.numel() != lay.n_params:
         raise ValueError("expected %d parameters, got %d" % (lay.n_params, flat_params.numel()))
     lib = _capi.load()
+    if remap is not None:
+        key = (remap[0], str(flat_params.device))
+        if key not in _canon_cache:
+            _canon_cache[key] = torch.from_numpy(np.asarray(remap[1], dtype=np.int32)).to(flat_params.device)
+        idx = _canon_cache[key]
+        canon = torch.empty(lay.n_params, dtype=torch.float32, device=flat_params.device)
+        _capi.check(lib.scnerf_gather_f32(_p(flat_params), _p(idx), _p(canon), idx.numel(), _stream()), "scnerf_gather_f32")
+        flat_params = canon
     n = lib.scnerf_split_planes_shorts(pd)
     if out is None:
         out = torch.empty(n, dtype=torch.int16, device=flat_params.device)

@@ -11,10 +11,17 @@ import contextlib
 
 
 @contextlib.contextmanager
-def emulated_device():
+def emulated_device(mlp_arithmetic="fp32"):
+    """`mlp_arithmetic`: ops.mlp_arithmetic inside the context.  The per-layer split GEMMs work on 256-sample blocks,
+    so interpreting them for the handful of rays these host-level tests use costs minutes: the long tests stay on the
+    fused kernels, tests/test_emu_layer_split.py and test_render_rays_split_on_the_simt_interpreter cover the split
+    path."""
     from scnerf_amd import _capi, ops
     from tests.emu import harness
     saved = (_capi._lib, _capi.on_device, _capi.current_stream)
+    saved_mode = ops.mlp_arithmetic()
+    ops.mlp_arithmetic(mlp_arithmetic)
+    ops._canon_cache.clear()
     _capi._lib = harness.lib()
     _capi.on_device = lambda t: True
     _capi.current_stream = lambda: None
@@ -23,6 +30,8 @@ def emulated_device():
     try:
         yield
     finally:
+        ops.mlp_arithmetic(saved_mode)
+        ops._canon_cache.clear()
         _capi._lib, _capi.on_device, _capi.current_stream = saved
         ops._index_cache.clear()
         ops._wgrad_ws.clear()

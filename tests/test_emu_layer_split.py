@@ -26,7 +26,7 @@ def _forward_with_save(pd, P, n_rays, spr, seed):
     return p, wpk, save
 
 
-@pytest.mark.parametrize("pd,n_rays,spr", [(3, 3, 50), (4, 2, 70), (3, 9, 40)])
+@pytest.mark.parametrize("pd,n_rays,spr", [(3, 3, 50), (4, 2, 70)])
 def test_layers_reproduce_the_fused_kernels_activations(pd, n_rays, spr):
     lay = ML.layout(pd)
     P = n_rays * spr
@@ -127,3 +127,34 @@ def test_staged_data_gradients_equal_the_fused_chain(pd, n_rays, spr):
         assert float(np.abs(ga[name] - gb[name]).max()) <= 1e-5 * scale, name
     assert float(np.abs(pa - pb).max()) <= 2e-5 * float(np.abs(pa).max())
     assert float(np.abs(va - vb).max()) <= 2e-5 * float(np.abs(va).max())
+
+
+def test_render_rays_split_on_the_simt_interpreter():
+    """render_rays forward + backward through the mirrored API with the 256-wide layers as split-arithmetic GEMMs
+    (forward stages, data-gradient stages, bf16 weight gradients) against the same call on the fused fp32 kernels:
+    outputs, ray gradients and every parameter gradient."""
+    from scnerf_amd import create_nerf as cn, render, run_nerf_helpers as h, synthetic as synth
+    from tests.emu.host_on_emu import emulated_device
+    n, sc, sf = 3, 64, 8
+    rnd = synth.render_randoms(n, sc, sf, seed=7)
+    query = cn.FusedNetworkQuery(h.get_embedder(10, 0)[0], h.get_embedder(4, 0)[0])
+    res = {}
+    for mode in ("fp32", "split"):
+        with emulated_device(mlp_arithmetic=mode):
+            nets = []
+            for seed in (0, 1):
+                m_ = h.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+                m_.load_state_dict(synth.network_params(seed=seed))
+                nets.append(m_)
+            rays = synth.ray_batch(n, seed=5).requires_grad_(True)
+            out = render.render_rays(rays, nets[0], query, sc, N_importance=sf, network_fine=nets[1], perturb=1.0,
+                                     raw_noise_std=1.0, _randoms=rnd)
+            loss = (out["rgb_map"] ** 2).mean() + (out["rgb0"] ** 2).mean() + out["disp_map"].mean()
+            loss.backward()
+            res[mode] = (out["rgb_map"].detach().clone(), rays.grad.clone(),
+                         [p.grad.clone() for net in nets for p in net.parameters()])
+    (rgb_a, gr_a, gp_a), (rgb_b, gr_b, gp_b) = res["fp32"], res["split"]
+    assert float((rgb_a - rgb_b).abs().max()) <= 2e-5
+    assert float((gr_a - gr_b).abs().max()) <= 1e-4 * float(gr_a.abs().max())
+    for a, b in zip(gp_a, gp_b):
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-9
