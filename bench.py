@@ -367,8 +367,8 @@ def main():
                     "measured": "HIP events around 20 back-to-back launches of scnerf_layer_split (layer 2) on a workspace of "
                                 "the fine pass's size, after the timed region; in the step these launches sit inside the "
                                 "mlp_fwd / mlp_bwd calls of `kernels` (profiles/*kernel_trace* has their in-step average)",
-                    "note": "power-bound: the shader clock falls to ~1.7 GHz under bf16 MFMAs at this density "
-                            "(profiles/r02d_pmc_kernels.txt), so the pipe's busy fraction is higher than frac"}
+                    "note": "stall-bound: matrix pipe busy 55 % of the cycles at 2.04 GHz (profiles/r02e_pmc_kernels.txt, "
+                            "DESIGN.md 4.2b); MFMAs + weight stream alone run the launch in 0.32 ms"}
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.isfile(pmc):
                 rec = json.load(open(pmc))
