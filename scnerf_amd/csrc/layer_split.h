@@ -44,6 +44,12 @@
 // pending-miss stalls 68 % of the cycles (TCP_PENDING_STALL, 6 % without), but halving the L1 requests -- four waves
 // side by side along the samples, each owning all 256 features of 64 samples, so that no two waves load the same
 // activations -- moved the cost into the epilogue (32 dependent pieces per tile) and the total not at all (0.547 ms).
+// Per CU and slab 56 KB go through the L1's 64 B/clk address unit (896 of ~4000 cycles), four lock-stepped waves at
+// a time; giving every wave load slots of its own (uniform `if (wave == k)` around each load) made it WORSE
+// (0.77 ms): behind every such branch the compiler's wait-count pass falls back to `s_waitcnt vmcnt(0)` (156 of them).
+// Two rows of the epilogue interleaved with prefetched bias pieces: no change (the epilogue's cost is its 64 stores
+// per wave, 0.056 ms, and 0.035 ms of arithmetic).  Run on half of the CUs each workgroup is 25 % faster (MFMAs
+// + weight stream alone: 21 %): the full chip is also clock-limited (2.04 GHz sustained).
 #pragma once
 #include <type_traits>
 
