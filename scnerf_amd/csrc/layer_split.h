@@ -49,7 +49,8 @@
 // (0.77 ms): behind every such branch the compiler's wait-count pass falls back to `s_waitcnt vmcnt(0)` (156 of them).
 // Two rows of the epilogue interleaved with prefetched bias pieces: no change (the epilogue's cost is its 64 stores
 // per wave, 0.056 ms, and 0.035 ms of arithmetic).  Run on half of the CUs each workgroup is 25 % faster (MFMAs
-// + weight stream alone: 21 %): the full chip is also clock-limited (2.04 GHz sustained).
+// + weight stream alone: 21 %): the full chip is also clock-limited (2.04 GHz sustained).  Without any barrier in the
+// slab loop (racy, timing only): 0.551 vs 0.555 ms -- neither the barrier nor the lock-step of the waves costs.
 #pragma once
 #include <type_traits>
 
@@ -88,6 +89,7 @@ enum : int {
     kNoEpilogue = 1,      // timing experiment: only the last block is stored
     kNoCut = 2,           // timing experiment: no loads / cuts of X (planes hold garbage)
     kNoCutMath = 8,       // timing experiment: X is loaded but not cut (the raw words serve as planes)
+    kNoBarrier = 64,      // timing experiment: no workgroup barriers in the slab loop (racy: results are wrong)
     kPlainStore = 4,      // experiment: default-policy stores instead of non-temporal ones (no difference)
     kNoZStore = 16,       // experiment: the epilogue computes but stores only the mask words
 };
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
         constexpr int pl = decltype(pl_tag)::value, i = decltype(i_tag)::value;
         wf[pl][i] = *(reinterpret_cast<const s16x8*>(lds + buf * kSlabShorts) + (pl * 8 + 4 * wn + i) * 64 + lane);
     };
-    auto sync = [&]() { block_sync(); };
+    auto sync = [&]() { if constexpr (!(FLAGS & kNoBarrier)) block_sync(); };
 
     // one sample tile of one slab: 24 MFMAs; `filler(slot)` goes in front of MFMA `slot`
     auto iteration = [&](auto j_tag, auto pp_tag, auto first_tag, auto filler) {

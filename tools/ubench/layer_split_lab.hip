@@ -134,6 +134,8 @@ int main(int argc, char** argv) {
     report("layer split x6, epilogue without Z stores", time_kernel(layer_split_kernel<kNoZStore>, a, G, 40));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kNoCutMath | kNoEpilogue>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
     report("layer split x6, X loaded but not cut, no epilogue", time_kernel(layer_split_kernel<kNoCutMath | kNoEpilogue>, a, G, 40));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kNoBarrier>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    report("layer split x6, no barriers (racy)", time_kernel(layer_split_kernel<kNoBarrier>, a, G, 40));
     report("layer split x6, no epilogue", time_kernel(layer_split_kernel<kNoEpilogue>, a, G, 40));
     report("layer split x6, no X loads / cuts", time_kernel(layer_split_kernel<kNoCut>, a, G, 40));
     report("layer split x6, MFMA + W stream only", time_kernel(layer_split_kernel<kNoCut | kNoEpilogue>, a, G, 40));
