@@ -360,7 +360,8 @@ def main():
             ach = flop / (layer_ms * 1e-3) / 1e12
             dom = "layer_split_kernel/P=%d" % P_f
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_SPLIT_TFLOPS,
-                    "unit": "TFLOP/s (fp32 products; peak = dense bf16 MFMA rate / 6 partial products)",
+                    "unit": "TFLOP/s",
+                    "peak_note": "fp32 products per second; peak = dense bf16 MFMA rate (2500) / 6 partial products per fp32 product",
                     "frac": ach / PEAK_SPLIT_TFLOPS, "traffic": None, "avg_launch_ms": layer_ms,
                     "launches_per_step": 16.0, "flop_per_launch": flop,
                     "achieved_over_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
