@@ -131,32 +131,6 @@ def _timed(step, steps, warmup, sync, profile=True):
     return dt / steps * 1e3, (_kernel_table(ops.PROFILE.summary(), steps) if profile else None)
 
 
-def time_layer_kernel(P, dev, iters=20):
-    """ms per launch of the split-arithmetic layer GEMM at P samples (HIP events on the current stream)"""
-    from scnerf_amd import _capi, mlp_layout as ML, ops, synthetic as synth
-    lay = ML.layout(3)
-    p = synth.network_params(seed=0)
-    flat = torch.cat([p[name].reshape(-1) for name, _ in ML.PARAM_SHAPES]).to(dev)
-    wf, planes = ops.pack_weights(flat, "fwd"), ops.pack_planes(flat)
-    save = ops.save_workspace(P, dev).zero_()
-    Pp = ML.padded_samples(P)
-    off, total = ML.section_offsets(lay.save_sections, P)
-    lib = _capi.load()
-    esz = save.element_size()
-    base = save.data_ptr()
-    args = (3, 2, planes.data_ptr(), wf.data_ptr() + (lay.fwd_bias + 512) * 4, base + off["act1"] * esz, base + off["epts"] * esz,
-            base + off["act2"] * esz, base + (total + 2 * (Pp // 32) * 256) * esz, P, ops._stream())
-    for _ in range(3):
-        _capi.check(lib.scnerf_layer_split(*args), "scnerf_layer_split")
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        lib.scnerf_layer_split(*args)
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1) / iters
-
-
 def build_world(dev, rank, n):
     """networks, query object, camera model, per-rank synthetic data"""
     from scnerf_amd import synthetic as synth
@@ -343,45 +317,30 @@ def main():
         dt = float(tt.item())
     ms = dt / a.steps * 1e3
 
-    layer_ms = None
-    if rank == 0 and ops.mlp_arithmetic() == "split":
-        layer_ms = time_layer_kernel(n * (S_C + S_F), dev)
     if rank == 0:
         kern = ops.PROFILE.summary()
         # dominant kernel family by total time
         single = {k: v for k, v in kern.items() if not v["group"]}
         dom = max(single, key=lambda k: single[k]["total_ms"]) if single else None
         roof = None
-        if layer_ms is not None:
-            # split mode: the dominant kernel is the per-layer GEMM (16 launches per step at the fine pass's size, 16 at
-            # the coarse pass's), issued from inside one C call per pass; timed here launch by launch
-            P_f = n * (S_C + S_F)
-            flop = 2.0 * 256 * 256 * P_f
-            ach = flop / (layer_ms * 1e-3) / 1e12
-            dom = "layer_split_kernel/P=%d" % P_f
-            roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_SPLIT_TFLOPS,
-                    "unit": "TFLOP/s",
-                    "peak_note": "fp32 products per second; peak = dense bf16 MFMA rate (2500) / 6 partial products per fp32 product",
-                    "frac": ach / PEAK_SPLIT_TFLOPS, "traffic": None, "avg_launch_ms": layer_ms,
-                    "launches_per_step": 16.0, "flop_per_launch": flop,
-                    "achieved_over_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
-                    "measured": "HIP events around 20 back-to-back launches of scnerf_layer_split (layer 2) on a workspace of "
-                                "the fine pass's size, after the timed region; in the step these launches sit inside the "
-                                "mlp_fwd / mlp_bwd calls of `kernels` (profiles/*kernel_trace* has their in-step average)",
-                    "note": "stall-bound: matrix pipe busy 55 % of the cycles at 2.04 GHz (profiles/r02e_pmc_kernels.txt, "
-                            "DESIGN.md 4.2b); MFMAs + weight stream alone run the launch in 0.32 ms"}
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.isfile(pmc):
-                rec = json.load(open(pmc))
-                roof["traffic"] = rec.get(dom)
-                roof["traffic_source"] = rec.get("_source")
-        elif dom:
+        if dom:
             k = kern[dom]
             ach = k["flop_per_launch"] / (k["avg_ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            split_kernel = dom.startswith("layer_split_kernel")
+            peak = PEAK_SPLIT_TFLOPS if split_kernel else PEAK_F32_MFMA_TFLOPS
+            roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak,
+                    "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                     "avg_launch_ms": k["avg_ms"], "launches_per_step": k["launches"] / a.steps,
                     "flop_per_launch": k["flop_per_launch"]}
+            if split_kernel:
+                roof["peak_note"] = ("fp32 products per second; peak = dense bf16 MFMA rate (2500) / 6 partial products per "
+                                     "fp32 product")
+                roof["achieved_over_fp32_mfma_peak"] = ach / PEAK_F32_MFMA_TFLOPS
+                roof["measured"] = ("HIP events around each of the launches of this size inside the timed region (forward "
+                                    "layers 1-8 and the eight transposed layers of the data-gradient chain of the fine pass; "
+                                    "layer 5 carries 25 % more FLOP: flop_per_launch is the mean)")
+                roof["note"] = ("stall-bound: matrix pipe busy 55 % of the cycles at 2.04 GHz (profiles/r02e_pmc_kernels.txt, "
+                                "DESIGN.md 4.2b); MFMAs + weight stream alone run the launch in 0.32 ms")
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.isfile(pmc):
                 rec = json.load(open(pmc))

@@ -249,6 +249,20 @@ int scnerf_nerf_param_count(int pt_dims);
 /* scnerf_mlp_bwd_split: scnerf_mlp_bwd with the eight 256-wide transposed layers (feature_linear^T + the density
  * head, layers 7 .. 1) as such GEMMs between the heads and the encoded-point end of the fused kernel; same arguments
  * plus `planes` (the buffer holds the transposed planes too), same outputs. */
+/* The pieces of the two calls above one launch at a time (per-kernel timing): scnerf_mlp_fwd_stage (1 = encoding +
+ * layer 0, 2 = heads) around scnerf_layer_split for layers 1 .. 8; scnerf_mlp_bwd_stage (1 = heads, 2 = encoded-point
+ * end) around scnerf_layer_split_bwd for entries 0 .. 7 (0 = feature_linear^T + the density head's rank-1 term from
+ * d_raw, e = layer (8 - e)^T; grad_in = d feature | dZ_{8-e}, grad_out = dZ_{7-e}, mask_in = ReLU bits of layer 7 - e,
+ * alpha_table = the lane-vector alpha weights inside the packed backward weights). */
+int scnerf_mlp_fwd_stage(int pt_dims, int stage, const float* pts, const float* viewdirs, int vd_stride,
+                         int samples_per_ray, const float* wpacked, float* raw, float* save, long long n_samples,
+                         void* stream);
+int scnerf_mlp_bwd_stage(int pt_dims, int stage, const float* d_raw, const float* pts, const float* viewdirs,
+                         int vd_stride, int samples_per_ray, const float* wpacked_bwd, const float* save, float* grads,
+                         float* d_pts, float* d_views, long long n_samples, void* stream);
+int scnerf_layer_split_bwd(int pt_dims, int entry, const short* planes, const float* alpha_table, const float* grad_in,
+                           float* grad_out, const unsigned* mask_in, const float* d_raw, long long n_samples,
+                           void* stream);
 long long scnerf_split_planes_shorts(int pt_dims);
 int scnerf_mlp_bwd_split(int pt_dims, const float* d_raw, const float* pts, const float* viewdirs, int vd_stride,
                          int samples_per_ray, const float* wpacked_bwd, const short* planes, const float* save,

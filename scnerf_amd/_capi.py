@@ -69,6 +69,9 @@ PROTOTYPES = {
     "scnerf_wgrad_arithmetic": [I],
     "scnerf_pack_split_planes": [I, P, P, P],
     "scnerf_mlp_fwd_split": [I, P, P, I, I, P, P, P, P, LL, P],
+    "scnerf_mlp_fwd_stage": [I, I, P, P, I, I, P, P, P, LL, P],
+    "scnerf_mlp_bwd_stage": [I, I, P, P, P, I, I, P, P, P, P, P, LL, P],
+    "scnerf_layer_split_bwd": [I, I, P, P, P, P, P, P, LL, P],
     "scnerf_mlp_bwd_split": [I, P, P, P, I, I, P, P, P, P, P, P, LL, P],
     "scnerf_coarse_stage_fwd_split": [P, I, P, P, I, P, P, P, P, I, P, P, P, P, P, P, P, P, I, I, P],
     "scnerf_layer_split": [I, I, P, P, P, P, P, P, LL, P],

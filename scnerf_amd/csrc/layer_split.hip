@@ -183,3 +183,15 @@ extern "C" int scnerf_layer_split(int pt_dims, int layer, const short* planes, c
     return pt_dims == 3 ? scn::lsp::launch_network_layer<3>(layer, planes, bias_table, act_in, epts, act_out, mask, Ppad, st)
                         : scn::lsp::launch_network_layer<4>(layer, planes, bias_table, act_in, epts, act_out, mask, Ppad, st);
 }
+
+extern "C" int scnerf_layer_split_bwd(int pt_dims, int entry, const short* planes, const float* alpha_table,
+                                      const float* grad_in, float* grad_out, const unsigned* mask_in, const float* d_raw,
+                                      long long n_samples, void* stream) {
+    SCN_RETURN_IF(!planes || !alpha_table || !grad_in || !grad_out || !mask_in || !d_raw || n_samples < 0, SCN_EINVAL);
+    SCN_RETURN_IF((pt_dims != 3 && pt_dims != 4) || entry < 0 || entry > 7, SCN_EINVAL);
+    if (n_samples == 0) return 0;
+    const long Ppad = padded_samples(n_samples);
+    hipStream_t st = (hipStream_t)stream;
+    return pt_dims == 3 ? scn::lsp::launch_network_layer_bwd<3>(entry, planes, alpha_table, grad_in, grad_out, mask_in, d_raw + 3, 4, (long)n_samples, Ppad, st)
+                        : scn::lsp::launch_network_layer_bwd<4>(entry, planes, alpha_table, grad_in, grad_out, mask_in, d_raw + 3, 4, (long)n_samples, Ppad, st);
+}

@@ -291,6 +291,22 @@ extern "C" int scnerf_mlp_bwd(int pt_dims, const float* d_raw, const float* pts,
                         : launch_bwd<4, 0>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st);
 }
 
+// The pieces of scnerf_mlp_bwd_split one by one (for per-kernel timing: bench.py): stage 1 = heads, 2 = the
+// encoded-point end; the transposed layer GEMMs in between are scnerf_layer_split_bwd.
+extern "C" int scnerf_mlp_bwd_stage(int pt_dims, int stage, const float* d_raw, const float* pts, const float* viewdirs,
+                                    int vd_stride, int samples_per_ray, const float* wpacked_bwd, const float* save,
+                                    float* grads, float* d_pts, float* d_views, long long n_samples, void* stream) {
+    SCN_RETURN_IF(!d_raw || !pts || !viewdirs || !wpacked_bwd || !save || !grads || !d_pts || !d_views, SCN_EINVAL);
+    SCN_RETURN_IF((stage != 1 && stage != 2) || samples_per_ray < 1 || vd_stride < 3 || n_samples < 0 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
+    if (n_samples == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (pt_dims == 3)
+        return stage == 1 ? launch_bwd<3, 1>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st)
+                          : launch_bwd<3, 2>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st);
+    return stage == 1 ? launch_bwd<4, 1>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st)
+                      : launch_bwd<4, 2>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st);
+}
+
 extern "C" int scnerf_mlp_bwd_split(int pt_dims, const float* d_raw, const float* pts, const float* viewdirs,
                                     int vd_stride, int samples_per_ray, const float* wpacked_bwd, const short* planes,
                                     const float* save, float* grads, float* d_pts, float* d_views, long long n_samples,

@@ -411,6 +411,22 @@ extern "C" int scnerf_coarse_stage_fwd_split(const float* rays, int ray_stride, 
     return launch_coarse_stage<true, 2>(cs, wpacked, raw, save, st);
 }
 
+// The pieces of scnerf_mlp_fwd_split one by one (for per-kernel timing: bench.py): stage 1 = encoding + layer 0,
+// 2 = heads; the layer GEMMs in between are scnerf_layer_split.
+extern "C" int scnerf_mlp_fwd_stage(int pt_dims, int stage, const float* pts, const float* viewdirs, int vd_stride,
+                                    int samples_per_ray, const float* wpacked, float* raw, float* save,
+                                    long long n_samples, void* stream) {
+    SCN_RETURN_IF(!pts || !viewdirs || !wpacked || !raw || !save || (stage != 1 && stage != 2), SCN_EINVAL);
+    SCN_RETURN_IF(samples_per_ray < 1 || vd_stride < 3 || n_samples < 0 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
+    if (n_samples == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (pt_dims == 3)
+        return stage == 1 ? launch_fwd<3, true, 1>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, n_samples, st)
+                          : launch_fwd<3, true, 2>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, n_samples, st);
+    return stage == 1 ? launch_fwd<4, true, 1>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, n_samples, st)
+                      : launch_fwd<4, true, 2>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, n_samples, st);
+}
+
 extern "C" int scnerf_mlp_fwd_split(int pt_dims, const float* pts, const float* viewdirs, int vd_stride,
                                     int samples_per_ray, const float* wpacked, const short* planes, float* raw,
                                     float* save, long long n_samples, void* stream) {

@@ -54,7 +54,7 @@ class _Profile:
         for name, recs in self.records.items():
             ms = [a.elapsed_time(b) for a, b, _, _ in recs]
             out[name] = {"launches": len(recs), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms),
-                         "flop_per_launch": recs[0][2], "group": recs[0][3]}
+                         "flop_per_launch": sum(r[2] for r in recs) / len(recs), "group": recs[0][3]}
         return out
 
 
@@ -251,6 +251,31 @@ def _vd(viewdirs: Tensor):
 _MAC_PER_SAMPLE = {3: 593408, 4: 593408 + 2 * 256 * 21}       # layer 0 and the skip layer are 21 columns wider
 
 
+def _layer_flop(pd: int, layer: int, P: int) -> int:
+    return 2 * 256 * (256 + (ML.layout(pd).in_pts if layer == 5 else 0)) * P
+
+
+def _fwd_split_piecewise(pd, P, tag, wpacked, planes, save, stage_call):
+    """stage 1, layers 1 .. 8, stage 2 of the split-arithmetic training forward as separate C calls (what
+    scnerf_mlp_fwd_split / scnerf_coarse_stage_fwd_split do inside), each in a PROFILE region"""
+    lay, lib = ML.layout(pd), _capi.load()
+    Pp = ML.padded_samples(P)
+    off, total = ML.section_offsets(lay.save_sections, P)
+    base, esz = save.data_ptr(), 4
+    names = ["act%d" % l for l in range(8)] + ["feat"]
+    with PROFILE.region("mlp_fwd_kernel<stage 1: encoding + layer 0>%s/P=%d" % (tag, P), 2 * 256 * lay.in_pts * P):
+        _capi.check(stage_call(1), "forward stage 1")
+    for l in range(1, 9):
+        bias = wpacked.data_ptr() + ((lay.fwd_bias + 256 * l) if l < 8 else lay.fwd_bias_f) * esz
+        mask = base + (total + l * (Pp // 32) * 256) * esz if l < 8 else None
+        with PROFILE.region("layer_split_kernel%s/P=%d" % (tag, P), _layer_flop(pd, l, P)):
+            _capi.check(lib.scnerf_layer_split(pd, l, _p(planes), bias, base + off[names[l - 1]] * esz,
+                                               base + off["epts"] * esz, base + off[names[l]] * esz, mask, P, _stream()),
+                        "scnerf_layer_split")
+    with PROFILE.region("mlp_fwd_kernel<stage 2: heads>%s/P=%d" % (tag, P), 2 * (128 * 283 + 3 * 128 + 256) * P):
+        _capi.check(stage_call(2), "forward stage 2")
+
+
 def mlp_fwd(pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked: Tensor,
             save: Optional[Tensor] = None, pd: int = 3, planes: Optional[Tensor] = None) -> Tensor:
     """pts [P, pd] (pd = 3: x y z; pd = 4: x y z 1/r) -> raw [P, 4] (rgb logits, sigma pre-activation).
@@ -271,8 +296,16 @@ def mlp_fwd(pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked: Tensor
         if save is None:
             raise ValueError("the split-arithmetic forward runs through the activation workspace (training mode)")
         with PROFILE.region("mlp_fwd(stages + 8 layer GEMMs)%s/P=%d/train" % (tag, P), 2 * _MAC_PER_SAMPLE[pd] * P, group=True):
-            st = _capi.load().scnerf_mlp_fwd_split(pd, _p(pts), vptr, vstride, int(samples_per_ray), _p(wpacked),
-                                                   _p(planes), _p(raw), _p(save), P, _stream())
+            if PROFILE.enabled:
+                # the same ten launches one by one, each in its own timing region
+                _fwd_split_piecewise(pd, P, tag, wpacked, planes, save,
+                                     lambda stage: _capi.load().scnerf_mlp_fwd_stage(
+                                         pd, stage, _p(pts), vptr, vstride, int(samples_per_ray), _p(wpacked), _p(raw),
+                                         _p(save), P, _stream()))
+                st = 0
+            else:
+                st = _capi.load().scnerf_mlp_fwd_split(pd, _p(pts), vptr, vstride, int(samples_per_ray), _p(wpacked),
+                                                       _p(planes), _p(raw), _p(save), P, _stream())
         _capi.check(st, "scnerf_mlp_fwd_split")
         return raw
     with PROFILE.region("mlp_fwd_kernel%s/P=%d/%s" % (tag, P, "train" if save is not None else "infer"),
@@ -316,6 +349,8 @@ def coarse_stage_fwd(rays: Tensor, t_vals: Tensor, t_rand: Optional[Tensor], lin
         if save is None:
             raise ValueError("the split-arithmetic forward runs through the activation workspace (training mode)")
         with PROFILE.region("mlp_fwd(stages + 8 layer GEMMs)/P=%d/train" % P, 2 * _MAC_PER_SAMPLE[3] * P, group=True):
+            # (profiled or not: one C call; its layer launches are timed at this size by the fine pass's regions'
+            # twin below only when the fused coarse stage is not in use)
             st = _capi.load().scnerf_coarse_stage_fwd_split(
                 _p(rays), rays.shape[1], _p(t_vals), _p(t_rand), int(bool(lindisp)), _p(wpacked), _p(planes), _p(save),
                 _p(noise), int(bool(white_bkgd)), _p(z), _p(pts), _p(raw), _p(rgb), _p(disp), _p(acc), _p(depth), _p(w),
@@ -332,6 +367,29 @@ def coarse_stage_fwd(rays: Tensor, t_vals: Tensor, t_rand: Optional[Tensor], lin
 
 def save_workspace(P: int, device, pd: int = 3) -> Tensor:
     return torch.empty(ML.layout(pd).save_floats(P), dtype=torch.float32, device=device)
+
+
+def _bwd_split_piecewise(pd, P, tag, wpacked_bwd, planes, save, grads, d_raw, stage_call):
+    """stage 1, the eight transposed layers, stage 2 of the split-arithmetic data-gradient chain as separate C calls,
+    each in a PROFILE region"""
+    lay, lib = ML.layout(pd), _capi.load()
+    Pp = ML.padded_samples(P)
+    _, total = ML.section_offsets(lay.save_sections, P)
+    goff, _ = ML.section_offsets(ML.GRAD_SECTIONS, P)
+    gnames = ["dz%d" % l for l in range(8)]
+    masks = save.data_ptr() + total * 4
+    alpha = wpacked_bwd.data_ptr() + lay.bwd_alpha_w * 4
+    with PROFILE.region("mlp_bwd_kernel<stage 1: heads>%s/P=%d" % (tag, P), 2 * (128 * 283 + 3 * 128) * P):
+        _capi.check(stage_call(1), "backward stage 1")
+    for e in range(8):
+        src = goff["dfeat"] if e == 0 else goff[gnames[8 - e]]
+        dst = goff[gnames[7 - e]]
+        with PROFILE.region("layer_split_kernel%s/P=%d" % (tag, P), 2 * 256 * 256 * P):
+            _capi.check(lib.scnerf_layer_split_bwd(pd, e, _p(planes), alpha, grads.data_ptr() + src * 4,
+                                                   grads.data_ptr() + dst * 4, masks + (7 - e) * (Pp // 32) * 256 * 4,
+                                                   _p(d_raw), P, _stream()), "scnerf_layer_split_bwd")
+    with PROFILE.region("mlp_bwd_kernel<stage 2: encoded-point end>%s/P=%d" % (tag, P), 2 * 2 * 256 * lay.in_pts * P):
+        _capi.check(stage_call(2), "backward stage 2")
 
 
 def mlp_bwd(d_raw: Tensor, pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked_bwd: Tensor,
@@ -351,9 +409,16 @@ def mlp_bwd(d_raw: Tensor, pts: Tensor, viewdirs: Tensor, samples_per_ray: int, 
     if planes is not None:
         with PROFILE.region("mlp_bwd(stages + 8 layer GEMMs)%s/P=%d" % ("" if pd == 3 else "/pd4", P),
                             2 * _MAC_PER_SAMPLE[pd] * P, group=True):
-            st = _capi.load().scnerf_mlp_bwd_split(pd, _p(d_raw), _p(pts), vptr, vstride, int(samples_per_ray),
-                                                   _p(wpacked_bwd), _p(planes), _p(save), _p(grads), _p(d_pts),
-                                                   _p(d_views), P, _stream())
+            if PROFILE.enabled:
+                _bwd_split_piecewise(pd, P, "" if pd == 3 else "/pd4", wpacked_bwd, planes, save, grads, d_raw,
+                                     lambda stage: _capi.load().scnerf_mlp_bwd_stage(
+                                         pd, stage, _p(d_raw), _p(pts), vptr, vstride, int(samples_per_ray),
+                                         _p(wpacked_bwd), _p(save), _p(grads), _p(d_pts), _p(d_views), P, _stream()))
+                st = 0
+            else:
+                st = _capi.load().scnerf_mlp_bwd_split(pd, _p(d_raw), _p(pts), vptr, vstride, int(samples_per_ray),
+                                                       _p(wpacked_bwd), _p(planes), _p(save), _p(grads), _p(d_pts),
+                                                       _p(d_views), P, _stream())
         _capi.check(st, "scnerf_mlp_bwd_split")
         return grads, d_pts, d_views
     with PROFILE.region("mlp_bwd_kernel%s/P=%d" % ("" if pd == 3 else "/pd4", P), 2 * _MAC_PER_SAMPLE[pd] * P):

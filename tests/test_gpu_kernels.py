@@ -326,3 +326,34 @@ def test_split_layer_gemm_is_fp32_grade(ops):
     for layer, r in report.items():
         assert r["split"]["rms"] <= 2.0 * r["fp32"]["rms"] and r["split"]["max"] <= 3.0 * r["fp32"]["max"] + 1e-9, (layer, r)
         assert r["split"]["max"] < 1e-6, (layer, r)
+
+
+def test_profiled_piecewise_launches_equal_the_single_calls(ops):
+    """With ops.PROFILE enabled (bench.py) the split-arithmetic forward / data-gradient chain is issued launch by launch
+    from Python (scnerf_mlp_fwd_stage, scnerf_layer_split, scnerf_layer_split_bwd, scnerf_mlp_bwd_stage) so that
+    every kernel gets its own HIP-event region; the results must be bit-identical to the single C calls."""
+    from tests.emu_mlp_util import network_params
+    for pd, n_rays, spr in ((3, 40, 50), (4, 33, 70)):
+        p = network_params(4 if pd == 3 else 779, pd)
+        flat = dev(_flat(p, pd))
+        P = n_rays * spr
+        g = torch.Generator().manual_seed(9)
+        pts = dev(torch.rand(P, pd, generator=g) * 2.4 - 1.2)
+        vd = torch.randn(n_rays, 3, generator=g)
+        vd = dev(vd / vd.norm(dim=-1, keepdim=True))
+        d_raw = dev(torch.randn(P, 4, generator=g))
+        wf, wb, planes = ops.pack_weights(flat, "fwd", pd=pd), ops.pack_weights(flat, "bwd", pd=pd), ops.pack_planes(flat, pd)
+        res = []
+        for profiled in (False, True):
+            ops.PROFILE.reset(enabled=profiled)
+            try:
+                save = ops.save_workspace(P, "cuda", pd).zero_()
+                raw = ops.mlp_fwd(pts, vd, spr, wf, save, pd=pd, planes=planes)
+                grads, d_pts, d_views = ops.mlp_bwd(d_raw, pts, vd, spr, wb, save, pd=pd, planes=planes)
+            finally:
+                names = set(ops.PROFILE.records)
+                ops.PROFILE.reset(enabled=False)
+            res.append((raw, save, grads, d_pts, d_views))
+        assert any(k.startswith("layer_split_kernel") for k in names)
+        for a, b in zip(*res):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
