@@ -336,11 +336,13 @@ def main():
                 roof["peak_note"] = ("fp32 products per second; peak = dense bf16 MFMA rate (2500) / 6 partial products per "
                                      "fp32 product")
                 roof["achieved_over_fp32_mfma_peak"] = ach / PEAK_F32_MFMA_TFLOPS
-                roof["measured"] = ("HIP events around each of the launches of this size inside the timed region (forward "
-                                    "layers 1-8 and the eight transposed layers of the data-gradient chain of the fine pass; "
-                                    "layer 5 carries 25 % more FLOP: flop_per_launch is the mean)")
-                roof["note"] = ("stall-bound: matrix pipe busy 55 % of the cycles at 2.04 GHz (profiles/r02e_pmc_kernels.txt, "
-                                "DESIGN.md 4.2b); MFMAs + weight stream alone run the launch in 0.32 ms")
+                roof["measured"] = ("HIP events around each of the launches of this size inside the timed region: one launch "
+                                    "runs the eight 256-wide layers of a pass (forward layers 1-8, or the eight transposed "
+                                    "layers of the data-gradient chain); flop_per_launch is the mean of the two")
+                roof["note"] = ("power-bound: matrix pipe busy 68-70 % of the cycles at a shader clock of 1.7 GHz, against the "
+                                "2.4 GHz the peak is quoted at (clock read inside the kernel, profiles/r02f_layer_split_lab.txt; "
+                                "counters, profiles/r02f_pmc_kernels.txt; DESIGN.md 4.2b): at the clock it is given the kernel "
+                                "delivers frac x 2.4 / 1.73 of the matrix pipe's rate")
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.isfile(pmc):
                 rec = json.load(open(pmc))

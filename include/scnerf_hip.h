@@ -263,6 +263,16 @@ int scnerf_mlp_bwd_stage(int pt_dims, int stage, const float* d_raw, const float
 int scnerf_layer_split_bwd(int pt_dims, int entry, const short* planes, const float* alpha_table, const float* grad_in,
                            float* grad_out, const unsigned* mask_in, const float* d_raw, long long n_samples,
                            void* stream);
+/* The eight layers of a pass as ONE launch (a workgroup keeps its 256-sample blocks from layer to layer, so layer
+ * l + 1 reads what the same workgroup wrote: no dependency between workgroups) when every persistent workgroup owns
+ * at least two blocks, else layer by layer: forward layers 1 .. 8 over the training workspace `save`, data-gradient
+ * entries 0 .. 7 over `grads`.  scnerf_layer_split_workgroups: cap on the persistent workgroups per launch (default
+ * 256 = one per CU; values outside 1 .. 1024 only query); returns the cap in force. */
+int scnerf_layer_split_chain_fwd(int pt_dims, const short* planes, const float* wpacked, float* save,
+                                 long long n_samples, void* stream);
+int scnerf_layer_split_chain_bwd(int pt_dims, const short* planes, const float* wpacked_bwd, const float* save,
+                                 float* grads, const float* d_raw, long long n_samples, void* stream);
+int scnerf_layer_split_workgroups(int n);
 long long scnerf_split_planes_shorts(int pt_dims);
 int scnerf_mlp_bwd_split(int pt_dims, const float* d_raw, const float* pts, const float* viewdirs, int vd_stride,
                          int samples_per_ray, const float* wpacked_bwd, const short* planes, const float* save,

@@ -72,6 +72,9 @@ PROTOTYPES = {
     "scnerf_mlp_fwd_stage": [I, I, P, P, I, I, P, P, P, LL, P],
     "scnerf_mlp_bwd_stage": [I, I, P, P, P, I, I, P, P, P, P, P, LL, P],
     "scnerf_layer_split_bwd": [I, I, P, P, P, P, P, P, LL, P],
+    "scnerf_layer_split_chain_fwd": [I, P, P, P, LL, P],
+    "scnerf_layer_split_chain_bwd": [I, P, P, P, P, P, LL, P],
+    "scnerf_layer_split_workgroups": [I],
     "scnerf_mlp_bwd_split": [I, P, P, P, I, I, P, P, P, P, P, P, LL, P],
     "scnerf_coarse_stage_fwd_split": [P, I, P, P, I, P, P, P, P, I, P, P, P, P, P, P, P, P, I, I, P],
     "scnerf_layer_split": [I, I, P, P, P, P, P, P, LL, P],

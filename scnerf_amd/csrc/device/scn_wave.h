@@ -48,12 +48,26 @@ __device__ __forceinline__ unsigned high_halves(unsigned lo_word, unsigned hi_wo
 // pointers (2 VGPRs per distinct offset, hoisted out of the loop, spilled).  The pointer stays in the global address
 // space (rebuilt from integers as a generic pointer it would produce flat loads).
 typedef const __attribute__((address_space(1))) char* global_bytes;
-__device__ __forceinline__ global_bytes uniform_global(const void* p) {
-    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+__device__ __forceinline__ global_bytes uniform_global_bits(unsigned long long v) {
     unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
     unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     asm("" : "+s"(lo), "+s"(hi));            // (readfirstlane of an already-scalar value folds away; this does not)
     return reinterpret_cast<global_bytes>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ global_bytes uniform_global(const void* p) {
+    return uniform_global_bits(reinterpret_cast<unsigned long long>(p));
+}
+__device__ __forceinline__ global_bytes uniform_global(global_bytes p) {
+    return uniform_global_bits(reinterpret_cast<unsigned long long>(p));
+}
+// clocks for lab measurements: shader-core cycles (follow the DVFS clock) and the constant 100 MHz reference
+__device__ __forceinline__ unsigned long long shader_cycles() { return __builtin_amdgcn_s_memtime(); }
+__device__ __forceinline__ unsigned long long reference_ticks() { return __builtin_amdgcn_s_memrealtime(); }
+// A per-lane value the compiler must recompute where it is used: keeps address arithmetic that is invariant in an
+// outer loop from being hoisted into long-lived registers (which then spill around a 256-AGPR MFMA loop).
+__device__ __forceinline__ unsigned pinned_here(unsigned x) {
+    asm volatile("" : "+v"(x));
+    return x;
 }
 __device__ __forceinline__ f32x4 load_f32x4(global_bytes base, unsigned lane_off) {
     return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(base + lane_off);
@@ -61,6 +75,23 @@ __device__ __forceinline__ f32x4 load_f32x4(global_bytes base, unsigned lane_off
 // the same for data read once (does not displace what the caches hold)
 __device__ __forceinline__ f32x4 load_stream_f32x4(global_bytes base, unsigned lane_off) {
     return __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(base + lane_off));
+}
+// stores through a wave-uniform base + 32-bit lane offset (`global_store v_off, v[data], s[base]`)
+typedef __attribute__((address_space(1))) char* global_bytes_rw;
+__device__ __forceinline__ global_bytes_rw uniform_global_rw(void* p) {
+    return const_cast<global_bytes_rw>(uniform_global(p));
+}
+template <typename V>
+__device__ __forceinline__ void store_at(global_bytes_rw base, unsigned lane_off, V v) {
+    *reinterpret_cast<__attribute__((address_space(1))) V*>(base + lane_off) = v;
+}
+template <typename V>
+__device__ __forceinline__ void store_stream_at(global_bytes_rw base, unsigned lane_off, V v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<__attribute__((address_space(1))) V*>(base + lane_off));
+}
+template <typename V>
+__device__ __forceinline__ V load_at(global_bytes base, unsigned lane_off) {
+    return *reinterpret_cast<const __attribute__((address_space(1))) V*>(base + lane_off);
 }
 // 16-byte global load that does not displace what the caches hold (streamed-once operands)
 __device__ __forceinline__ f32x4 load_stream(const f32x4* p) { return __builtin_nontemporal_load(p); }

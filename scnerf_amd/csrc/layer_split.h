@@ -19,38 +19,43 @@
 //     this for the same samples (the second one hits in L1).
 // A slab of 16 k = 4 sample tiles x 6 products x 4 feature tiles = 96 MFMAs; the fillers (the cut of the NEXT
 // sample tile's fragment, the loads two slabs ahead, the weight copy one slab ahead, the weight fragment reads
-// as their registers fall free) sit between the MFMAs, at most 4 per slot; one barrier per slab.
+// as their registers fall free) sit between the MFMAs, one memory instruction every 6 slots; one barrier per slab.
 //
-// Measured (tools/ubench/layer_split_lab.hip, P = 786 432): 0.56-0.58 ms per layer against 0.80 ms for a layer inside
-// the fused fp32-MFMA kernel; MFMAs + weight stream alone 0.30-0.32 ms, + activation loads and cuts 0.44, + epilogue
-// 0.57.  Like wgrad256_split.h the kernel is POWER-bound (shader clock ~1.7 GHz), so what counts is the number of
-// instructions, not where they sit: spreading the epilogue's 1400 instructions per block over the 144 MFMA slots
-// around the block seam instead of issuing them as a burst changed nothing (0.573 vs 0.558 ms); staggering the
-// workgroups' block boundaries neither.  What did matter: a bias read from global memory inside the epilogue
-// waits on vmcnt, which also counts the stores just issued -- one store round trip per 16-byte piece, 20 us per
-// block (the table is read from LDS instead); accumulator reads hoisted out of their pieces spill, and a scratch
-// reload waits on vmcnt just the same.
-// Open (profiles/r02d_layer_lab_pmc.txt): the matrix pipe is busy 46-50 % of the cycles at 2.04 GHz, 36 % of the wave
-// cycles sit in s_waitcnt, so this kernel -- unlike wgrad256_split -- is stall-bound, not power-bound.  Ablations
-// (lab, one box): MFMAs + weight stream 0.32 ms; + activation LOADS 0.45 (the cut's VALU on top: +0.005, i.e. hidden);
-// + epilogue 0.54.  Kept from the hunt: wave-uniform load bases made opaque to the compiler (uniform_global) -- with
-// 64-bit per-lane pointers every load carried ~20 VALU of address arithmetic and the compiler recycled landed
-// staging registers for the temporaries behind an `s_waitcnt vmcnt(0)` once per two slabs (0.575 -> 0.54 ms); the
-// weight loads issued BEFORE the slab's activation loads and waited for three iterations later (vmcnt counts in
-// order: a weight wait covers every older activation load; neutral by itself).  Tried, no effect: two independent
-// dependency chains per cut step; non-temporal activation loads; buffer-descriptor loads (they bloat the code to
-// 11 k lines through loop unswitching and slow the weight stream).  What the activation loads cost is not yet
-// explained (they are issued two slabs = 4 us ahead and the waits are counted, vmcnt(19)); with them the L1 reports
-// pending-miss stalls 68 % of the cycles (TCP_PENDING_STALL, 6 % without), but halving the L1 requests -- four waves
-// side by side along the samples, each owning all 256 features of 64 samples, so that no two waves load the same
-// activations -- moved the cost into the epilogue (32 dependent pieces per tile) and the total not at all (0.547 ms).
-// Per CU and slab 56 KB go through the L1's 64 B/clk address unit (896 of ~4000 cycles), four lock-stepped waves at
-// a time; giving every wave load slots of its own (uniform `if (wave == k)` around each load) made it WORSE
-// (0.77 ms): behind every such branch the compiler's wait-count pass falls back to `s_waitcnt vmcnt(0)` (156 of them).
-// Two rows of the epilogue interleaved with prefetched bias pieces: no change (the epilogue's cost is its 64 stores
-// per wave, 0.056 ms, and 0.035 ms of arithmetic).  Run on half of the CUs each workgroup is 25 % faster (MFMAs
-// + weight stream alone: 21 %): the full chip is also clock-limited (2.04 GHz sustained).  Without any barrier in the
-// slab loop (racy, timing only): 0.551 vs 0.555 ms -- neither the barrier nor the lock-step of the waves costs.
+// Measured (tools/ubench/layer_split_lab.hip, profiles/r02f_layer_split_lab.txt; P = 786 432): 0.51 ms per layer as a
+// launch of its own, 0.48-0.49 in a chain of eight (0.80 ms for a layer inside the fused fp32-MFMA kernel).
+// What bounds it.  The lab reads the shader clock inside the kernel (s_memtime against the 100 MHz s_memrealtime):
+//     MFMAs + weight stream, activation planes never written   615 k cycles per workgroup at 2.03-2.09 GHz  0.30-0.32 ms
+//     the same with pseudo-random bits in the planes           627 k cycles             at 1.68-1.70 GHz  0.38-0.39 ms
+//     + activation loads and cuts (no epilogue)                720 k cycles             at 1.69-1.72 GHz  0.44 ms
+//     whole kernel                                             842 k cycles             at 1.71-1.81 GHz  0.51 ms
+// against 589 824 cycles of MFMA work per workgroup: the matrix pipe is busy 70 % of the cycles (82 % between the
+// epilogues), and the chip runs this kernel at 1.7 GHz -- it is POWER-bound like wgrad256_split.h, and what the
+// matrix pipe draws depends on the operand bits (static registers: 2.05 GHz).  Two earlier readings of this kernel
+// were wrong: "busy 46-55 % at 2.04 GHz, stall-bound" came from GRBM_GUI_ACTIVE / duration, which is not the shader
+// clock (it reads 10 GHz on a 3 us copy kernel); and "the activation loads cost 0.12 ms, unexplained" compared runs
+// with and without real operand bits -- half of that difference is the clock, not a stall.  Ruled out on the way
+// (lab flags below, none changed the time): HBM locality (chains in groups of 2 blocks read what they wrote 40 us ago:
+// same time), two waves loading the same lines (kNoDupX), all workgroups walking K in step (kRotate), the memory
+// system altogether (kXfromW: the loads fetch L2-resident weight pieces instead, 0.425 vs 0.447 ms).
+// What did cost cycles, found in the ISA and fixed in round 2:
+//   * a bias read from global memory inside the epilogue waits on vmcnt, which also counts the stores just issued --
+//     one store round trip per 16-byte piece, 20 us per block (table in LDS);
+//   * then the LDS read itself: issued right where it was used, each of the 64 pieces per wave and block waited out an
+//     LDS round trip (176 k -> 122 k cycles per workgroup with the read one piece ahead and shared by the four sample
+//     tiles);
+//   * 64-bit per-lane pointers: ~20 VALU of address arithmetic per load, lane-invariant parts hoisted out of the block
+//     loop into registers that spill, scratch reloads waiting on vmcnt(0) in the middle of the stores (wave-uniform
+//     bases made opaque with an empty asm + 32-bit lane offsets, pinned_here for what must not be hoisted);
+//   * ~50 scalar instructions per load (64-bit tile arithmetic, the layer's pointers re-fetched from the argument
+//     block behind s_waitcnt lgkmcnt(0)): scalar instructions issue from the same in-order stream as the MFMAs
+//     (addresses once per slab, ahead_of);
+//   * memory instructions issued back to back (six weight pieces in six slots, two activation pieces in one) by four
+//     lock-stepped waves: 0.344 -> 0.317 ms for MFMAs + weight stream with one every 6 slots;
+//   * accumulator reads hoisted out of their pieces spill; `if (wave == k)` around a load makes the wait-count pass
+//     fall back to vmcnt(0) behind the branch (0.77 ms); buffer-descriptor loads bloat the code through unswitching.
+// Tried, no effect (consistent with a power bound -- the instructions cost the same wherever they sit): spreading the
+// epilogue over the MFMA slots around the block seam, staggering the workgroups, non-temporal loads, no barriers
+// (racy), four waves side by side along the samples.  Run on half of the CUs each workgroup is 21-25 % faster.
 #pragma once
 #include <type_traits>
 
@@ -65,32 +70,56 @@ constexpr int kSlabUnits = 3 * 8 * 64;              // 16-byte fragments of one 
 constexpr int kSlabShorts = kSlabUnits * 8;
 constexpr unsigned kLdsBytes = 2u * kSlabUnits * 16u + 1024u;  // two slab images + the bias table
 
-struct Args {
+struct Layer {
     const float* X;        // tile-native, width 256: K slabs 0 .. 15
-    const float* X2;       // row-major [Ppad][x2_ld] (the skip layer's encoded points): K slabs 16 .. n_k - 1, or nullptr
-    int x2_ld;
+    const float* X2;       // row-major [Ppad][x2_ld] (the skip layer's encoded points): K slabs 16 .. n_k - 1 (else = X)
     int n_k;               // K slabs per block: 16, or 16 + x2 width / 16 (even)
+    int relu;
     const short* W;        // [n_k][3][8][64][8] bf16 bits (pack_planes)
     const float* bias;     // lane-vector table of 8 tiles: entry ((4 t + q) * 2 + h) * 4 + j
     float* Z;              // tile-native, width 256
-    unsigned* mask;        // ReLU bits [wave tile][64 lanes][4 words] or nullptr
+    unsigned* mask;        // ReLU bits [wave tile][64 lanes][4 words] or nullptr (mode 0)
+    const unsigned* mask_in;   // mode 1: the gate, [wave tile][64 lanes][4 words]
+    const float* vec;          // mode 1: per-sample scalar of the rank-1 term, element p * vec_stride (p < n_vec), or nullptr
+};
+// A chain of layers in ONE launch: layer l + 1 of a 256-sample block reads what layer l wrote for the SAME block, and
+// a workgroup keeps its blocks from layer to layer, so there is no dependency between workgroups -- the software
+// pipeline simply runs on across the layer boundary.  A workgroup takes a GROUP of its blocks (>= 2) through all the
+// layers before it turns to the next group: the loads two slabs ahead then fetch the group's first block in the next
+// layer, stored a whole block (~40 us) earlier.  Groups of 2 keep what a layer reads within 128 MB of what the chip
+// wrote last (with default-policy stores: 2-3 % faster than layer by layer over all blocks, lab; the kernel is not
+// bound by where its activations come from).  The launcher only chains when every workgroup owns at least two
+// blocks.  Saves the launch gaps and pipeline refills of eight launches per pass: 0.51 -> 0.48-0.49 ms per layer.
+constexpr int kMaxLayers = 8;
+struct Args {
+    Layer layer[kMaxLayers];
+    int n_layers;
+    int group;             // blocks a workgroup takes through ALL layers before it turns to its next blocks (>= 2;
+                           // >= its block count: layer by layer over all of them)
+    int x2_ld;
     long Ppad;             // samples covered (multiple of 128)
-    int relu;
-    // mode 1 (data gradients): Z = select(mask_in, W X + bias[n] * vec[p]) -- the ReLU gate of the layer below and
-    // the rank-1 density-head term (bias = alpha_linear's weights, vec = d sigma); no bias add, no bits written
+    // mode 0: Z = act(W X + b), ReLU bits written; mode 1 (data gradients): Z = select(mask_in, W X + bias[n] * vec[p])
+    // -- the ReLU gate of the layer below and the rank-1 density-head term (bias = alpha_linear's weights, vec = d sigma)
     int mode;
-    const unsigned* mask_in;   // [wave tile][64 lanes][4 words]
-    const float* vec;          // per-sample scalar, element p * vec_stride (p < n_vec), or nullptr
     int vec_stride;
     long n_vec;
+    unsigned long long* clock_probe;   // lab only (kClockProbe): [workgroup][2]
 };
 
 enum : int {
     kNoEpilogue = 1,      // timing experiment: only the last block is stored
     kNoCut = 2,           // timing experiment: no loads / cuts of X (planes hold garbage)
     kNoCutMath = 8,       // timing experiment: X is loaded but not cut (the raw words serve as planes)
+    kSameX = 32,          // timing experiment: every activation load fetches the tiles of block 0 (always an L2 hit)
+    kNoWCopy = 128,       // timing experiment: the weight slabs are not copied (LDS holds the first two)
+    kRotate = 512,        // timing experiment: every block starts its K loop at another slab (X only: wrong results)
+    kXfromW = 1024,       // timing experiment: the activation loads fetch pieces of the weight slab instead (wrong results)
+    kRandomX = 2048,      // timing experiment (with kNoCut): the activation planes hold pseudo-random bits instead of garbage
+    kClockProbe = 4096,   // lab: every workgroup writes its shader-cycle and reference-tick counts to Args::clock_probe
+    kNoDupX = 256,        // timing experiment: the two waves that share samples load DIFFERENT tiles (wrong results)
     kNoBarrier = 64,      // timing experiment: no workgroup barriers in the slab loop (racy: results are wrong)
-    kPlainStore = 4,      // experiment: default-policy stores instead of non-temporal ones (no difference)
+    kPlainStore = 4,      // default-policy stores instead of non-temporal ones: what a chain in groups of 2 blocks uses
+                          // (the next layer re-reads the block 40 us later: 2-3 % faster); alone no difference
     kNoZStore = 16,       // experiment: the epilogue computes but stores only the mask words
 };
 
@@ -107,7 +136,7 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
     const long n_blocks = (n_tiles + 7) / 8;
     if ((long)blockIdx.x >= n_blocks) return;
     const int my_blocks = (int)((n_blocks - blockIdx.x + gridDim.x - 1) / gridDim.x);
-    const int n_k = a.n_k;
+    const int n_layers = a.n_layers;
 
     f32x16 acc[4][4];       // written by MFMAs only: a block's first product starts from the constant 0
 
@@ -118,26 +147,57 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
     const int wp_u = uniform(wp);
     const unsigned xoff_a = (unsigned)((g * 64 + m) * 16);                                   // main operand, piece h' = 0
     const unsigned xoff_b = (unsigned)((m * a.x2_ld + 8 * g) * 4);                           // second operand
-    auto tile_of = [&](int b, int j) {             // sample tile j of this workgroup's b-th block, clamped into the tensor
+    // The addresses of a slab's loads are wave-uniform and computed ONCE per slab (ahead_of): scalar instructions issue
+    // from the same in-order stream as the MFMAs, and ~50 of them per load -- 64-bit tile arithmetic, the layer's
+    // pointers fetched from the argument block behind an `s_waitcnt lgkmcnt(0)` -- was what the activation loads cost
+    // (0.05-0.08 ms per layer even when every load hit in L1).  A load now adds j * stride to the slab's base.
+    struct LayerPtrs { global_bytes X, X2, W; };
+    auto layer_ptrs = [&](int l) {
+        const Layer& L = a.layer[l];
+        return LayerPtrs{uniform_global(L.X), uniform_global(L.X2), uniform_global(L.W)};
+    };
+    struct Ahead {
+        global_bytes x;       // piece h' = 0 of sample tile 0 of the wave
+        unsigned x_stride;    // bytes from sample tile to sample tile
+        unsigned off[2];      // per-lane byte offsets of the two pieces
+        global_bytes w;       // the slab's weight image
+    };
+    // (b, s): block and K slab; s >= 16: the row-major second operand, k = 16 (s - 16) + 8 g + 4 h' .. +3.
+    // The four sample tiles of a wave are consecutive and Ppad is a multiple of 128, so they are clamped as one.
+    auto ahead_of = [&](const LayerPtrs& P, int b, int s) {
         const long blk = blockIdx.x + (long)(b < my_blocks ? b : my_blocks - 1) * gridDim.x;
-        const long t = blk * 8 + wp_u * 4 + j;
-        return t < n_tiles ? t : n_tiles - 1;
+        long t0 = blk * 8 + wp_u * 4;
+        if constexpr (FLAGS & kNoDupX) t0 += uniform(wn) * 8 * (long)gridDim.x;
+        if (t0 >= n_tiles) t0 = n_tiles - 4;
+        if constexpr (FLAGS & kSameX) t0 = 0;
+        // (selects, not branches: control flow here would cut the MFMA stream into scheduling regions)
+        const bool main_part = s < 16;
+        int sx = s;
+        if constexpr (FLAGS & kRotate) sx = (s + (int)blk * 5) & 15;
+        const global_bytes p1 = P.X + t0 * 32768 + sx * 2048;
+        const global_bytes p2 = P.X2 + t0 * 128 * a.x2_ld + (s - 16) * 64;
+        Ahead A;
+        A.x = uniform_global(main_part ? p1 : p2);
+        A.x_stride = main_part ? 32768u : 128u * (unsigned)a.x2_ld;
+        // (pinned: for the two peeled slabs of a block the select is block-invariant -- hoisted, it spills)
+        const unsigned xa = pinned_here(xoff_a), xb = pinned_here(xoff_b);
+        A.off[0] = main_part ? xa : xb;
+        A.off[1] = A.off[0] + (main_part ? 512u : 16u);
+        A.w = uniform_global(P.W + (long)s * (kSlabShorts * 2));
+        if constexpr (FLAGS & kXfromW) {
+            A.x = A.w + wp_u * 8192;
+            A.x_stride = 2048u;
+            A.off[0] = (unsigned)lane * 16u;
+            A.off[1] = A.off[0] + 1024u;
+        }
+        return A;
     };
     f32x4 raw[2][4][2];                             // [set = slab parity][sample tile][h']
-    // (b, s): block and K slab; s >= 16: the row-major second operand, k = 16 (s - 16) + 8 g + 4 h' .. +3
-    auto load_x = [&](auto set_tag, int b, int s, auto j_tag) {
-        constexpr int SET = decltype(set_tag)::value, j = decltype(j_tag)::value;
+    auto load_x = [&](auto set_tag, const Ahead& A, auto j_tag, auto half_tag) {
+        constexpr int SET = decltype(set_tag)::value, j = decltype(j_tag)::value, HALF = decltype(half_tag)::value;
         if constexpr (!(FLAGS & kNoCut)) {
-            const long t = tile_of(b, j);
-            // (selects, not a branch: control flow here would cut the MFMA stream into scheduling regions)
-            const bool main_part = s < 16;
-            const float* p1 = a.X + t * 8192 + s * 512;
-            const float* p2 = a.X2 + t * 32 * a.x2_ld + (s - 16) * 16;
-            const global_bytes base = uniform_global(main_part ? p1 : p2);
-            const unsigned off0 = main_part ? xoff_a : xoff_b;
-            const unsigned off1 = off0 + (main_part ? 512u : 16u);
-            raw[SET][j][0] = load_f32x4(base, off0);      // (non-temporal loads: no difference; the two waves that
-            raw[SET][j][1] = load_f32x4(base, off1);      // share a sample tile meet in L1 either way)
+            // (non-temporal loads: no difference; the two waves that share a sample tile meet in L1 either way)
+            raw[SET][j][HALF] = load_f32x4(uniform_global(A.x + j * A.x_stride), A.off[HALF]);
         }
     };
     // planes of the fragment being used / being cut: [ping-pong][plane]
@@ -178,9 +238,9 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
     // ---- W: slab image copy (6 x 16 bytes per thread) and fragment reads
     f32x4 wst[6];
     const unsigned woff = (unsigned)tid * 16u;
-    auto load_w = [&](int s, auto x_tag) {
+    auto load_w = [&](const Ahead& A, auto x_tag) {
         constexpr int x = decltype(x_tag)::value;
-        wst[x] = load_f32x4(uniform_global(a.W + (long)s * kSlabShorts) + x * (kThreads * 16), woff);
+        wst[x] = load_f32x4(A.w + x * (kThreads * 16), woff);
     };
     auto write_w = [&](int buf, auto x_tag) {
         constexpr int x = decltype(x_tag)::value;
@@ -219,35 +279,50 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
 
     // slab u out of LDS buffer BUF (= u & 1 = raw set): per sample tile j
     //   slots 0-10   cut the next fragment ((u, j + 1), or (u + 1, 0) out of the other raw set)
-    //   slot 11 (j = 0: slot 23)   reload raw fragment j for the slab two ahead (load_x: both pieces)
-    //   j = 0: slots 13-16 read Wl(u);   slots 17-22 load W(u + 2) into the staging registers
-    //   j = 2: barrier at the end (every wave is done with W(u): its buffer is free; W(u + 1), written during slab
-    //          u - 1, is visible)
-    //   j = 3: slots 0-5 write W(u + 2) into buffer BUF;   slots 12-15 read Wh(u + 1);   slots 20-23 read Wm(u + 1)
-    // vmcnt counts loads IN ORDER: waiting for a weight piece also waits for every activation load issued before it.
-    // The weight loads therefore go out BEFORE slab u's activation loads and are waited for three iterations later,
-    // when the youngest activation load ahead of them is a whole slab old (with the weight loads in iterations 2-3
-    // and their writes right after, every slab waited twice for activation loads two iterations old).
-    auto slab = [&](auto buf_tag, auto first_tag, int b, int s) {
+    //   slots 6, 18  reload the two pieces of raw fragment j for the slab two ahead
+    //   slots 0, 12  j = 0, 1, 2: write piece 2 j, 2 j + 1 of W(u + 1) (loaded during slab u - 1) into buffer BUF ^ 1;
+    //                j = 1, 2, 3: load piece 2 (j - 1), 2 (j - 1) + 1 of W(u + 2) into the staging register just written
+    //   j = 0: slots 2, 6, 10, 14 read Wl(u);   j = 3: slots 12, 14, 16, 18 read Wh(u + 1), slots 20-23 Wm(u + 1)
+    //   j = 2: barrier at the end (every wave is done with W(u): its buffer is free for slab u + 1's writes; W(u + 1),
+    //          written during this slab, is visible)
+    // One memory instruction per wave every 6 slots: the four waves issue theirs in lock-step, 4 KB per slot position
+    // = 64 clocks of the CU's 64 B/clk address unit = two MFMA slots; issued back to back (six weight pieces in six
+    // slots, two activation pieces in one) the address unit's queue filled and the waves stalled in front of their
+    // next MFMA -- the unit's busy time was exposed nearly one to one (lab: weights +0.054 ms, activations even when
+    // they always hit in L1 +0.047 ms per layer on top of 0.290 for the MFMAs alone).
+    // vmcnt counts loads IN ORDER: waiting for a weight piece also waits for every activation load issued before it;
+    // a piece is written 72 slots (~1.1 us) after its load.
+    auto slab = [&](auto buf_tag, auto first_tag, const LayerPtrs& cur, const LayerPtrs& nxt, bool last_layer, int n_k,
+                    int b0, int b1, int b, int s) {
         constexpr int BUF = decltype(buf_tag)::value;
         using Set = I<BUF>;
         using Other = I<BUF ^ 1>;
-        const bool wraps = s + 2 >= n_k;               // two slabs ahead: the next block's slab 0 / 1
-        const int b2 = wraps ? b + 1 : b, s2 = wraps ? s + 2 - n_k : s + 2;
+        // two slabs ahead: this block, or slab 0 / 1 of the group's next block, or of its first block in the next
+        // layer (nxt), or of the next group's first block in layer 0 (nxt again; past the end: clamped, never used)
+        const bool wraps = s + 2 >= n_k;
+        const bool last_of_group = b + 1 >= b1;
+        const bool to_next = wraps && last_of_group;
+        const int b2 = !wraps ? b : !last_of_group ? b + 1 : last_layer ? b1 : b0;
+        const int s2 = wraps ? s + 2 - n_k : s + 2;
+        const LayerPtrs P{to_next ? nxt.X : cur.X, to_next ? nxt.X2 : cur.X2, to_next ? nxt.W : cur.W};
+        const Ahead A = ahead_of(P, b2, s2);
         auto fill = [&](auto j_tag) {
             return [&](auto slot_tag) {
                 constexpr int j = decltype(j_tag)::value, S = decltype(slot_tag)::value;
-                if constexpr (j == 3 && S <= 5) write_w(BUF, I<S>{});
                 if constexpr (S <= 10) {
                     if constexpr (j < 3) cut_step(Set{}, I<j + 1>{}, I<(j + 1) & 1>{}, I<S>{});
                     else cut_step(Other{}, I<0>{}, I<0>{}, I<S>{});
                 }
-                if constexpr (S == (j == 0 ? 23 : 11)) load_x(Set{}, b2, s2, I<j>{});
+                if constexpr (S == 6) load_x(Set{}, A, I<j>{}, I<0>{});
+                if constexpr (S == 18) load_x(Set{}, A, I<j>{}, I<1>{});
+                if constexpr ((S == 0 || S == 12) && !(FLAGS & kNoWCopy)) {
+                    if constexpr (j <= 2) write_w(BUF ^ 1, I<2 * j + (S == 12)>{});
+                    if constexpr (j >= 1) load_w(A, I<2 * (j - 1) + (S == 12)>{});
+                }
                 if constexpr (j == 0) {
-                    if constexpr (S >= 13 && S <= 16) read_w(BUF, I<2>{}, I<S - 13>{});
-                    if constexpr (S >= 17 && S <= 22) load_w(s2, I<S - 17>{});
+                    if constexpr (S == 2 || S == 6 || S == 10 || S == 14) read_w(BUF, I<2>{}, I<(S - 2) / 4>{});
                 } else if constexpr (j == 3) {
-                    if constexpr (S >= 12 && S <= 15) read_w(BUF ^ 1, I<0>{}, I<S - 12>{});
+                    if constexpr (S == 12 || S == 14 || S == 16 || S == 18) read_w(BUF ^ 1, I<0>{}, I<(S - 12) / 2>{});
                     if constexpr (S >= 20) read_w(BUF ^ 1, I<1>{}, I<S - 20>{});
                 }
             };
@@ -259,102 +334,133 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
         iteration(I<3>{}, I<1>{}, first_tag, fill(I<3>{}));
     };
 
-    // finished block: bias, activation, ReLU bits, tile-native stores
-    auto epilogue = [&](int b) {
-        {
-            const long blk = blockIdx.x + (long)b * gridDim.x;
-            const float lo = a.relu ? 0.f : -__builtin_huge_valf();
-            const long tile0 = blk * 8 + uniform(wp) * 4;              // wave-uniform: the range checks are scalar branches
-            auto tile = [&](auto j_tag) {
-                constexpr int j = decltype(j_tag)::value;
-                const long t = tile0 + j;
-                if (t >= n_tiles) return;
-                float* zt = a.Z + t * 8192 + wn * 4096 + lane * 4;      // + (4 i + q) * 256
-                unsigned bits[2] = {0u, 0u};
+    // finished block: bias, activation, ReLU bits, tile-native stores.  Piece (i, q) -- 16 bytes per lane, features
+    // 32 (4 wn + i) + 8 q + 4 g .. +3 -- of all FOUR sample tiles at a time: its bias piece is read from the LDS table
+    // once (and one piece ahead: read right where it is used, every piece waited out an LDS round trip -- 64 of them
+    // per block and wave were nearly half of the epilogue's 14.7 k cycles).  From LDS, not from memory: a global load
+    // here waits on vmcnt, which counts the stores just issued too.  The stores go through a wave-uniform base + a
+    // 32-bit lane offset recomputed here: as 64-bit per-lane pointers their lane-invariant parts were hoisted out of
+    // the block loop and spilled, and a scratch reload between the stores waits for all of them.  The fence keeps the
+    // accumulator reads piece by piece: hoisted, they spill.
+    auto epilogue = [&](int l, int b) {
+        const Layer& L = a.layer[l];
+        const long blk = blockIdx.x + (long)b * gridDim.x;
+        const long tile0 = blk * 8 + wp_u * 4;      // Ppad is a multiple of 128: a wave's four tiles are in range together
+        if (tile0 >= n_tiles) return;               // (wave-uniform: a scalar branch)
+        const int wn_u = uniform(wn);
+        const global_bytes_rw z0 = uniform_global_rw(L.Z + tile0 * 8192 + wn_u * 4096);     // + j * 32 KB + (4 i + q) * 1 KB
+        const unsigned lane_here = pinned_here((unsigned)lane);       // (lane-invariant values derived outside get hoisted
+        const unsigned zoff = lane_here * 16u;                        //  out of the block loop into registers that spill)
+        const float* const table = lds_bias + (16 * wn_u) * 8 + (lane_here >> 5) * 4;       // + (4 i + q) * 8
+        auto pieces = [&](auto f) {
+            f(I<0>{}); f(I<1>{}); f(I<2>{}); f(I<3>{}); f(I<4>{}); f(I<5>{}); f(I<6>{}); f(I<7>{});
+            f(I<8>{}); f(I<9>{}); f(I<10>{}); f(I<11>{}); f(I<12>{}); f(I<13>{}); f(I<14>{}); f(I<15>{});
+        };
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        if (a.mode == 0) {
+            const float lo = L.relu ? 0.f : -__builtin_huge_valf();
+            auto tile_pair = [&](auto j0_tag) {
+            constexpr int J0 = decltype(j0_tag)::value;
+            unsigned hb[4] = {0u, 0u, 0u, 0u}, bits[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+            f32x4 b_next = *reinterpret_cast<const f32x4*>(table);
+            pieces([&](auto idx_tag) {
+                constexpr int IDX = decltype(idx_tag)::value, i = IDX >> 2, q = IDX & 3;
+                sched_fence();
+                const f32x4 bc = b_next;
+                if constexpr (IDX < 15) b_next = *reinterpret_cast<const f32x4*>(table + (IDX + 1) * 8);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    unsigned hb = 0u;
+                for (int j = J0; j < J0 + 2; ++j) {
+                    f32x4 v;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        // (the bias piece is re-read for every tile: kept in registers across the four sample tiles
-                        // it costs 64 VGPRs the slab loop does not have.  From LDS, not from memory: a global load
-                        // here waits on vmcnt, which counts the stores of the previous piece too -- one store round
-                        // trip per piece, 20 us per block.  The fence keeps the accumulator reads piece by piece:
-                        // hoisted, they spill, and a scratch reload waits on vmcnt just the same.)
-                        sched_fence();
-                        const f32x4 b = *reinterpret_cast<const f32x4*>(lds_bias + ((4 * (4 * wn + i) + q) * 2 + g) * 4);
-                        f32x4 v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = max_raw(add_raw(acc[i][j][4 * q + e], b[e]), lo);
-                            hb = shift_in_positive(hb, v[e]);
-                        }
-                        f32x4* dst = reinterpret_cast<f32x4*>(zt + (4 * i + q) * 256);
-                        if constexpr (FLAGS & kNoZStore) { (void)dst; }
-                        else if constexpr (FLAGS & kPlainStore) *dst = v;
-                        else __builtin_nontemporal_store(v, dst);
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = max_raw(add_raw(acc[i][j][4 * q + e], bc[e]), lo);
+                        hb[j] = shift_in_positive(hb[j], v[e]);
                     }
-                    bits[i >> 1] = (bits[i >> 1] << 16) | hb;
+                    const unsigned dst = zoff + (unsigned)IDX * 1024u;
+                    if constexpr (FLAGS & kNoZStore) { (void)dst; }
+                    else if constexpr (FLAGS & kPlainStore) store_at(z0 + j * 32768, dst, v);
+                    else store_stream_at(z0 + j * 32768, dst, v);
                 }
-                if (a.mask) {
-                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                    *reinterpret_cast<u32x2*>(a.mask + t * 256 + lane * 4 + 2 * wn) = u32x2{bits[0], bits[1]};
+                if constexpr (q == 3) {
+#pragma unroll
+                    for (int j = J0; j < J0 + 2; ++j) {
+                        bits[j][i >> 1] = (bits[j][i >> 1] << 16) | hb[j];
+                        hb[j] = 0u;
+                    }
                 }
-            };
-            // data-gradient form: gate by the ReLU bits of the layer below (element 16 t + r of a lane: word t >> 1,
-            // bit 31 - (16 (t & 1) + r)), after adding the density head's rank-1 term
-            auto tile_bwd = [&](auto j_tag) {
-                constexpr int j = decltype(j_tag)::value;
-                const long t = tile0 + j;
-                if (t >= n_tiles) return;
-                float* zt = a.Z + t * 8192 + wn * 4096 + lane * 4;
-                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                const u32x2 gate = *reinterpret_cast<const u32x2*>(a.mask_in + t * 256 + lane * 4 + 2 * wn);
-                const long p = t * 32 + m;
-                const float vs = (a.vec && p < a.n_vec) ? a.vec[p * a.vec_stride] : 0.f;
-                // RANK1: the density head's term (feature_linear^T only); the other seven layers skip the FMA and
-                // the LDS read of the table
-                auto tile_rows = [&](auto rank1_tag) {
-                    constexpr bool RANK1 = decltype(rank1_tag)::value;
-                    auto row = [&](auto i_tag) {
-                        constexpr int i = decltype(i_tag)::value;
-                        auto piece = [&](auto q_tag) {
-                            constexpr int q = decltype(q_tag)::value;
-                            sched_fence();
-                            f32x4 b = {0.f, 0.f, 0.f, 0.f};
-                            if constexpr (RANK1) b = *reinterpret_cast<const f32x4*>(lds_bias + ((4 * (4 * wn + i) + q) * 2 + g) * 4);
-                            constexpr int bit0 = 31 - (16 * (i & 1) + 4 * q);
-                            const unsigned word = gate[i >> 1];
-                            auto val = [&](int e) { return RANK1 ? fmaf(b[e], vs, acc[i][j][4 * q + e]) : acc[i][j][4 * q + e]; };
-                            f32x4 v;
-                            v[0] = keep_if_bit<bit0 - 0>(val(0), word);
-                            v[1] = keep_if_bit<bit0 - 1>(val(1), word);
-                            v[2] = keep_if_bit<bit0 - 2>(val(2), word);
-                            v[3] = keep_if_bit<bit0 - 3>(val(3), word);
-                            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(zt + (4 * i + q) * 256));
-                        };
-                        piece(I<0>{}); piece(I<1>{}); piece(I<2>{}); piece(I<3>{});
-                    };
-                    row(I<0>{}); row(I<1>{}); row(I<2>{}); row(I<3>{});
-                };
-                if (a.vec) tile_rows(std::true_type{}); else tile_rows(std::false_type{});
-            };
-            if (a.mode == 1) {
-                tile_bwd(I<0>{}); tile_bwd(I<1>{}); tile_bwd(I<2>{}); tile_bwd(I<3>{});
-                return;
+            });
+            if (L.mask) {
+#pragma unroll
+                for (int j = J0; j < J0 + 2; ++j)
+                    store_at(uniform_global_rw(L.mask + (tile0 + j) * 256 + 2 * wn_u), zoff, u32x2{bits[j][0], bits[j][1]});
             }
-            tile(I<0>{}); tile(I<1>{}); tile(I<2>{}); tile(I<3>{});
+            };
+            tile_pair(I<0>{});       // (two tiles at a time: all four hold 16 accumulator values + their results per
+            tile_pair(I<2>{});       //  piece next to the loop's prefetched operands -- the allocator spills 32 registers)
+            return;
         }
+        // data-gradient form: gate by the ReLU bits of the layer below (element 16 t + r of a lane: word t >> 1, bit
+        // 31 - (16 (t & 1) + r)), after adding the density head's rank-1 term.  The gates and the per-sample scalars of
+        // the four tiles are fetched up front (one wait, before this block's first store).
+        auto tile_pair_bwd = [&](auto j0_tag) {
+        constexpr int J0 = decltype(j0_tag)::value;
+        u32x2 gate[4];
+        float vs[4];
+#pragma unroll
+        for (int j = J0; j < J0 + 2; ++j) {
+            gate[j] = load_at<u32x2>(uniform_global(L.mask_in + (tile0 + j) * 256 + 2 * wn_u), zoff);
+            const unsigned p_in = (unsigned)j * 32u + (lane_here & 31u);          // sample within the wave's four tiles
+            vs[j] = (L.vec && tile0 * 32 + p_in < a.n_vec)
+                        ? load_at<float>(uniform_global(L.vec + tile0 * 32 * a.vec_stride), p_in * (unsigned)a.vec_stride * 4u)
+                        : 0.f;
+        }
+        // RANK1: the density head's term (feature_linear^T only); the other seven layers skip the FMA and the table
+        auto all_pieces = [&](auto rank1_tag) {
+            constexpr bool RANK1 = decltype(rank1_tag)::value;
+            f32x4 b_next = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (RANK1) b_next = *reinterpret_cast<const f32x4*>(table);
+            pieces([&](auto idx_tag) {
+                constexpr int IDX = decltype(idx_tag)::value, i = IDX >> 2, q = IDX & 3;
+                sched_fence();
+                const f32x4 bc = b_next;
+                if constexpr (RANK1 && IDX < 15) b_next = *reinterpret_cast<const f32x4*>(table + (IDX + 1) * 8);
+                constexpr int bit0 = 31 - (16 * (i & 1) + 4 * q);
+#pragma unroll
+                for (int j = J0; j < J0 + 2; ++j) {
+                    const unsigned word = gate[j][i >> 1];
+                    auto val = [&](int e) { return RANK1 ? fmaf(bc[e], vs[j], acc[i][j][4 * q + e]) : acc[i][j][4 * q + e]; };
+                    f32x4 v;
+                    v[0] = keep_if_bit<bit0 - 0>(val(0), word);
+                    v[1] = keep_if_bit<bit0 - 1>(val(1), word);
+                    v[2] = keep_if_bit<bit0 - 2>(val(2), word);
+                    v[3] = keep_if_bit<bit0 - 3>(val(3), word);
+                    if constexpr (FLAGS & kPlainStore) store_at(z0 + j * 32768, zoff + (unsigned)IDX * 1024u, v);
+                    else store_stream_at(z0 + j * 32768, zoff + (unsigned)IDX * 1024u, v);
+                }
+            });
+        };
+        if (L.vec) all_pieces(std::true_type{}); else all_pieces(std::false_type{});
+        };
+        tile_pair_bwd(I<0>{});
+        tile_pair_bwd(I<2>{});
     };
 
-    lds_bias[tid] = a.bias[tid];
+    unsigned long long probe_c = 0, probe_r = 0;
+    if constexpr (FLAGS & kClockProbe) { probe_c = shader_cycles(); probe_r = reference_ticks(); }
+    lds_bias[tid] = a.layer[0].bias[tid];
     // ---- prologue: W slabs 0 and 1 -> buffers 0 and 1; X raw of slabs 0 and 1; first fragment cut
-    load_w(0, I<0>{}); load_w(0, I<1>{}); load_w(0, I<2>{}); load_w(0, I<3>{}); load_w(0, I<4>{}); load_w(0, I<5>{});
-    load_x(I<0>{}, 0, 0, I<0>{}); load_x(I<0>{}, 0, 0, I<1>{}); load_x(I<0>{}, 0, 0, I<2>{}); load_x(I<0>{}, 0, 0, I<3>{});
-    load_x(I<1>{}, 0, 1, I<0>{}); load_x(I<1>{}, 0, 1, I<1>{}); load_x(I<1>{}, 0, 1, I<2>{}); load_x(I<1>{}, 0, 1, I<3>{});
-    write_w(0, I<0>{}); write_w(0, I<1>{}); write_w(0, I<2>{}); write_w(0, I<3>{}); write_w(0, I<4>{}); write_w(0, I<5>{});
-    load_w(1, I<0>{}); load_w(1, I<1>{}); load_w(1, I<2>{}); load_w(1, I<3>{}); load_w(1, I<4>{}); load_w(1, I<5>{});
-    write_w(1, I<0>{}); write_w(1, I<1>{}); write_w(1, I<2>{}); write_w(1, I<3>{}); write_w(1, I<4>{}); write_w(1, I<5>{});
+    {
+        const LayerPtrs P0 = layer_ptrs(0);
+        const Ahead A0 = ahead_of(P0, 0, 0), A1 = ahead_of(P0, 0, 1);
+        load_w(A0, I<0>{}); load_w(A0, I<1>{}); load_w(A0, I<2>{}); load_w(A0, I<3>{}); load_w(A0, I<4>{}); load_w(A0, I<5>{});
+        load_x(I<0>{}, A0, I<0>{}, I<0>{}); load_x(I<0>{}, A0, I<1>{}, I<0>{}); load_x(I<0>{}, A0, I<2>{}, I<0>{}); load_x(I<0>{}, A0, I<3>{}, I<0>{});
+        load_x(I<0>{}, A0, I<0>{}, I<1>{}); load_x(I<0>{}, A0, I<1>{}, I<1>{}); load_x(I<0>{}, A0, I<2>{}, I<1>{}); load_x(I<0>{}, A0, I<3>{}, I<1>{});
+        load_x(I<1>{}, A1, I<0>{}, I<0>{}); load_x(I<1>{}, A1, I<1>{}, I<0>{}); load_x(I<1>{}, A1, I<2>{}, I<0>{}); load_x(I<1>{}, A1, I<3>{}, I<0>{});
+        load_x(I<1>{}, A1, I<0>{}, I<1>{}); load_x(I<1>{}, A1, I<1>{}, I<1>{}); load_x(I<1>{}, A1, I<2>{}, I<1>{}); load_x(I<1>{}, A1, I<3>{}, I<1>{});
+        write_w(0, I<0>{}); write_w(0, I<1>{}); write_w(0, I<2>{}); write_w(0, I<3>{}); write_w(0, I<4>{}); write_w(0, I<5>{});
+        // (slab 1's image stays in the staging registers: slab 0 writes it, as every slab writes its successor's)
+        load_w(A1, I<0>{}); load_w(A1, I<1>{}); load_w(A1, I<2>{}); load_w(A1, I<3>{}); load_w(A1, I<4>{}); load_w(A1, I<5>{});
+    }
     sync();
     read_w(0, I<0>{}, I<0>{}); read_w(0, I<0>{}, I<1>{}); read_w(0, I<0>{}, I<2>{}); read_w(0, I<0>{}, I<3>{});
     read_w(0, I<1>{}, I<0>{}); read_w(0, I<1>{}, I<1>{}); read_w(0, I<1>{}, I<2>{}); read_w(0, I<1>{}, I<3>{});
@@ -364,16 +470,46 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
         whole(I<7>{}); whole(I<8>{}); whole(I<9>{}); whole(I<10>{});
     }
 
-    for (int b = 0; b < my_blocks; ++b) {
-        slab(I<0>{}, std::true_type{}, b, 0);
-        slab(I<1>{}, std::false_type{}, b, 1);
-        for (int s = 2; s < n_k; s += 2) {
-            slab(I<0>{}, std::false_type{}, b, s);
-            slab(I<1>{}, std::false_type{}, b, s + 1);
-        }
-        if constexpr (!(FLAGS & kNoEpilogue)) epilogue(b);
+    bool first_table = true;
+    if constexpr (FLAGS & kRandomX) {
+        unsigned h = (unsigned)tid * 2654435761u + 12345u;
+        for (int d = 0; d < 2; ++d)
+            for (int pl = 0; pl < 3; ++pl)
+                for (int e = 0; e < 8; ++e) {
+                    h = h * 1664525u + 1013904223u;
+                    xp[d][pl][e] = (short)((h >> 16) & 0xbfff);        // (exponent below 2: no overflow over the K loop)
+                }
     }
-    if constexpr (FLAGS & kNoEpilogue) epilogue(my_blocks - 1);       // (keeps the MFMAs alive)
+    for (int b0 = 0, b1; b0 < my_blocks; b0 = b1) {
+        b1 = b0 + a.group;
+        if (b1 + 2 > my_blocks) b1 = my_blocks;             // (a stray last block joins the last group)
+        for (int l = 0; l < n_layers; ++l) {
+            const int n_k = a.layer[l].n_k;
+            const bool last_layer = l + 1 >= n_layers;
+            const LayerPtrs cur = layer_ptrs(l), nxt = layer_ptrs(last_layer ? 0 : l + 1);
+            if (!first_table) {
+                sync();                                     // every wave is done with the previous layer's bias table
+                lds_bias[tid] = a.layer[l].bias[tid];       // (visible long before the first epilogue: a barrier per slab)
+            }
+            first_table = false;
+            for (int b = b0; b < b1; ++b) {
+                slab(I<0>{}, std::true_type{}, cur, nxt, last_layer, n_k, b0, b1, b, 0);
+                slab(I<1>{}, std::false_type{}, cur, nxt, last_layer, n_k, b0, b1, b, 1);
+                for (int s = 2; s < n_k; s += 2) {
+                    slab(I<0>{}, std::false_type{}, cur, nxt, last_layer, n_k, b0, b1, b, s);
+                    slab(I<1>{}, std::false_type{}, cur, nxt, last_layer, n_k, b0, b1, b, s + 1);
+                }
+                if constexpr (!(FLAGS & kNoEpilogue)) epilogue(l, b);
+            }
+        }
+    }
+    if constexpr (FLAGS & kNoEpilogue) epilogue(n_layers - 1, my_blocks - 1);
+    if constexpr (FLAGS & kClockProbe) {
+        if (tid == 0) {
+            a.clock_probe[2 * blockIdx.x] = shader_cycles() - probe_c;
+            a.clock_probe[2 * blockIdx.x + 1] = reference_ticks() - probe_r;
+        }
+    }       // (keeps the MFMAs alive)
 }
 
 }  // namespace lsp

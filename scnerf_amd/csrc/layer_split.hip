@@ -3,6 +3,7 @@
 //
 // What it computes is nn.Linear (+ ReLU) of the reference network's trunk, layers 1 .. 7 and feature_linear
 // (/root/reference NeRF/run_nerf_helpers.py:92-103, :105-128), layer 5 with the skip input [encoded point | h].
+#include <cstdlib>
 #include <scn_wave.h>
 
 #include "launch.h"
@@ -93,36 +94,106 @@ __global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restric
 namespace scn {
 namespace lsp {
 
-int launch_layer(const Args& a, hipStream_t stream) {
-    SCN_LDS_OPT_IN((layer_split_kernel<0>), kLdsBytes);
+// persistent workgroups per launch (one per CU of the MI355X; scnerf_layer_split_workgroups lowers it, e.g. to give
+// every workgroup several blocks of a small problem)
+static int& max_workgroups() {
+    static int g = 256;
+    return g;
+}
+
+// blocks per group of a chain (layer_split.h); SCNERF_LAYER_GROUP overrides (experiments)
+static int chain_group() {
+    static const int g = [] {
+        const char* e = getenv("SCNERF_LAYER_GROUP");
+        const int v = e ? atoi(e) : 0;
+        return v >= 2 ? v : 2;
+    }();
+    return g;
+}
+
+static int launch(const Args& a, hipStream_t stream) {
     const long n_blocks = (a.Ppad / 32 + 7) / 8;
-    constexpr long kCUs = 256;                 // MI355X: one persistent workgroup per CU (the kernel owns a SIMD per wave)
-    const unsigned G = (unsigned)(n_blocks < kCUs ? n_blocks : kCUs);
-    hipLaunchKernelGGL((layer_split_kernel<0>), dim3(G), dim3(kThreads), kLdsBytes, stream, a);
+    const long cap = max_workgroups();
+    const unsigned G = (unsigned)(n_blocks < cap ? n_blocks : cap);
+    if (a.n_layers > 1) {       // a chain: what a layer stores is read back two blocks later -- default cache policy
+        SCN_LDS_OPT_IN((layer_split_kernel<kPlainStore>), kLdsBytes);
+        hipLaunchKernelGGL((layer_split_kernel<kPlainStore>), dim3(G), dim3(kThreads), kLdsBytes, stream, a);
+    } else {
+        SCN_LDS_OPT_IN((layer_split_kernel<0>), kLdsBytes);
+        hipLaunchKernelGGL((layer_split_kernel<0>), dim3(G), dim3(kThreads), kLdsBytes, stream, a);
+    }
     return scn_launch_status();
+}
+
+// A chain goes out as ONE launch when every workgroup owns at least two 256-sample blocks (the pipeline then fetches
+// the next layer's first block long after it was stored); otherwise layer by layer.
+static int launch_chain(const Args& chain, hipStream_t stream) {
+    const long n_blocks = (chain.Ppad / 32 + 7) / 8;
+    if (chain.n_layers == 1 || n_blocks >= 2L * max_workgroups()) return launch(chain, stream);
+    for (int l = 0; l < chain.n_layers; ++l) {
+        Args one = chain;
+        one.layer[0] = chain.layer[l];
+        one.n_layers = 1;
+        const int rc = launch(one, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+template <int PD>
+static Layer forward_layer(int l, const short* planes, const float* bias_table, const float* act_in, const float* epts,
+                           float* act_out, unsigned* mask) {
+    Layer L;
+    L.X = act_in;
+    L.X2 = l == 5 ? epts : act_in;          // (a valid pointer either way: the select in load_x forms both addresses)
+    L.n_k = l == 5 ? 16 + skip_slabs<PD>() : 16;
+    L.relu = l < 8;
+    L.W = planes + (long)slab_offset<PD>(l) * kSlabShorts;
+    L.bias = bias_table;
+    L.Z = act_out;
+    L.mask = mask;
+    L.mask_in = nullptr;
+    L.vec = nullptr;
+    return L;
+}
+
+template <int PD>
+static Layer backward_layer(int entry, const short* planes, const float* alpha_table, const float* grad_in,
+                            float* grad_out, const unsigned* mask_in, const float* vec) {
+    Layer L;
+    L.X = grad_in;
+    L.X2 = grad_in;
+    L.n_k = 16;
+    L.relu = 0;
+    L.W = planes + (long)(fwd_slabs<PD>() + 16 * entry) * kSlabShorts;
+    L.bias = alpha_table;                    // read into LDS whether used or not: must be a valid table
+    L.Z = grad_out;
+    L.mask = nullptr;
+    L.mask_in = mask_in;
+    L.vec = entry == 0 ? vec : nullptr;
+    return L;
+}
+
+static Args chain_header(int n_layers, int x2_ld, long Ppad, int mode, int vec_stride, long n_vec) {
+    Args a;
+    a.n_layers = n_layers;
+    a.clock_probe = nullptr;
+    a.group = chain_group();
+    a.x2_ld = x2_ld;
+    a.Ppad = Ppad;
+    a.mode = mode;
+    a.vec_stride = vec_stride;
+    a.n_vec = n_vec;
+    return a;
 }
 
 // layer l = 1 .. 8 of the network out of the plane buffer; act_in / act_out tile-native sections
 template <int PD>
 int launch_network_layer(int l, const short* planes, const float* bias_table, const float* act_in, const float* epts,
                          float* act_out, unsigned* mask, long Ppad, hipStream_t stream) {
-    Args a;
-    a.X = act_in;
-    a.X2 = l == 5 ? epts : act_in;          // (a valid pointer either way: the select in load_x forms both addresses)
-    a.x2_ld = Var<PD>::kEW;
-    a.n_k = l == 5 ? 16 + skip_slabs<PD>() : 16;
-    a.W = planes + (long)slab_offset<PD>(l) * kSlabShorts;
-    a.bias = bias_table;
-    a.Z = act_out;
-    a.mask = mask;
-    a.Ppad = Ppad;
-    a.relu = l < 8;
-    a.mode = 0;
-    a.mask_in = nullptr;
-    a.vec = nullptr;
-    a.vec_stride = 0;
-    a.n_vec = 0;
-    return launch_layer(a, stream);
+    Args a = chain_header(1, Var<PD>::kEW, Ppad, 0, 0, 0);
+    a.layer[0] = forward_layer<PD>(l, planes, bias_table, act_in, epts, act_out, mask);
+    return launch_chain(a, stream);
 }
 
 // data-gradient layer `entry` (0: feature_linear^T + the density head's rank-1 term; e = 1 .. 7: layer (8 - e)^T):
@@ -131,32 +202,75 @@ template <int PD>
 int launch_network_layer_bwd(int entry, const short* planes, const float* alpha_table, const float* grad_in,
                              float* grad_out, const unsigned* mask_in, const float* vec, int vec_stride, long n_vec,
                              long Ppad, hipStream_t stream) {
-    Args a;
-    a.X = grad_in;
-    a.X2 = grad_in;
-    a.x2_ld = 0;
-    a.n_k = 16;
-    a.W = planes + (long)(fwd_slabs<PD>() + 16 * entry) * kSlabShorts;
-    a.bias = alpha_table;                    // read into LDS whether used or not: must be a valid table
-    a.Z = grad_out;
-    a.mask = nullptr;
-    a.Ppad = Ppad;
-    a.relu = 0;
-    a.mode = 1;
-    a.mask_in = mask_in;
-    a.vec = entry == 0 ? vec : nullptr;
-    a.vec_stride = vec_stride;
-    a.n_vec = n_vec;
-    return launch_layer(a, stream);
+    Args a = chain_header(1, Var<PD>::kEW, Ppad, 1, vec_stride, n_vec);
+    a.layer[0] = backward_layer<PD>(entry, planes, alpha_table, grad_in, grad_out, mask_in, vec);
+    return launch_chain(a, stream);
 }
-template int launch_network_layer_bwd<3>(int, const short*, const float*, const float*, float*, const unsigned*, const float*, int, long, long, hipStream_t);
-template int launch_network_layer_bwd<4>(int, const short*, const float*, const float*, float*, const unsigned*, const float*, int, long, long, hipStream_t);
+
+// layers 1 .. 8 over the training workspace `save` (sections of mlp_common.h) as one chain
+template <int PD>
+int launch_network_chain_fwd(const short* planes, const float* wpacked, float* save, long P, hipStream_t stream) {
+    using V = Var<PD>;
+    const long Ppad = padded_samples(P);
+    unsigned* masks = reinterpret_cast<unsigned*>(save + (long)V::kSavePerSample * Ppad);
+    const float* epts = save + (long)kSaveEpts * Ppad;
+    Args a = chain_header(8, V::kEW, Ppad, 0, 0, 0);
+    for (int l = 1; l <= 8; ++l)
+        a.layer[l - 1] = forward_layer<PD>(l, planes, wpacked + (l < 8 ? V::kFwdBias + 256 * l : V::kFwdBiasF),
+                                           save + (long)(kSaveAct + 256 * (l - 1)) * Ppad, epts,
+                                           save + (long)(l < 8 ? kSaveAct + 256 * l : kSaveFeat) * Ppad,
+                                           l < 8 ? masks + (long)l * (Ppad / 32) * 256 : nullptr);
+    return launch_chain(a, stream);
+}
+
+// entries 0 .. 7 of the data-gradient chain over the gradient workspace: d feature -> dZ_7 -> ... -> dZ_0
+template <int PD>
+int launch_network_chain_bwd(const short* planes, const float* wpacked_bwd, const float* save, float* grads,
+                             const float* d_raw, long P, hipStream_t stream) {
+    using V = Var<PD>;
+    const long Ppad = padded_samples(P);
+    const unsigned* masks = reinterpret_cast<const unsigned*>(save + (long)V::kSavePerSample * Ppad);
+    const float* alpha = wpacked_bwd + V::kBwdAlphaW;
+    Args a = chain_header(8, V::kEW, Ppad, 1, 4, P);
+    for (int e = 0; e < 8; ++e)
+        a.layer[e] = backward_layer<PD>(e, planes, alpha, grads + (long)(e == 0 ? kGradDfeat : kGradDz + (8 - e) * 256) * Ppad,
+                                        grads + (long)(kGradDz + (7 - e) * 256) * Ppad,
+                                        masks + (long)(7 - e) * (Ppad / 32) * 256, d_raw + 3);
+    return launch_chain(a, stream);
+}
 
 template int launch_network_layer<3>(int, const short*, const float*, const float*, const float*, float*, unsigned*, long, hipStream_t);
 template int launch_network_layer<4>(int, const short*, const float*, const float*, const float*, float*, unsigned*, long, hipStream_t);
+template int launch_network_layer_bwd<3>(int, const short*, const float*, const float*, float*, const unsigned*, const float*, int, long, long, hipStream_t);
+template int launch_network_layer_bwd<4>(int, const short*, const float*, const float*, float*, const unsigned*, const float*, int, long, long, hipStream_t);
+template int launch_network_chain_fwd<3>(const short*, const float*, float*, long, hipStream_t);
+template int launch_network_chain_fwd<4>(const short*, const float*, float*, long, hipStream_t);
+template int launch_network_chain_bwd<3>(const short*, const float*, const float*, float*, const float*, long, hipStream_t);
+template int launch_network_chain_bwd<4>(const short*, const float*, const float*, float*, const float*, long, hipStream_t);
 
 }  // namespace lsp
 }  // namespace scn
+
+extern "C" int scnerf_layer_split_workgroups(int n) {
+    if (n >= 1 && n <= 1024) scn::lsp::max_workgroups() = n;
+    return scn::lsp::max_workgroups();
+}
+
+extern "C" int scnerf_layer_split_chain_fwd(int pt_dims, const short* planes, const float* wpacked, float* save,
+                                            long long n_samples, void* stream) {
+    SCN_RETURN_IF(!planes || !wpacked || !save || n_samples < 0 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
+    if (n_samples == 0) return 0;
+    return pt_dims == 3 ? scn::lsp::launch_network_chain_fwd<3>(planes, wpacked, save, (long)n_samples, (hipStream_t)stream)
+                        : scn::lsp::launch_network_chain_fwd<4>(planes, wpacked, save, (long)n_samples, (hipStream_t)stream);
+}
+
+extern "C" int scnerf_layer_split_chain_bwd(int pt_dims, const short* planes, const float* wpacked_bwd, const float* save,
+                                            float* grads, const float* d_raw, long long n_samples, void* stream) {
+    SCN_RETURN_IF(!planes || !wpacked_bwd || !save || !grads || !d_raw || n_samples < 0 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
+    if (n_samples == 0) return 0;
+    return pt_dims == 3 ? scn::lsp::launch_network_chain_bwd<3>(planes, wpacked_bwd, save, grads, d_raw, (long)n_samples, (hipStream_t)stream)
+                        : scn::lsp::launch_network_chain_bwd<4>(planes, wpacked_bwd, save, grads, d_raw, (long)n_samples, (hipStream_t)stream);
+}
 
 extern "C" long long scnerf_split_planes_shorts(int pt_dims) {
     if (pt_dims != 3 && pt_dims != 4) return -1;

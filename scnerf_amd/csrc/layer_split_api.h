@@ -20,5 +20,13 @@ int launch_network_layer_bwd(int entry, const short* planes, const float* alpha_
                              float* grad_out, const unsigned* mask_in, const float* vec, int vec_stride, long n_vec,
                              long Ppad, hipStream_t stream);
 
+// layers 1 .. 8 of the training forward over the workspace `save` / entries 0 .. 7 of the data-gradient chain over
+// `grads`, as ONE launch when every workgroup owns at least two 256-sample blocks (else layer by layer)
+template <int PD>
+int launch_network_chain_fwd(const short* planes, const float* wpacked, float* save, long P, hipStream_t stream);
+template <int PD>
+int launch_network_chain_bwd(const short* planes, const float* wpacked_bwd, const float* save, float* grads,
+                             const float* d_raw, long P, hipStream_t stream);
+
 }  // namespace lsp
 }  // namespace scn

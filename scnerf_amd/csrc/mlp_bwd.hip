@@ -262,20 +262,11 @@ template <int PD>
 static int bwd_split(const float* d_raw, const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
                      const float* wpacked_bwd, const short* planes, const float* save, float* grads, float* d_pts,
                      float* d_views, long long n_samples, hipStream_t st) {
-    using V = Var<PD>;
-    const long P = (long)n_samples, Ppad = padded_samples(P);
+    const long P = (long)n_samples;
     int rc = launch_bwd<PD, 1>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st);
     if (rc) return rc;
-    const unsigned* masks = reinterpret_cast<const unsigned*>(save + (long)V::kSavePerSample * Ppad);
-    const float* alpha = wpacked_bwd + V::kBwdAlphaW;
-    // entry 0: d feature -> dZ_7 (feature_linear^T + the density head, gate 7); entry e: dZ_{8-e} -> dZ_{7-e}
-    for (int e = 0; e < 8; ++e) {
-        const float* in = grads + (long)(e == 0 ? kGradDfeat : kGradDz + (8 - e) * 256) * Ppad;
-        float* out = grads + (long)(kGradDz + (7 - e) * 256) * Ppad;
-        rc = scn::lsp::launch_network_layer_bwd<PD>(e, planes, alpha, in, out, masks + (long)(7 - e) * (Ppad / 32) * 256,
-                                                    d_raw + 3, 4, P, Ppad, st);
-        if (rc) return rc;
-    }
+    rc = scn::lsp::launch_network_chain_bwd<PD>(planes, wpacked_bwd, save, grads, d_raw, P, st);
+    if (rc) return rc;
     return launch_bwd<PD, 2>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st);
 }
 

@@ -352,19 +352,7 @@ static int launch_coarse_stage(const CoarseStage& cs, const float* wpacked, floa
 // layers 1 .. 7 and feature_linear as split-arithmetic GEMMs between the two stages of the fused kernel
 template <int PD>
 static int trunk_layers_split(const float* wpacked, const short* planes, float* save, long P, hipStream_t st) {
-    using V = Var<PD>;
-    const long Ppad = padded_samples(P);
-    unsigned* masks = reinterpret_cast<unsigned*>(save + (long)V::kSavePerSample * Ppad);
-    const float* epts = save + (long)kSaveEpts * Ppad;
-    for (int l = 1; l <= 8; ++l) {
-        const float* in = save + (long)(kSaveAct + 256 * (l - 1)) * Ppad;
-        float* out = save + (long)(l < 8 ? kSaveAct + 256 * l : kSaveFeat) * Ppad;
-        const float* bias = wpacked + (l < 8 ? V::kFwdBias + 256 * l : V::kFwdBiasF);
-        unsigned* mask = l < 8 ? masks + (long)l * (Ppad / 32) * 256 : nullptr;
-        const int rc = scn::lsp::launch_network_layer<PD>(l, planes, bias, in, epts, out, mask, Ppad, st);
-        if (rc) return rc;
-    }
-    return 0;
+    return scn::lsp::launch_network_chain_fwd<PD>(planes, wpacked, save, P, st);
 }
 
 template <int PD>

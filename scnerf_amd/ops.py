@@ -265,13 +265,10 @@ def _fwd_split_piecewise(pd, P, tag, wpacked, planes, save, stage_call):
     names = ["act%d" % l for l in range(8)] + ["feat"]
     with PROFILE.region("mlp_fwd_kernel<stage 1: encoding + layer 0>%s/P=%d" % (tag, P), 2 * 256 * lay.in_pts * P):
         _capi.check(stage_call(1), "forward stage 1")
-    for l in range(1, 9):
-        bias = wpacked.data_ptr() + ((lay.fwd_bias + 256 * l) if l < 8 else lay.fwd_bias_f) * esz
-        mask = base + (total + l * (Pp // 32) * 256) * esz if l < 8 else None
-        with PROFILE.region("layer_split_kernel%s/P=%d" % (tag, P), _layer_flop(pd, l, P)):
-            _capi.check(lib.scnerf_layer_split(pd, l, _p(planes), bias, base + off[names[l - 1]] * esz,
-                                               base + off["epts"] * esz, base + off[names[l]] * esz, mask, P, _stream()),
-                        "scnerf_layer_split")
+    # (layers 1 .. 8 go out as one launch -- a chain -- when every persistent workgroup owns two blocks or more)
+    with PROFILE.region("layer_split_kernel<8 layers>%s/P=%d" % (tag, P), sum(_layer_flop(pd, l, P) for l in range(1, 9))):
+        _capi.check(lib.scnerf_layer_split_chain_fwd(pd, _p(planes), _p(wpacked), _p(save), P, _stream()),
+                    "scnerf_layer_split_chain_fwd")
     with PROFILE.region("mlp_fwd_kernel<stage 2: heads>%s/P=%d" % (tag, P), 2 * (128 * 283 + 3 * 128 + 256) * P):
         _capi.check(stage_call(2), "forward stage 2")
 
@@ -381,13 +378,9 @@ def _bwd_split_piecewise(pd, P, tag, wpacked_bwd, planes, save, grads, d_raw, st
     alpha = wpacked_bwd.data_ptr() + lay.bwd_alpha_w * 4
     with PROFILE.region("mlp_bwd_kernel<stage 1: heads>%s/P=%d" % (tag, P), 2 * (128 * 283 + 3 * 128) * P):
         _capi.check(stage_call(1), "backward stage 1")
-    for e in range(8):
-        src = goff["dfeat"] if e == 0 else goff[gnames[8 - e]]
-        dst = goff[gnames[7 - e]]
-        with PROFILE.region("layer_split_kernel%s/P=%d" % (tag, P), 2 * 256 * 256 * P):
-            _capi.check(lib.scnerf_layer_split_bwd(pd, e, _p(planes), alpha, grads.data_ptr() + src * 4,
-                                                   grads.data_ptr() + dst * 4, masks + (7 - e) * (Pp // 32) * 256 * 4,
-                                                   _p(d_raw), P, _stream()), "scnerf_layer_split_bwd")
+    with PROFILE.region("layer_split_kernel<8 layers>%s/P=%d" % (tag, P), 8 * 2 * 256 * 256 * P):
+        _capi.check(lib.scnerf_layer_split_chain_bwd(pd, _p(planes), _p(wpacked_bwd), _p(save), _p(grads), _p(d_raw), P,
+                                                     _stream()), "scnerf_layer_split_chain_bwd")
     with PROFILE.region("mlp_bwd_kernel<stage 2: encoded-point end>%s/P=%d" % (tag, P), 2 * 2 * 256 * lay.in_pts * P):
         _capi.check(stage_call(2), "backward stage 2")
 

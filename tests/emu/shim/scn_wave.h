@@ -84,6 +84,22 @@ inline unsigned high_halves(unsigned lo_word, unsigned hi_word) { return (lo_wor
 inline f32x4 load_stream(const f32x4* p) { return *p; }
 typedef const char* global_bytes;
 inline global_bytes uniform_global(const void* p) { return static_cast<const char*>(p); }
+inline global_bytes uniform_global(global_bytes p) { return p; }
+inline unsigned pinned_here(unsigned x) { return x; }
+inline unsigned long long shader_cycles() { return 0; }
+inline unsigned long long reference_ticks() { return 0; }
+typedef char* global_bytes_rw;
+inline global_bytes_rw uniform_global_rw(void* p) { return static_cast<char*>(p); }
+template <typename V>
+inline void store_at(global_bytes_rw base, unsigned lane_off, V v) { std::memcpy(base + lane_off, &v, sizeof(V)); }
+template <typename V>
+inline void store_stream_at(global_bytes_rw base, unsigned lane_off, V v) { std::memcpy(base + lane_off, &v, sizeof(V)); }
+template <typename V>
+inline V load_at(global_bytes base, unsigned lane_off) {
+    V v;
+    std::memcpy(&v, base + lane_off, sizeof(V));
+    return v;
+}
 inline f32x4 load_stream_f32x4(global_bytes base, unsigned lane_off) {
     f32x4 v;
     std::memcpy(&v, base + lane_off, 16);

@@ -158,3 +158,36 @@ def test_render_rays_split_on_the_simt_interpreter():
     assert float((gr_a - gr_b).abs().max()) <= 1e-4 * float(gr_a.abs().max())
     for a, b in zip(gp_a, gp_b):
         assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-9
+
+
+def test_chained_layers_equal_layer_by_layer_launches():
+    """Eight layers in ONE launch (every workgroup keeps its blocks from layer to layer; taken when a workgroup owns
+    at least two blocks -- here forced by capping the persistent workgroups at one) against the layer-by-layer
+    launches, forward and data-gradient chains: bit-identical workspaces."""
+    pd, n_rays, spr = 3, 16, 50
+    P = n_rays * spr                                           # 4 blocks of 256 samples (the last one partial): with one
+                                                               # workgroup, two groups of two blocks
+    p, wpk, save = _forward_with_save(pd, P, n_rays, spr, 41)
+    from tests.emu_mlp_util import pack_backward
+    wbk = pack_backward(p, pd)
+    planes = np.zeros(H.lib().scnerf_split_planes_shorts(pd), np.int16)
+    H.call("scnerf_pack_split_planes", pd, flat_params(p, pd), planes, None)
+    g = torch.Generator().manual_seed(41)
+    d_raw = torch.randn(P, 4, generator=g).numpy()
+    out = {}
+    try:
+        for cap in (256, 1):
+            assert H.lib().scnerf_layer_split_workgroups(cap) == cap
+            s2 = save.copy()
+            s2[np.isnan(s2)] = 0.0
+            H.call("scnerf_layer_split_chain_fwd", pd, planes, wpk, s2, P, None)
+            grads = np.zeros(ML.grad_floats(P), np.float32)
+            off, _ = ML.section_offsets(ML.GRAD_SECTIONS, P)
+            Pp = ML.padded_samples(P)
+            grads[off["dfeat"]: off["dfeat"] + 256 * Pp] = np.random.default_rng(3).standard_normal(256 * Pp).astype(np.float32)
+            H.call("scnerf_layer_split_chain_bwd", pd, planes, wbk, s2, grads, d_raw, P, None)
+            out[cap] = (s2, grads)
+    finally:
+        H.lib().scnerf_layer_split_workgroups(256)
+    np.testing.assert_array_equal(out[256][0].view(np.int32), out[1][0].view(np.int32))
+    np.testing.assert_array_equal(out[256][1].view(np.int32), out[1][1].view(np.int32))

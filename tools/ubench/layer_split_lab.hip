@@ -108,7 +108,18 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(bias_table_kernel, dim3(1), dim3(256), 0, 0, b, table);
     CK(hipMemset(Z, 0xff, (size_t)Ppad * 256 * 4));
     CK(hipDeviceSynchronize());
-    Args a{X, nullptr, 0, 16, Wp, table, Z, mask, Ppad, 1, 0, nullptr, nullptr, 0, 0};
+    Args a;
+    a.n_layers = 1; a.clock_probe = nullptr; a.group = 1 << 20; a.x2_ld = 64; a.Ppad = Ppad; a.mode = 0; a.vec_stride = 0; a.n_vec = 0;
+    a.layer[0] = Layer{X, X, 16, 1, Wp, table, Z, mask, nullptr, nullptr};
+    // the same layer eight times in ONE launch, every layer into a buffer of its own (what a training pass does)
+    float* Zs[8];
+    for (int l = 0; l < 8; ++l) CK(hipMalloc(&Zs[l], (size_t)Ppad * 256 * 4));
+    Args chain = a;
+    chain.n_layers = 8;
+    for (int l = 0; l < 8; ++l) {
+        const float* in = l ? Zs[l - 1] : X;
+        chain.layer[l] = Layer{in, in, 16, 1, Wp, table, Zs[l], mask, nullptr, nullptr};
+    }
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kNoEpilogue>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kNoCut>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
@@ -129,6 +140,23 @@ int main(int argc, char** argv) {
     };
     report("layer split x6", time_kernel(layer_split_kernel<0>, a, G, 40));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kPlainStore>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    for (int group : {1 << 20, 2, 3, 4, 6}) {
+        chain.group = group;
+        const float ms8 = time_kernel(layer_split_kernel<0>, chain, G, 8);
+        const float ms8p = time_kernel(layer_split_kernel<kPlainStore>, chain, G, 8);
+        printf("chained, groups of %-7d                     %8.3f ms per layer (8 layers in one launch: %.3f ms); plain stores %.3f\n",
+               group, ms8 / 8, ms8, ms8p / 8);
+        fflush(stdout);
+    }
+    {   // the chain's last layer against fp64 from its input (groups of 2)
+        chain.group = 2;
+        hipLaunchKernelGGL((layer_split_kernel<0>), dim3(G), dim3(256), kLdsBytes, 0, chain);
+        CK(hipMemset(errs, 0, 16));
+        hipLaunchKernelGGL(check_kernel, dim3(4096), dim3(256), 0, 0, Zs[6], W, b, Zs[7], P, 1, 7919L, errs, errs + 1);
+        CK(hipMemcpy(h, errs, 16, hipMemcpyDeviceToHost));
+        printf("chain, groups of 2, layer 8 from layer 7 vs fp64: max |err| = %.3e, scaled %.3e\n", h[0], h[1]);
+    }
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kPlainStore>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
     report("layer split x6, plain stores", time_kernel(layer_split_kernel<kPlainStore>, a, G, 40));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kNoZStore>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
     report("layer split x6, epilogue without Z stores", time_kernel(layer_split_kernel<kNoZStore>, a, G, 40));
@@ -136,6 +164,46 @@ int main(int argc, char** argv) {
     report("layer split x6, X loaded but not cut, no epilogue", time_kernel(layer_split_kernel<kNoCutMath | kNoEpilogue>, a, G, 40));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kNoBarrier>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
     report("layer split x6, no barriers (racy)", time_kernel(layer_split_kernel<kNoBarrier>, a, G, 40));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kSameX | kNoEpilogue>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    report("layer split x6, X always block 0 (L2 hits), no epilogue", time_kernel(layer_split_kernel<kSameX | kNoEpilogue>, a, G, 40));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kNoWCopy | kNoEpilogue>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    report("layer split x6, no W copy, no epilogue", time_kernel(layer_split_kernel<kNoWCopy | kNoEpilogue>, a, G, 40));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kNoWCopy | kSameX | kNoEpilogue>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    report("layer split x6, no W copy, X tile 0, no epilogue", time_kernel(layer_split_kernel<kNoWCopy | kSameX | kNoEpilogue>, a, G, 40));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kNoWCopy | kNoCut | kNoEpilogue>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    report("layer split x6, MFMA only (no W copy, no X)", time_kernel(layer_split_kernel<kNoWCopy | kNoCut | kNoEpilogue>, a, G, 40));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kNoDupX | kNoEpilogue>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    report("layer split x6, no two waves load the same X, no epilogue", time_kernel(layer_split_kernel<kNoDupX | kNoEpilogue>, a, G, 40));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kNoDupX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    report("layer split x6, no two waves load the same X", time_kernel(layer_split_kernel<kNoDupX>, a, G, 40));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kRotate | kNoEpilogue>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    report("layer split x6, K loop rotated per block, no epilogue", time_kernel(layer_split_kernel<kRotate | kNoEpilogue>, a, G, 40));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kRotate>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    report("layer split x6, K loop rotated per block", time_kernel(layer_split_kernel<kRotate>, a, G, 40));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kXfromW | kNoEpilogue>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    report("layer split x6, X loads fetch W pieces, no epilogue", time_kernel(layer_split_kernel<kXfromW | kNoEpilogue>, a, G, 40));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kRandomX | kNoCut | kNoEpilogue>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    report("layer split x6, MFMA + W stream, random static X planes", time_kernel(layer_split_kernel<kRandomX | kNoCut | kNoEpilogue>, a, G, 40));
+    {   // the shader clock under each variant: shader cycles / 100 MHz reference ticks, workgroup 0 and the mean
+        unsigned long long* probe;
+        CK(hipMalloc(&probe, 16 * 256));
+        Args ap = a;
+        ap.clock_probe = probe;
+        auto clock_of = [&](auto kern, const char* name) {
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+            const float ms = time_kernel(kern, ap, G, 40);
+            unsigned long long h2[512];
+            CK(hipMemcpy(h2, probe, 16 * G, hipMemcpyDeviceToHost));
+            double cyc = 0, ref = 0;
+            for (int i = 0; i < G; ++i) { cyc += (double)h2[2 * i]; ref += (double)h2[2 * i + 1]; }
+            printf("%-60s %8.3f ms   shader clock %.3f GHz (cycles per workgroup %.0f)\n", name, ms, cyc / ref * 0.1, cyc / G);
+            fflush(stdout);
+        };
+        clock_of(layer_split_kernel<kClockProbe>, "clock: full kernel");
+        clock_of(layer_split_kernel<kClockProbe | kNoEpilogue>, "clock: no epilogue");
+        clock_of(layer_split_kernel<kClockProbe | kNoCut | kNoEpilogue>, "clock: MFMA + W stream, garbage X planes");
+        clock_of(layer_split_kernel<kClockProbe | kRandomX | kNoCut | kNoEpilogue>, "clock: MFMA + W stream, random static X planes");
+    }
     report("layer split x6, no epilogue", time_kernel(layer_split_kernel<kNoEpilogue>, a, G, 40));
     report("layer split x6, no X loads / cuts", time_kernel(layer_split_kernel<kNoCut>, a, G, 40));
     report("layer split x6, MFMA + W stream only", time_kernel(layer_split_kernel<kNoCut | kNoEpilogue>, a, G, 40));
