@@ -33,6 +33,18 @@ __device__ __forceinline__ f32x16 mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c)
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+// v_mfma_f32_32x32x16_f16: the same shape on fp16 operands (bit patterns in shorts)
+__device__ __forceinline__ f32x16 mfma_32x32x16_f16(s16x8 a, s16x8 b, f32x16 c) {
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// fp32 -> fp16 (round to nearest even) as a bit pattern in the low half of a word, and back
+__device__ __forceinline__ unsigned f16_bits(float x) { return __builtin_bit_cast(unsigned short, (_Float16)x); }
+__device__ __forceinline__ float f16_value(unsigned bits) { return (float)__builtin_bit_cast(_Float16, (unsigned short)bits); }
+// the low halves of two words as one word (lo_word's in the low half)
+__device__ __forceinline__ unsigned low_halves(unsigned lo_word, unsigned hi_word) {
+    return __builtin_amdgcn_perm(hi_word, lo_word, 0x05040100u);
+}
 // ds_read_b64_tr_b16: every lane names 8 bytes of LDS (4 x 16 bit, 8-byte aligned); the 16 lanes of a group
 // together name a [4 rows][16 columns] block (lane c: row c >> 2, columns 4 (c & 3) .. +3) and lane c
 // receives column c, rows 0 .. 3 -- the transpose an MFMA operand needs when the LDS image is k-major.

@@ -104,6 +104,7 @@ struct Args {
     int vec_stride;
     long n_vec;
     unsigned long long* clock_probe;   // lab only (kClockProbe): [workgroup][2]
+    float x_scale, out_scale;          // lab only (kHalf3)
 };
 
 enum : int {
@@ -116,6 +117,8 @@ enum : int {
     kXfromW = 1024,       // timing experiment: the activation loads fetch pieces of the weight slab instead (wrong results)
     kRandomX = 2048,      // timing experiment (with kNoCut): the activation planes hold pseudo-random bits instead of garbage
     kClockProbe = 4096,   // lab: every workgroup writes its shader-cycle and reference-tick counts to Args::clock_probe
+    kHalf3 = 8192,        // lab prototype: TWO fp16 planes per operand and three products (Wh Xh)(Wh Xl)(Wl Xh); the
+                          // operands scaled by the powers of two in Args::x_scale / the packer, the result by out_scale
     kNoDupX = 256,        // timing experiment: the two waves that share samples load DIFFERENT tiles (wrong results)
     kNoBarrier = 64,      // timing experiment: no workgroup barriers in the slab loop (racy: results are wrong)
     kPlainStore = 4,      // default-policy stores instead of non-temporal ones: what a chain in groups of 2 blocks uses
@@ -207,7 +210,19 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
     auto cut_step = [&](auto set_tag, auto j_tag, auto dst_tag, auto step_tag) {
         constexpr int SET = decltype(set_tag)::value, j = decltype(j_tag)::value, D = decltype(dst_tag)::value,
                       STEP = decltype(step_tag)::value;
-        if constexpr (FLAGS & kNoCutMath) {
+        if constexpr (FLAGS & kHalf3) {
+            if constexpr (STEP < 8) {
+                const float x = raw[SET][j][STEP >> 2][STEP & 3] * a.x_scale;
+                cu[STEP] = f16_bits(x);
+                c1[STEP] = f16_bits(x - f16_value(cu[STEP]));          // (the difference is exact)
+            } else if constexpr (STEP < 10) {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const unsigned (&src)[8] = STEP == 8 ? cu : c1;
+                const u32x4 v = {low_halves(src[0], src[1]), low_halves(src[2], src[3]),
+                                 low_halves(src[4], src[5]), low_halves(src[6], src[7])};
+                xp[D][STEP - 8] = __builtin_bit_cast(s16x8, v);
+            }
+        } else if constexpr (FLAGS & kNoCutMath) {
             if constexpr (STEP == 8) {
                 xp[D][0] = __builtin_bit_cast(s16x8, raw[SET][j][0]);
                 xp[D][1] = __builtin_bit_cast(s16x8, raw[SET][j][1]);
@@ -272,9 +287,28 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
             }
             sched_fence();
         };
+        if constexpr (FLAGS & kHalf3) {
+            auto one3 = [&](auto slot_tag) {
+                constexpr int S = decltype(slot_tag)::value;
+                constexpr int prod = S >> 2, i = S & 3;
+                constexpr int wpl = prod == 2 ? 1 : 0, xpl = prod == 1 ? 1 : 0;          // (Wh Xh)(Wh Xl)(Wl Xh)
+                filler(slot_tag);
+                sched_fence();
+                if constexpr (FIRST && prod == 0) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    acc[i][j] = mfma_32x32x16_f16(wf[wpl][i], xp[PP][xpl], zero);
+                } else {
+                    acc[i][j] = mfma_32x32x16_f16(wf[wpl][i], xp[PP][xpl], acc[i][j]);
+                }
+                sched_fence();
+            };
+            one3(I<0>{}); one3(I<1>{}); one3(I<2>{}); one3(I<3>{}); one3(I<4>{}); one3(I<5>{});
+            one3(I<6>{}); one3(I<7>{}); one3(I<8>{}); one3(I<9>{}); one3(I<10>{}); one3(I<11>{});
+        } else {
         one(I<0>{}); one(I<1>{}); one(I<2>{}); one(I<3>{}); one(I<4>{}); one(I<5>{}); one(I<6>{}); one(I<7>{});
         one(I<8>{}); one(I<9>{}); one(I<10>{}); one(I<11>{}); one(I<12>{}); one(I<13>{}); one(I<14>{}); one(I<15>{});
         one(I<16>{}); one(I<17>{}); one(I<18>{}); one(I<19>{}); one(I<20>{}); one(I<21>{}); one(I<22>{}); one(I<23>{});
+        }
     };
 
     // slab u out of LDS buffer BUF (= u & 1 = raw set): per sample tile j
@@ -309,6 +343,20 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
         auto fill = [&](auto j_tag) {
             return [&](auto slot_tag) {
                 constexpr int j = decltype(j_tag)::value, S = decltype(slot_tag)::value;
+                if constexpr (FLAGS & kHalf3) {         // 12 slots per sample tile: the same fillers, twice as dense
+                    if constexpr (S <= 9) {
+                        if constexpr (j < 3) cut_step(Set{}, I<j + 1>{}, I<(j + 1) & 1>{}, I<S>{});
+                        else cut_step(Other{}, I<0>{}, I<0>{}, I<S>{});
+                    }
+                    if constexpr (S == 3) load_x(Set{}, A, I<j>{}, I<0>{});
+                    if constexpr (S == 9) load_x(Set{}, A, I<j>{}, I<1>{});
+                    if constexpr ((S == 0 || S == 6) && !(FLAGS & kNoWCopy)) {
+                        if constexpr (j <= 2) write_w(BUF ^ 1, I<2 * j + (S == 6)>{});
+                        if constexpr (j >= 1) load_w(A, I<2 * (j - 1) + (S == 6)>{});
+                    }
+                    if constexpr (j == 0 && S >= 1 && S <= 4) read_w(BUF, I<1>{}, I<S - 1>{});
+                    if constexpr (j == 3 && S >= 8) read_w(BUF ^ 1, I<0>{}, I<S - 8>{});
+                } else {
                 if constexpr (S <= 10) {
                     if constexpr (j < 3) cut_step(Set{}, I<j + 1>{}, I<(j + 1) & 1>{}, I<S>{});
                     else cut_step(Other{}, I<0>{}, I<0>{}, I<S>{});
@@ -324,6 +372,7 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
                 } else if constexpr (j == 3) {
                     if constexpr (S == 12 || S == 14 || S == 16 || S == 18) read_w(BUF ^ 1, I<0>{}, I<(S - 12) / 2>{});
                     if constexpr (S >= 20) read_w(BUF ^ 1, I<1>{}, I<S - 20>{});
+                }
                 }
             };
         };
@@ -373,7 +422,8 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = max_raw(add_raw(acc[i][j][4 * q + e], bc[e]), lo);
+                        if constexpr (FLAGS & kHalf3) v[e] = max_raw(fmaf(acc[i][j][4 * q + e], a.out_scale, bc[e]), lo);
+                        else v[e] = max_raw(add_raw(acc[i][j][4 * q + e], bc[e]), lo);
                         hb[j] = shift_in_positive(hb[j], v[e]);
                     }
                     const unsigned dst = zoff + (unsigned)IDX * 1024u;

@@ -178,6 +178,7 @@ static Args chain_header(int n_layers, int x2_ld, long Ppad, int mode, int vec_s
     Args a;
     a.n_layers = n_layers;
     a.clock_probe = nullptr;
+    a.x_scale = a.out_scale = 1.f;
     a.group = chain_group();
     a.x2_ld = x2_ld;
     a.Ppad = Ppad;

@@ -69,6 +69,42 @@ inline f32x16 mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
     }
     return c;
 }
+inline unsigned f16_bits(float x) {
+    const _Float16 h = (_Float16)x;
+    unsigned short u;
+    std::memcpy(&u, &h, 2);
+    return u;
+}
+inline float f16_value(unsigned bits) {
+    const unsigned short u = (unsigned short)bits;
+    _Float16 h;
+    std::memcpy(&h, &u, 2);
+    return (float)h;
+}
+inline unsigned low_halves(unsigned lo_word, unsigned hi_word) { return (lo_word & 0xffffu) | (hi_word << 16); }
+inline f32x16 mfma_32x32x16_f16(s16x8 a, s16x8 b, f32x16 c) {
+    uint64_t mine[4];
+    std::memcpy(&mine[0], &a, 16);
+    std::memcpy(&mine[2], &b, 16);
+    uint64_t all[4][64];
+    for (int w = 0; w < 4; ++w) {
+        const uint64_t* x = simt::wave_exchange(mine[w]);
+        std::memcpy(all[w], x, sizeof(all[w]));
+    }
+    auto elem = [&](int word0, int lane, int k) {
+        const uint64_t u = all[word0 + (k >> 2)][lane];
+        return f16_value((unsigned)(uint16_t)(u >> (16 * (k & 3))));
+    };
+    const int l = simt::cur_lane();
+    const int j = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        double sum = 0.0;
+        for (int k = 0; k < 16; ++k) sum += (double)elem(0, i + 32 * (k >> 3), k & 7) * (double)elem(2, j + 32 * (k >> 3), k & 7);
+        c[r] = (float)((double)c[r] + sum);
+    }
+    return c;
+}
 // ds_read_b64_tr_b16: lane c of a 16-lane group names row c >> 2, columns 4 (c & 3) .. +3 of the group's
 // [4][16] block and receives column c
 inline s16x4 lds_read_tr16(const short* p) {

@@ -50,6 +50,19 @@ __global__ void pack_planes_kernel(const float* W, short* out) {
     for (int q = 0; q < 3; ++q) out[(((size_t)(s * 3 + q) * 8 + T) * 64 + lane) * 8 + e] = (short)pl[q];
 }
 
+// the fp16 prototype's planes: h = f16(w * scale), l = f16(w * scale - h) (the third plane stays empty)
+__global__ void pack_planes_f16_kernel(const float* W, short* out, float scale) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // (s, T, lane, e)
+    if (idx >= 16 * 8 * 64 * 8) return;
+    const int e = idx & 7, lane = (idx >> 3) & 63, T = (idx >> 9) & 7, s = idx >> 12;
+    const int n = 32 * T + (lane & 31), k = 16 * s + 8 * (lane >> 5) + e;
+    const float x = W[n * 256 + k] * scale;
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    const short pl[3] = {__builtin_bit_cast(short, h), __builtin_bit_cast(short, l), 0};
+    for (int q = 0; q < 3; ++q) out[(((size_t)(s * 3 + q) * 8 + T) * 64 + lane) * 8 + e] = pl[q];
+}
+
 __global__ void bias_table_kernel(const float* b, float* table) {
     const int i = threadIdx.x;      // 256 entries: ((4 t + q) * 2 + h) * 4 + j  <->  feature 32 t + 8 q + 4 h + j
     const int j = i & 3, h = (i >> 2) & 1, q = (i >> 3) & 3, t = i >> 5;
@@ -109,7 +122,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(Z, 0xff, (size_t)Ppad * 256 * 4));
     CK(hipDeviceSynchronize());
     Args a;
-    a.n_layers = 1; a.clock_probe = nullptr; a.group = 1 << 20; a.x2_ld = 64; a.Ppad = Ppad; a.mode = 0; a.vec_stride = 0; a.n_vec = 0;
+    a.n_layers = 1; a.clock_probe = nullptr; a.x_scale = a.out_scale = 1.f; a.group = 1 << 20; a.x2_ld = 64; a.Ppad = Ppad; a.mode = 0; a.vec_stride = 0; a.n_vec = 0;
     a.layer[0] = Layer{X, X, 16, 1, Wp, table, Z, mask, nullptr, nullptr};
     // the same layer eight times in ONE launch, every layer into a buffer of its own (what a training pass does)
     float* Zs[8];
@@ -203,6 +216,46 @@ int main(int argc, char** argv) {
         clock_of(layer_split_kernel<kClockProbe | kNoEpilogue>, "clock: no epilogue");
         clock_of(layer_split_kernel<kClockProbe | kNoCut | kNoEpilogue>, "clock: MFMA + W stream, garbage X planes");
         clock_of(layer_split_kernel<kClockProbe | kRandomX | kNoCut | kNoEpilogue>, "clock: MFMA + W stream, random static X planes");
+    }
+    {   // PROTOTYPE: two fp16 planes per operand, three products (see kHalf3); same data, same check against fp64
+        short* Wp16;
+        CK(hipMalloc(&Wp16, (size_t)16 * kSlabShorts * 2));
+        const float sx = 4096.f, sw = 32768.f;
+        hipLaunchKernelGGL(pack_planes_f16_kernel, dim3(16 * 8 * 64 * 8 / 256), dim3(256), 0, 0, W, Wp16, sw);
+        Args h3 = a;
+        h3.layer[0].W = Wp16;
+        h3.x_scale = sx;
+        h3.out_scale = 1.f / (sx * sw);
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kHalf3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+        CK(hipMemset(Z, 0xff, (size_t)Ppad * 256 * 4));
+        hipLaunchKernelGGL((layer_split_kernel<kHalf3>), dim3(G), dim3(256), kLdsBytes, 0, h3);
+        CK(hipDeviceSynchronize()); CK(hipGetLastError());
+        CK(hipMemset(errs, 0, 16));
+        hipLaunchKernelGGL(check_kernel, dim3(4096), dim3(256), 0, 0, X, W, b, Z, P, 1, 7919L, errs, errs + 1);
+        CK(hipMemcpy(h, errs, 16, hipMemcpyDeviceToHost));
+        printf("fp16 x 3 products: 4096 sampled rows x 256 features vs fp64: max |err| = %.3e, max |err| / (|b| + sum |w x|) = %.3e\n", h[0], h[1]);
+        report("fp16 x 3 products, one layer per launch", time_kernel(layer_split_kernel<kHalf3>, h3, G, 40));
+        Args c3 = chain;
+        c3.group = 2; c3.x_scale = sx; c3.out_scale = h3.out_scale;
+        for (int l = 0; l < 8; ++l) c3.layer[l].W = Wp16;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_split_kernel<kHalf3 | kPlainStore>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+        const float ms8 = time_kernel(layer_split_kernel<kHalf3 | kPlainStore>, c3, G, 8);
+        printf("fp16 x 3 products, chained (groups of 2, plain stores) %8.3f ms per layer (8 layers in one launch: %.3f ms)\n", ms8 / 8, ms8);
+        unsigned long long* probe;
+        CK(hipMalloc(&probe, 16 * 256));
+        h3.clock_probe = probe;
+        auto clock_of = [&](auto kern, const char* name) {
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+            const float ms = time_kernel(kern, h3, G, 40);
+            unsigned long long h2[512];
+            CK(hipMemcpy(h2, probe, 16 * G, hipMemcpyDeviceToHost));
+            double cyc = 0, ref = 0;
+            for (int i = 0; i < G; ++i) { cyc += (double)h2[2 * i]; ref += (double)h2[2 * i + 1]; }
+            printf("%-60s %8.3f ms   shader clock %.3f GHz (cycles per workgroup %.0f)\n", name, ms, cyc / ref * 0.1, cyc / G);
+        };
+        clock_of(layer_split_kernel<kHalf3 | kClockProbe>, "clock: fp16 x 3, full kernel");
+        clock_of(layer_split_kernel<kHalf3 | kClockProbe | kNoEpilogue>, "clock: fp16 x 3, no epilogue");
+        fflush(stdout);
     }
     report("layer split x6, no epilogue", time_kernel(layer_split_kernel<kNoEpilogue>, a, G, 40));
     report("layer split x6, no X loads / cuts", time_kernel(layer_split_kernel<kNoCut>, a, G, 40));
