@@ -32,6 +32,17 @@ PEAK_F32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md "Peak FP32 (matr
 PEAK_BF16_MFMA_TFLOPS = 2500.0            # ibid., dense bf16
 # the weight-gradient GEMMs in "split" arithmetic spend 6 bf16 MFMA products per fp32 product
 PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+# ... and 3 fp16 MFMA products (same matrix-pipe rate) where the "half" arithmetic applies
+PEAK_HALF_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
+
+
+def _layer_region_peak(name):
+    """ceiling of a `layer_split_kernel<8 layers[: n on three fp16 products]>` region: the eight layers' time at the
+    matrix pipe's dense rate, n of them at three products per product and 8 - n at six"""
+    import re
+    m = re.search(r": (\d) on three fp16 products", name)
+    n16 = int(m.group(1)) if m else 0
+    return 8.0 / ((8 - n16) / PEAK_SPLIT_TFLOPS + n16 / PEAK_HALF_TFLOPS)
 
 
 def cpu_baseline(n_rays, iters=3):
@@ -111,6 +122,13 @@ def _kernel_table(kern, steps):
             e["peak"] = PEAK_SPLIT_TFLOPS if on_split else PEAK_F32_MFMA_TFLOPS
             e["pipe"] = ("bf16 MFMA x6 (fp32 operands cut into 3 bf16, fp32 accumulate)" +
                          ("; encoding + layer 0 and the heads on the fp32 MFMA" if "layer GEMMs" in k else "")) if on_split else "fp32 MFMA"
+            if k.startswith("layer_split_kernel") and "fp16" in k:
+                e["peak"] = _layer_region_peak(k)
+                e["pipe"] = ("fp16 MFMA x3 (fp32 operands scaled by a power of two per sample / layer and cut into 2 fp16, fp32 "
+                             "accumulate) on the layers named, bf16 MFMA x6 on the others")
+            elif "layer GEMMs" in k and ops.mlp_arithmetic() == "half":
+                e["pipe"] = e["pipe"].replace("bf16 MFMA x6 (fp32 operands cut into 3 bf16, fp32 accumulate)",
+                                              "fp16 MFMA x3 on 6 / 7 of the 8 layer GEMMs, bf16 MFMA x6 on the others")
         out[k] = e
     return out
 
@@ -252,7 +270,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=512)
     ap.add_argument("--camera", action="store_true", help="rays from the learnable camera model also at N = 1")
-    ap.add_argument("--mlp-arithmetic", choices=("split", "fp32"), default=None,
+    ap.add_argument("--mlp-arithmetic", choices=("split", "fp32", "half"), default=None,
                     help="the eight 256-wide layers of the training forward and of the data-gradient chain: per-layer GEMMs on "
                          "the bf16 matrix pipe with exactly cut fp32 operands (default) or inside the fused fp32-MFMA kernels")
     ap.add_argument("--wgrad-arithmetic", choices=("split", "fp32"), default=None,
@@ -327,14 +345,15 @@ def main():
             k = kern[dom]
             ach = k["flop_per_launch"] / (k["avg_ms"] * 1e-3) / 1e12
             split_kernel = dom.startswith("layer_split_kernel")
-            peak = PEAK_SPLIT_TFLOPS if split_kernel else PEAK_F32_MFMA_TFLOPS
+            peak = (_layer_region_peak(dom) if split_kernel else PEAK_F32_MFMA_TFLOPS)
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak,
                     "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                     "avg_launch_ms": k["avg_ms"], "launches_per_step": k["launches"] / a.steps,
                     "flop_per_launch": k["flop_per_launch"]}
             if split_kernel:
-                roof["peak_note"] = ("fp32 products per second; peak = dense bf16 MFMA rate (2500) / 6 partial products per "
-                                     "fp32 product")
+                roof["peak_note"] = ("fp32 products per second; peak = dense bf16 / fp16 MFMA rate (2500) over the partial "
+                                     "products per fp32 product: 6 (three-way bf16 cut) on the layers that run on bf16, 3 "
+                                     "(two-way fp16 cut) on those the kernel name counts -- 416.7 for a pass all on bf16")
                 roof["achieved_over_fp32_mfma_peak"] = ach / PEAK_F32_MFMA_TFLOPS
                 roof["measured"] = ("HIP events around each of the launches of this size inside the timed region: one launch "
                                     "runs the eight 256-wide layers of a pass (forward layers 1-8, or the eight transposed "
@@ -343,6 +362,11 @@ def main():
                                 "2.4 GHz the peak is quoted at (clock read inside the kernel, profiles/r02f_layer_split_lab.txt; "
                                 "counters, profiles/r02f_pmc_kernels.txt; DESIGN.md 4.2b): at the clock it is given the kernel "
                                 "delivers frac x 2.4 / 1.73 of the matrix pipe's rate")
+                if "fp16" in dom:
+                    roof["note"] = ("six (forward) / seven (data gradients) of the eight layers on three fp16 products: half the "
+                                    "matrix-pipe work of the all-bf16 pass -- the launch is bound by its non-MFMA work now "
+                                    "(epilogue 26 %, loads / cuts / scalar work in the slab loop 27 % of the cycles of an fp16 "
+                                    "layer; profiles/r02g_layer_split_lab.txt, DESIGN.md 4.2b)")
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.isfile(pmc):
                 rec = json.load(open(pmc))
@@ -361,7 +385,14 @@ def main():
                     "activations / gradients in registers), 6 of the 9 partial products on v_mfma_f32_32x32x16_bf16, fp32 "
                     "accumulate; per-layer error vs fp64 1.3x the fp32 MFMA's rms (profiles/parity_r02.json "
                     "layer_gemm_arithmetic_*; --mlp-arithmetic fp32 keeps them inside the fused fp32-MFMA kernels)")
-                if ops.mlp_arithmetic() == "split" else "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32 (fused kernels)",
+                if ops.mlp_arithmetic() == "split" else (
+                    "GEMMs over all samples; forward layers 2-4 and 6-8 and the data-gradient layers 7^T .. 1^T: fp32 operands "
+                    "scaled by a power of two (per sample from the maxima the producing layer leaves, per layer for the "
+                    "weights) and cut into 2 fp16 numbers, 3 partial products on v_mfma_f32_32x32x16_f16, fp32 accumulate; "
+                    "layer 1, the skip layer and feature_linear^T: 3 bf16 numbers, 6 products (--mlp-arithmetic split: "
+                    "all of them); per-layer error vs fp64 that of the fp32 MFMA (profiles/parity_r02.json "
+                    "layer_gemm_arithmetic_*)")
+                if ops.mlp_arithmetic() == "half" else "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32 (fused kernels)",
                 "encoding + layer 0, heads, inference forward, narrow weight gradients": "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32",
                 "256x256 weight gradients": (
                     "fp32 operands cut EXACTLY into 3 bf16 numbers each, 6 of the 9 partial products on "

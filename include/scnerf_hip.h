@@ -268,23 +268,30 @@ int scnerf_layer_split_bwd(int pt_dims, int entry, const short* planes, const fl
  * at least two blocks, else layer by layer: forward layers 1 .. 8 over the training workspace `save`, data-gradient
  * entries 0 .. 7 over `grads`.  scnerf_layer_split_workgroups: cap on the persistent workgroups per launch (default
  * 256 = one per CU; values outside 1 .. 1024 only query); returns the cap in force. */
-int scnerf_layer_split_chain_fwd(int pt_dims, const short* planes, const float* wpacked, float* save,
+/* `amax` in the calls below: NULL -- every 256-wide layer on six bf16 products -- or a workspace of
+ * scnerf_layer_amax_floats(n_samples) floats: the layers whose input comes with per-sample maxima (forward 2-4 and
+ * 6-8, data gradients 7^T .. 1^T) then run on THREE fp16 products -- operands cut into two fp16 numbers after scaling
+ * by a power of two per sample / per layer (csrc/layer_split.h) -- and every layer leaves the maxima of what it stores
+ * there.  The fp16 planes and the weight scales follow the bf16 planes in `planes` (scnerf_pack_split_planes writes
+ * both). */
+long long scnerf_layer_amax_floats(long long n_samples);
+int scnerf_layer_split_chain_fwd(int pt_dims, const short* planes, const float* wpacked, float* save, float* amax,
                                  long long n_samples, void* stream);
 int scnerf_layer_split_chain_bwd(int pt_dims, const short* planes, const float* wpacked_bwd, const float* save,
-                                 float* grads, const float* d_raw, long long n_samples, void* stream);
+                                 float* grads, const float* d_raw, float* amax, long long n_samples, void* stream);
 int scnerf_layer_split_workgroups(int n);
 long long scnerf_split_planes_shorts(int pt_dims);
 int scnerf_mlp_bwd_split(int pt_dims, const float* d_raw, const float* pts, const float* viewdirs, int vd_stride,
                          int samples_per_ray, const float* wpacked_bwd, const short* planes, const float* save,
-                         float* grads, float* d_pts, float* d_views, long long n_samples, void* stream);
+                         float* grads, float* d_pts, float* d_views, float* amax, long long n_samples, void* stream);
 int scnerf_mlp_fwd_split(int pt_dims, const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
-                         const float* wpacked, const short* planes, float* raw, float* save, long long n_samples,
-                         void* stream);
+                         const float* wpacked, const short* planes, float* raw, float* save, float* amax,
+                         long long n_samples, void* stream);
 int scnerf_coarse_stage_fwd_split(const float* rays, int ray_stride, const float* t_vals, const float* t_rand,
                                   int lindisp, const float* wpacked, const short* planes, float* save,
                                   const float* noise, int white_bkgd, float* z, float* pts, float* raw,
                                   float* rgb_map, float* disp_map, float* acc_map, float* depth_map, float* weights,
-                                  int n_rays, int n_samples, void* stream);
+                                  float* amax, int n_rays, int n_samples, void* stream);
 int scnerf_pack_split_planes(int pt_dims, const float* flat_params, short* planes, void* stream);
 int scnerf_layer_split(int pt_dims, int layer, const short* planes, const float* bias_table, const float* act_in,
                        const float* epts, float* act_out, unsigned* mask, long long n_samples, void* stream);

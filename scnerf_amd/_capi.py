@@ -68,15 +68,15 @@ PROTOTYPES = {
     "scnerf_vecmat": [P, P, I, LL, I, P, P, P, P],
     "scnerf_wgrad_arithmetic": [I],
     "scnerf_pack_split_planes": [I, P, P, P],
-    "scnerf_mlp_fwd_split": [I, P, P, I, I, P, P, P, P, LL, P],
+    "scnerf_mlp_fwd_split": [I, P, P, I, I, P, P, P, P, P, LL, P],
     "scnerf_mlp_fwd_stage": [I, I, P, P, I, I, P, P, P, LL, P],
     "scnerf_mlp_bwd_stage": [I, I, P, P, P, I, I, P, P, P, P, P, LL, P],
     "scnerf_layer_split_bwd": [I, I, P, P, P, P, P, P, LL, P],
-    "scnerf_layer_split_chain_fwd": [I, P, P, P, LL, P],
-    "scnerf_layer_split_chain_bwd": [I, P, P, P, P, P, LL, P],
+    "scnerf_layer_split_chain_fwd": [I, P, P, P, P, LL, P],
+    "scnerf_layer_split_chain_bwd": [I, P, P, P, P, P, P, LL, P],
     "scnerf_layer_split_workgroups": [I],
-    "scnerf_mlp_bwd_split": [I, P, P, P, I, I, P, P, P, P, P, P, LL, P],
-    "scnerf_coarse_stage_fwd_split": [P, I, P, P, I, P, P, P, P, I, P, P, P, P, P, P, P, P, I, I, P],
+    "scnerf_mlp_bwd_split": [I, P, P, P, I, I, P, P, P, P, P, P, P, LL, P],
+    "scnerf_coarse_stage_fwd_split": [P, I, P, P, I, P, P, P, P, I, P, P, P, P, P, P, P, P, P, I, I, P],
     "scnerf_layer_split": [I, I, P, P, P, P, P, P, LL, P],
 }
 
@@ -86,6 +86,7 @@ SIZE_FUNCS = {"scnerf_mlp_save_floats": [I, LL], "scnerf_mlp_grad_floats": [LL],
               "scnerf_wgrad_workspace_floats": [I, I, I],
               "scnerf_nerf_wgrad_workspace_floats": [I],
               "scnerf_split_planes_shorts": [I],
+              "scnerf_layer_amax_floats": [LL],
               "scnerf_camera_bwd_workspace_floats": [I]}
 
 

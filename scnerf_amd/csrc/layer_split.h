@@ -5,6 +5,12 @@
 // product is the fp32 sum of six bf16 x bf16 partial products -- (Wh Xh)(Wh Xm)(Wh Xl)(Wm Xh)(Wm Xm)(Wl Xh).
 // The weights are cut ONCE per optimizer step by the packing pass; only the activations are cut here.
 //
+// kHalf3 instantiations: the same kernel on THREE products per product -- every operand scaled by a power of two and
+// cut into two fp16 numbers, (Wh Xh)(Wh Xl)(Wl Xh) on v_mfma_f32_32x32x16_f16; scales per sample (activations,
+// gradients: a sample is a column of the transposed product, so the scale comes back out lane-wise in the epilogue)
+// and per layer (weights); see Layer::amax_in / amax_out.  Error against fp64 as for the six bf16 products (the dropped
+// terms are 2^-22 of the product in both), half the MFMA work: 0.355-0.38 ms per layer against 0.48-0.51.
+//
 // Shape.  The product is computed transposed, D[feature][sample], so an accumulator tile is the tile-native
 // piece layout of mlp_common.h (lane (m, h) owns features 32 t + 8 q + 4 h + j of sample m: one 16-byte store
 // per (t, q)).  A workgroup = 2 x 2 waves; wave (wn, wp) owns features 128 wn .. +127 of samples 128 wp .. +127 of a
@@ -68,7 +74,9 @@ constexpr int kThreads = 256;
 constexpr int kSlabs = 16;                          // K = 256 in slabs of 16
 constexpr int kSlabUnits = 3 * 8 * 64;              // 16-byte fragments of one slab image
 constexpr int kSlabShorts = kSlabUnits * 8;
-constexpr unsigned kLdsBytes = 2u * kSlabUnits * 16u + 1024u;  // two slab images + the bias table
+constexpr int kAmaxSlots = 3;                       // blocks of a group whose maxima go from layer to layer through LDS
+// two slab images + the bias table + the per-sample maxima of the group's blocks [slot][feature half][256 samples]
+constexpr unsigned kLdsBytes = 2u * kSlabUnits * 16u + 1024u + kAmaxSlots * 2u * 256u * 4u;
 
 struct Layer {
     const float* X;        // tile-native, width 256: K slabs 0 .. 15
@@ -81,6 +89,14 @@ struct Layer {
     unsigned* mask;        // ReLU bits [wave tile][64 lanes][4 words] or nullptr (mode 0)
     const unsigned* mask_in;   // mode 1: the gate, [wave tile][64 lanes][4 words]
     const float* vec;          // mode 1: per-sample scalar of the rank-1 term, element p * vec_stride (p < n_vec), or nullptr
+    // Two-way fp16 cut (kHalf3 instantiations).  fp16 has five exponent bits: every operand carries a power-of-two
+    // scale.  A sample is a COLUMN of the transposed product, so activations / gradients are scaled per sample:
+    // the producing layer's epilogue leaves the maximum |value| of each sample over either half of the features
+    // (amax_out, [2][Ppad]), the consumer derives 2^k from the two halves (amax_in) while cutting and divides it out
+    // again, lane-wise, in its own epilogue; the weights carry one scale per layer from the packing pass.
+    const float* amax_in;      // kHalf3: [2][Ppad] maxima of X (nullptr: Args::x_scale for every sample -- the lab)
+    float* amax_out;           // any instantiation: [2][Ppad] maxima of Z, or nullptr
+    const float* w_inv_scale;  // kHalf3: 1 / (the power of two the packer multiplied this layer's weights by)
 };
 // A chain of layers in ONE launch: layer l + 1 of a 256-sample block reads what layer l wrote for the SAME block, and
 // a workgroup keeps its blocks from layer to layer, so there is no dependency between workgroups -- the software
@@ -117,8 +133,9 @@ enum : int {
     kXfromW = 1024,       // timing experiment: the activation loads fetch pieces of the weight slab instead (wrong results)
     kRandomX = 2048,      // timing experiment (with kNoCut): the activation planes hold pseudo-random bits instead of garbage
     kClockProbe = 4096,   // lab: every workgroup writes its shader-cycle and reference-tick counts to Args::clock_probe
-    kHalf3 = 8192,        // lab prototype: TWO fp16 planes per operand and three products (Wh Xh)(Wh Xl)(Wl Xh); the
-                          // operands scaled by the powers of two in Args::x_scale / the packer, the result by out_scale
+    kHalf3 = 8192,        // TWO fp16 planes per operand and three products (Wh Xh)(Wh Xl)(Wl Xh); the operands scaled by
+                          // powers of two (Layer::amax_in / w_inv_scale; in the lab Args::x_scale / out_scale)
+    kAmaxOut = 16384,     // the epilogue also leaves the per-sample maxima of what it stores (Layer::amax_out)
     kNoDupX = 256,        // timing experiment: the two waves that share samples load DIFFERENT tiles (wrong results)
     kNoBarrier = 64,      // timing experiment: no workgroup barriers in the slab loop (racy: results are wrong)
     kPlainStore = 4,      // default-policy stores instead of non-temporal ones: what a chain in groups of 2 blocks uses
@@ -132,6 +149,7 @@ template <int FLAGS>
 __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
     short* lds = dynamic_lds<short>();
     float* const lds_bias = reinterpret_cast<float*>(lds + 2 * kSlabShorts);
+    float* const lds_amax = lds_bias + 256;
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const int wn = wave >> 1, wp = wave & 1;
     const int m = lane & 31, g = lane >> 5;
@@ -207,12 +225,12 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
     s16x8 xp[2][3];
     unsigned cu[8], c1[8], c2[8];
     // step 0..7: element e (and / sub / and / sub); 8, 9, 10: pack plane h, m, l (4 v_perm each)
-    auto cut_step = [&](auto set_tag, auto j_tag, auto dst_tag, auto step_tag) {
+    auto cut_step = [&](auto set_tag, auto j_tag, auto dst_tag, auto step_tag, float x_scale) {
         constexpr int SET = decltype(set_tag)::value, j = decltype(j_tag)::value, D = decltype(dst_tag)::value,
                       STEP = decltype(step_tag)::value;
         if constexpr (FLAGS & kHalf3) {
             if constexpr (STEP < 8) {
-                const float x = raw[SET][j][STEP >> 2][STEP & 3] * a.x_scale;
+                const float x = raw[SET][j][STEP >> 2][STEP & 3] * x_scale;
                 cu[STEP] = f16_bits(x);
                 c1[STEP] = f16_bits(x - f16_value(cu[STEP]));          // (the difference is exact)
             } else if constexpr (STEP < 10) {
@@ -246,6 +264,42 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
                 if constexpr (STEP == 8) xp[D][0] = pack(cu);
                 else if constexpr (STEP == 9) xp[D][1] = pack(c1);
                 else xp[D][2] = pack(c2);
+            }
+        }
+    };
+
+    // ---- per-sample scales (kHalf3): xs[j] for the block in work, xn[j] for its successor (fetched a block ahead)
+    float xs[4] = {1.f, 1.f, 1.f, 1.f}, xn[4] = {1.f, 1.f, 1.f, 1.f};
+    // 2^k with |x| 2^k < 2^13 for every |x| <= max(a0, a1): exponent field e of the maximum -> (266 - e) << 23;
+    // maxima below 2^-115 (zero, denormals) take the largest scale: nothing to represent there
+    auto scale_from = [&](float a0, float a1) {
+        const unsigned e = (__float_as_uint(fmaxf(a0, a1)) >> 23) & 0xffu;
+        return __uint_as_float((266u - (e < 13u ? 13u : e)) << 23);
+    };
+    // The maxima of a block that an EARLIER layer of this launch stored (l > 0) are taken from LDS (slot = the block's
+    // place in its group; the producing epilogue is at least a block, i.e. many barriers, back): through memory they
+    // would sit behind that epilogue's 256 KB of stores with nothing to order them against this read.  Layer 0 of a
+    // launch reads what an earlier launch left in memory.  (Groups longer than kAmaxSlots: memory, three blocks later.)
+    auto fetch_scales = [&](float (&dst)[4], int l, int b, int slot) {
+        if constexpr (FLAGS & kHalf3) {
+            const Layer& L = a.layer[l < n_layers ? l : n_layers - 1];
+            const long blk = blockIdx.x + (long)(b < my_blocks ? b : my_blocks - 1) * gridDim.x;
+            long t0 = blk * 8 + wp_u * 4;
+            if (t0 >= n_tiles) t0 = n_tiles - 4;
+            if (L.amax_in && l > 0 && slot >= 0) {
+                const float* t = lds_amax + slot * 512 + wp_u * 128 + (pinned_here((unsigned)lane) & 31u);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[j] = scale_from(t[j * 32], t[256 + j * 32]);
+            } else if (L.amax_in) {
+                const global_bytes base = uniform_global(L.amax_in + t0 * 32);
+                const unsigned off = (pinned_here((unsigned)lane) & 31u) * 4u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    dst[j] = scale_from(load_at<float>(base, off + j * 128u),
+                                        load_at<float>(base + a.Ppad * 4, off + j * 128u));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[j] = a.x_scale;
             }
         }
     };
@@ -345,8 +399,9 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
                 constexpr int j = decltype(j_tag)::value, S = decltype(slot_tag)::value;
                 if constexpr (FLAGS & kHalf3) {         // 12 slots per sample tile: the same fillers, twice as dense
                     if constexpr (S <= 9) {
-                        if constexpr (j < 3) cut_step(Set{}, I<j + 1>{}, I<(j + 1) & 1>{}, I<S>{});
-                        else cut_step(Other{}, I<0>{}, I<0>{}, I<S>{});
+                        // (the next slab's first fragment: in the block's last slab it belongs to the successor block)
+                        if constexpr (j < 3) cut_step(Set{}, I<j + 1>{}, I<(j + 1) & 1>{}, I<S>{}, xs[j + 1]);
+                        else cut_step(Other{}, I<0>{}, I<0>{}, I<S>{}, s + 1 >= n_k ? xn[0] : xs[0]);
                     }
                     if constexpr (S == 3) load_x(Set{}, A, I<j>{}, I<0>{});
                     if constexpr (S == 9) load_x(Set{}, A, I<j>{}, I<1>{});
@@ -358,8 +413,8 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
                     if constexpr (j == 3 && S >= 8) read_w(BUF ^ 1, I<0>{}, I<S - 8>{});
                 } else {
                 if constexpr (S <= 10) {
-                    if constexpr (j < 3) cut_step(Set{}, I<j + 1>{}, I<(j + 1) & 1>{}, I<S>{});
-                    else cut_step(Other{}, I<0>{}, I<0>{}, I<S>{});
+                    if constexpr (j < 3) cut_step(Set{}, I<j + 1>{}, I<(j + 1) & 1>{}, I<S>{}, 1.f);
+                    else cut_step(Other{}, I<0>{}, I<0>{}, I<S>{}, 1.f);
                 }
                 if constexpr (S == 6) load_x(Set{}, A, I<j>{}, I<0>{});
                 if constexpr (S == 18) load_x(Set{}, A, I<j>{}, I<1>{});
@@ -391,7 +446,7 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
     // 32-bit lane offset recomputed here: as 64-bit per-lane pointers their lane-invariant parts were hoisted out of
     // the block loop and spilled, and a scratch reload between the stores waits for all of them.  The fence keeps the
     // accumulator reads piece by piece: hoisted, they spill.
-    auto epilogue = [&](int l, int b) {
+    auto epilogue = [&](int l, int b, int slot) {
         const Layer& L = a.layer[l];
         const long blk = blockIdx.x + (long)b * gridDim.x;
         const long tile0 = blk * 8 + wp_u * 4;      // Ppad is a multiple of 128: a wave's four tiles are in range together
@@ -406,11 +461,32 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
             f(I<8>{}); f(I<9>{}); f(I<10>{}); f(I<11>{}); f(I<12>{}); f(I<13>{}); f(I<14>{}); f(I<15>{});
         };
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        // kHalf3: what the accumulators are multiplied by, per sample: 1 / (sample scale x weight scale), powers of two
+        float os[4] = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (FLAGS & kHalf3) {
+            const float w_inv = L.w_inv_scale ? *L.w_inv_scale : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                os[j] = L.w_inv_scale ? __uint_as_float(0x7f000000u - __float_as_uint(xs[j])) * w_inv : a.out_scale;
+        }
+        // kAmaxOut: max |stored value| per sample over this wave's 128 features -> amax_out[wn][sample]
+        auto store_amax = [&](int j, float hm) {
+            if constexpr (FLAGS & kAmaxOut) {
+                if (L.amax_out) {
+                    const float both = fmaxf(hm, shfl_xor(hm, 32));
+                    if (lane_here < 32u) {
+                        store_at(uniform_global_rw(L.amax_out + wn_u * a.Ppad + (tile0 + j) * 32), lane_here * 4u, both);
+                        if (slot >= 0) lds_amax[slot * 512 + wn_u * 256 + wp_u * 128 + j * 32 + lane_here] = both;
+                    }
+                }
+            }
+        };
         if (a.mode == 0) {
             const float lo = L.relu ? 0.f : -__builtin_huge_valf();
             auto tile_pair = [&](auto j0_tag) {
             constexpr int J0 = decltype(j0_tag)::value;
             unsigned hb[4] = {0u, 0u, 0u, 0u}, bits[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+            float hm[4] = {0.f, 0.f, 0.f, 0.f};
             f32x4 b_next = *reinterpret_cast<const f32x4*>(table);
             pieces([&](auto idx_tag) {
                 constexpr int IDX = decltype(idx_tag)::value, i = IDX >> 2, q = IDX & 3;
@@ -422,9 +498,10 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if constexpr (FLAGS & kHalf3) v[e] = max_raw(fmaf(acc[i][j][4 * q + e], a.out_scale, bc[e]), lo);
+                        if constexpr (FLAGS & kHalf3) v[e] = max_raw(fmaf(acc[i][j][4 * q + e], os[j], bc[e]), lo);
                         else v[e] = max_raw(add_raw(acc[i][j][4 * q + e], bc[e]), lo);
                         hb[j] = shift_in_positive(hb[j], v[e]);
+                        if constexpr (FLAGS & kAmaxOut) hm[j] = fmaxf(hm[j], fabsf(v[e]));
                     }
                     const unsigned dst = zoff + (unsigned)IDX * 1024u;
                     if constexpr (FLAGS & kNoZStore) { (void)dst; }
@@ -444,6 +521,8 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
                 for (int j = J0; j < J0 + 2; ++j)
                     store_at(uniform_global_rw(L.mask + (tile0 + j) * 256 + 2 * wn_u), zoff, u32x2{bits[j][0], bits[j][1]});
             }
+#pragma unroll
+            for (int j = J0; j < J0 + 2; ++j) store_amax(j, hm[j]);
             };
             tile_pair(I<0>{});       // (two tiles at a time: all four hold 16 accumulator values + their results per
             tile_pair(I<2>{});       //  piece next to the loop's prefetched operands -- the allocator spills 32 registers)
@@ -465,6 +544,7 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
                         : 0.f;
         }
         // RANK1: the density head's term (feature_linear^T only); the other seven layers skip the FMA and the table
+        float hm[4] = {0.f, 0.f, 0.f, 0.f};
         auto all_pieces = [&](auto rank1_tag) {
             constexpr bool RANK1 = decltype(rank1_tag)::value;
             f32x4 b_next = {0.f, 0.f, 0.f, 0.f};
@@ -478,18 +558,25 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
 #pragma unroll
                 for (int j = J0; j < J0 + 2; ++j) {
                     const unsigned word = gate[j][i >> 1];
-                    auto val = [&](int e) { return RANK1 ? fmaf(bc[e], vs[j], acc[i][j][4 * q + e]) : acc[i][j][4 * q + e]; };
+                    auto val = [&](int e) {
+                        const float d = (FLAGS & kHalf3) ? acc[i][j][4 * q + e] * os[j] : acc[i][j][4 * q + e];
+                        return RANK1 ? fmaf(bc[e], vs[j], d) : d;
+                    };
                     f32x4 v;
                     v[0] = keep_if_bit<bit0 - 0>(val(0), word);
                     v[1] = keep_if_bit<bit0 - 1>(val(1), word);
                     v[2] = keep_if_bit<bit0 - 2>(val(2), word);
                     v[3] = keep_if_bit<bit0 - 3>(val(3), word);
+                    if constexpr (FLAGS & kAmaxOut)
+                        hm[j] = fmaxf(fmaxf(hm[j], fabsf(v[0])), fmaxf(fmaxf(fabsf(v[1]), fabsf(v[2])), fabsf(v[3])));
                     if constexpr (FLAGS & kPlainStore) store_at(z0 + j * 32768, zoff + (unsigned)IDX * 1024u, v);
                     else store_stream_at(z0 + j * 32768, zoff + (unsigned)IDX * 1024u, v);
                 }
             });
         };
         if (L.vec) all_pieces(std::true_type{}); else all_pieces(std::false_type{});
+#pragma unroll
+        for (int j = J0; j < J0 + 2; ++j) store_amax(j, hm[j]);
         };
         tile_pair_bwd(I<0>{});
         tile_pair_bwd(I<2>{});
@@ -515,7 +602,8 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
     read_w(0, I<0>{}, I<0>{}); read_w(0, I<0>{}, I<1>{}); read_w(0, I<0>{}, I<2>{}); read_w(0, I<0>{}, I<3>{});
     read_w(0, I<1>{}, I<0>{}); read_w(0, I<1>{}, I<1>{}); read_w(0, I<1>{}, I<2>{}); read_w(0, I<1>{}, I<3>{});
     {
-        auto whole = [&](auto s) { cut_step(I<0>{}, I<0>{}, I<0>{}, s); };
+        fetch_scales(xs, 0, 0, -1);
+        auto whole = [&](auto s) { cut_step(I<0>{}, I<0>{}, I<0>{}, s, xs[0]); };
         whole(I<0>{}); whole(I<1>{}); whole(I<2>{}); whole(I<3>{}); whole(I<4>{}); whole(I<5>{}); whole(I<6>{});
         whole(I<7>{}); whole(I<8>{}); whole(I<9>{}); whole(I<10>{});
     }
@@ -544,16 +632,22 @@ __global__ __launch_bounds__(kThreads, 1) void layer_split_kernel(Args a) {
             first_table = false;
             for (int b = b0; b < b1; ++b) {
                 slab(I<0>{}, std::true_type{}, cur, nxt, last_layer, n_k, b0, b1, b, 0);
+                // (kHalf3) the successor block's scales, most of a block ahead of their first use -- and behind slab 0's
+                // barrier: the epilogue that has just run may be the one that left them in LDS
+                const bool slots = b1 - b0 <= kAmaxSlots;
+                fetch_scales(xn, b + 1 < b1 ? l : last_layer ? 0 : l + 1, b + 1 < b1 ? b + 1 : last_layer ? b1 : b0,
+                             !slots ? -1 : b + 1 < b1 ? b + 1 - b0 : 0);
                 slab(I<1>{}, std::false_type{}, cur, nxt, last_layer, n_k, b0, b1, b, 1);
                 for (int s = 2; s < n_k; s += 2) {
                     slab(I<0>{}, std::false_type{}, cur, nxt, last_layer, n_k, b0, b1, b, s);
                     slab(I<1>{}, std::false_type{}, cur, nxt, last_layer, n_k, b0, b1, b, s + 1);
                 }
-                if constexpr (!(FLAGS & kNoEpilogue)) epilogue(l, b);
+                if constexpr (!(FLAGS & kNoEpilogue)) epilogue(l, b, b1 - b0 <= kAmaxSlots ? b - b0 : -1);
+                if constexpr (FLAGS & kHalf3) { xs[0] = xn[0]; xs[1] = xn[1]; xs[2] = xn[2]; xs[3] = xn[3]; }
             }
         }
     }
-    if constexpr (FLAGS & kNoEpilogue) epilogue(n_layers - 1, my_blocks - 1);
+    if constexpr (FLAGS & kNoEpilogue) epilogue(n_layers - 1, my_blocks - 1, -1);
     if constexpr (FLAGS & kClockProbe) {
         if (tid == 0) {
             a.clock_probe[2 * blockIdx.x] = shader_cycles() - probe_c;

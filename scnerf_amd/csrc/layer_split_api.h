@@ -22,11 +22,13 @@ int launch_network_layer_bwd(int entry, const short* planes, const float* alpha_
 
 // layers 1 .. 8 of the training forward over the workspace `save` / entries 0 .. 7 of the data-gradient chain over
 // `grads`, as ONE launch when every workgroup owns at least two 256-sample blocks (else layer by layer)
+// amax: nullptr (all layers on six bf16 products), or the workspace of scnerf_layer_amax_floats: the layers fed with
+// per-sample maxima then run on three fp16 products (layer_split.h)
 template <int PD>
-int launch_network_chain_fwd(const short* planes, const float* wpacked, float* save, long P, hipStream_t stream);
+int launch_network_chain_fwd(const short* planes, const float* wpacked, float* save, float* amax, long P, hipStream_t stream);
 template <int PD>
 int launch_network_chain_bwd(const short* planes, const float* wpacked_bwd, const float* save, float* grads,
-                             const float* d_raw, long P, hipStream_t stream);
+                             const float* d_raw, float* amax, long P, hipStream_t stream);
 
 }  // namespace lsp
 }  // namespace scn

@@ -261,11 +261,11 @@ static int launch_bwd(const float* d_raw, const float* pts, const float* viewdir
 template <int PD>
 static int bwd_split(const float* d_raw, const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
                      const float* wpacked_bwd, const short* planes, const float* save, float* grads, float* d_pts,
-                     float* d_views, long long n_samples, hipStream_t st) {
+                     float* d_views, float* amax, long long n_samples, hipStream_t st) {
     const long P = (long)n_samples;
     int rc = launch_bwd<PD, 1>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st);
     if (rc) return rc;
-    rc = scn::lsp::launch_network_chain_bwd<PD>(planes, wpacked_bwd, save, grads, d_raw, P, st);
+    rc = scn::lsp::launch_network_chain_bwd<PD>(planes, wpacked_bwd, save, grads, d_raw, amax, P, st);
     if (rc) return rc;
     return launch_bwd<PD, 2>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st);
 }
@@ -300,12 +300,12 @@ extern "C" int scnerf_mlp_bwd_stage(int pt_dims, int stage, const float* d_raw, 
 
 extern "C" int scnerf_mlp_bwd_split(int pt_dims, const float* d_raw, const float* pts, const float* viewdirs,
                                     int vd_stride, int samples_per_ray, const float* wpacked_bwd, const short* planes,
-                                    const float* save, float* grads, float* d_pts, float* d_views, long long n_samples,
-                                    void* stream) {
+                                    const float* save, float* grads, float* d_pts, float* d_views, float* amax,
+                                    long long n_samples, void* stream) {
     SCN_RETURN_IF(!d_raw || !pts || !viewdirs || !wpacked_bwd || !planes || !save || !grads || !d_pts || !d_views, SCN_EINVAL);
     SCN_RETURN_IF(samples_per_ray < 1 || vd_stride < 3 || n_samples < 0 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
     if (n_samples == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    return pt_dims == 3 ? bwd_split<3>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, planes, save, grads, d_pts, d_views, n_samples, st)
-                        : bwd_split<4>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, planes, save, grads, d_pts, d_views, n_samples, st);
+    return pt_dims == 3 ? bwd_split<3>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, planes, save, grads, d_pts, d_views, amax, n_samples, st)
+                        : bwd_split<4>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, planes, save, grads, d_pts, d_views, amax, n_samples, st);
 }

@@ -351,16 +351,16 @@ static int launch_coarse_stage(const CoarseStage& cs, const float* wpacked, floa
 
 // layers 1 .. 7 and feature_linear as split-arithmetic GEMMs between the two stages of the fused kernel
 template <int PD>
-static int trunk_layers_split(const float* wpacked, const short* planes, float* save, long P, hipStream_t st) {
-    return scn::lsp::launch_network_chain_fwd<PD>(planes, wpacked, save, P, st);
+static int trunk_layers_split(const float* wpacked, const short* planes, float* save, float* amax, long P, hipStream_t st) {
+    return scn::lsp::launch_network_chain_fwd<PD>(planes, wpacked, save, amax, P, st);
 }
 
 template <int PD>
 static int fwd_split(const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray, const float* wpacked,
-                     const short* planes, float* raw, float* save, long long n_samples, hipStream_t st) {
+                     const short* planes, float* raw, float* save, float* amax, long long n_samples, hipStream_t st) {
     int rc = launch_fwd<PD, true, 1>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, n_samples, st);
     if (rc) return rc;
-    rc = trunk_layers_split<PD>(wpacked, planes, save, (long)n_samples, st);
+    rc = trunk_layers_split<PD>(wpacked, planes, save, amax, (long)n_samples, st);
     if (rc) return rc;
     return launch_fwd<PD, true, 2>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, n_samples, st);
 }
@@ -384,7 +384,7 @@ extern "C" int scnerf_coarse_stage_fwd_split(const float* rays, int ray_stride, 
                                              int lindisp, const float* wpacked, const short* planes, float* save,
                                              const float* noise, int white_bkgd, float* z, float* pts, float* raw,
                                              float* rgb_map, float* disp_map, float* acc_map, float* depth_map,
-                                             float* weights, int n_rays, int n_samples, void* stream) {
+                                             float* weights, float* amax, int n_rays, int n_samples, void* stream) {
     SCN_RETURN_IF(!rays || !t_vals || !wpacked || !planes || !save || !z || !pts || !raw || !rgb_map || !disp_map || !acc_map, SCN_EINVAL);
     SCN_RETURN_IF(n_rays < 0 || ray_stride < 11, SCN_EINVAL);
     SCN_RETURN_IF(n_samples != kCoarseSamples, SCN_ENOSUP);
@@ -394,7 +394,7 @@ extern "C" int scnerf_coarse_stage_fwd_split(const float* rays, int ray_stride, 
     hipStream_t st = (hipStream_t)stream;
     int rc = launch_coarse_stage<true, 1>(cs, wpacked, raw, save, st);
     if (rc) return rc;
-    rc = trunk_layers_split<3>(wpacked, planes, save, (long)n_rays * kCoarseSamples, st);
+    rc = trunk_layers_split<3>(wpacked, planes, save, amax, (long)n_rays * kCoarseSamples, st);
     if (rc) return rc;
     return launch_coarse_stage<true, 2>(cs, wpacked, raw, save, st);
 }
@@ -417,13 +417,13 @@ extern "C" int scnerf_mlp_fwd_stage(int pt_dims, int stage, const float* pts, co
 
 extern "C" int scnerf_mlp_fwd_split(int pt_dims, const float* pts, const float* viewdirs, int vd_stride,
                                     int samples_per_ray, const float* wpacked, const short* planes, float* raw,
-                                    float* save, long long n_samples, void* stream) {
+                                    float* save, float* amax, long long n_samples, void* stream) {
     SCN_RETURN_IF(!pts || !viewdirs || !wpacked || !planes || !raw || !save, SCN_EINVAL);
     SCN_RETURN_IF(samples_per_ray < 1 || vd_stride < 3 || n_samples < 0 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
     if (n_samples == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    return pt_dims == 3 ? fwd_split<3>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, planes, raw, save, n_samples, st)
-                        : fwd_split<4>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, planes, raw, save, n_samples, st);
+    return pt_dims == 3 ? fwd_split<3>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, planes, raw, save, amax, n_samples, st)
+                        : fwd_split<4>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, planes, raw, save, amax, n_samples, st);
 }
 
 extern "C" int scnerf_mlp_fwd(int pt_dims, const float* pts, const float* viewdirs, int vd_stride,

@@ -71,7 +71,7 @@ class RenderRaysFunction(torch.autograd.Function):
         wf_c = ops.pack_weights(flat_c, "fwd")
         save_c = ops.save_workspace(n * sc, dev) if train else None
         # training forward with the 256-wide layers as split-arithmetic GEMMs (ops.mlp_arithmetic)
-        split = train and n > 0 and ops.mlp_arithmetic() == "split"
+        split = train and n > 0 and ops.mlp_arithmetic() in ("split", "half")
         pl_c = ops.pack_planes(flat_c) if split else None
         if sc == ops.COARSE_STAGE_SAMPLES and n > 0:
             # the whole coarse stage -- stratified depths, network, compositing -- is one launch

@@ -65,7 +65,7 @@ class _NerfNetFunction(torch.autograd.Function):
         save_f = ops.save_workspace(n * sf, dev, 3) if train else None
         save_b = ops.save_workspace(n * sb, dev, 4) if train else None
         # training: the 256-wide layers as split-arithmetic GEMMs (ops.mlp_arithmetic), as in the SCNeRF step
-        split = train and n > 0 and ops.mlp_arithmetic() == "split"
+        split = train and n > 0 and ops.mlp_arithmetic() in ("split", "half")
         pl_f = ops.pack_planes(flat_f, 3, remap=fg_net.pack_remap()) if split else None
         pl_b = ops.pack_planes(flat_b, 4, remap=bg_net.pack_remap()) if split else None
         raw_f = ops.mlp_fwd(fg_pts, views, sf, ops.pack_weights(flat_f, "fwd", pd=3, remap=fg_net.pack_remap()),

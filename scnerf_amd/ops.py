@@ -194,23 +194,36 @@ def pack_weights(flat_params: Tensor, kind: str = "fwd", out: Optional[Tensor] =
     return out
 
 
-_MLP_ARITHMETIC = [os.environ.get("SCNERF_MLP_ARITHMETIC", "split")]
+_MLP_ARITHMETIC = [os.environ.get("SCNERF_MLP_ARITHMETIC", "half")]
 
 
 def mlp_arithmetic(mode: Optional[str] = None) -> str:
     """How the TRAINING forward and the data-gradient chain run the eight 256-wide layers (trunk 1 .. 7,
-    feature_linear): "fp32" -- inside the fused kernels on the exact-fp32 MFMA; "split" -- as per-layer GEMMs on the
-    bf16 matrix pipe with exactly cut fp32 operands (csrc/layer_split.h), between the fused kernels' end stages
-    (encoding + layer 0 / heads; heads / encoded-point end).
+    feature_linear): "fp32" -- inside the fused kernels on the exact-fp32 MFMA; "split" -- as GEMMs over all samples
+    on the bf16 matrix pipe with exactly cut fp32 operands, six products per product (csrc/layer_split.h), between the
+    fused kernels' end stages (encoding + layer 0 / heads; heads / encoded-point end); "half" -- the same, with the
+    layers whose input comes with per-sample maxima (forward 2-4 and 6-8, data gradients 7^T .. 1^T) on THREE fp16
+    products: operands scaled by a power of two per sample / per layer and cut into two fp16 numbers.
     Without an argument: the mode in force.  Environment preset: SCNERF_MLP_ARITHMETIC."""
     if mode is not None:
-        if mode not in ("fp32", "split"):
-            raise ValueError("mlp_arithmetic is 'fp32' or 'split'")
+        if mode not in ("fp32", "split", "half"):
+            raise ValueError("mlp_arithmetic is 'fp32', 'split' or 'half'")
         _MLP_ARITHMETIC[0] = mode
     return _MLP_ARITHMETIC[0]
 
 
 _canon_cache = {}
+_amax_cache = {}
+
+
+def _amax(P: int, device) -> Optional[Tensor]:
+    """the per-sample maxima workspace of the "half" arithmetic (None in the other modes)"""
+    if _MLP_ARITHMETIC[0] != "half":
+        return None
+    key = (int(P), str(device))
+    if key not in _amax_cache:
+        _amax_cache[key] = torch.empty(_capi.load().scnerf_layer_amax_floats(int(P)), dtype=torch.float32, device=device)
+    return _amax_cache[key]
 
 
 def pack_planes(flat_params: Tensor, pd: int = 3, out: Optional[Tensor] = None, remap=None) -> Tensor:
@@ -251,6 +264,12 @@ def _vd(viewdirs: Tensor):
 _MAC_PER_SAMPLE = {3: 593408, 4: 593408 + 2 * 256 * 21}       # layer 0 and the skip layer are 21 columns wider
 
 
+def _half_note(n: int) -> str:
+    """suffix of the layer GEMMs' timing region in the "half" arithmetic: how many of the eight run on three fp16
+    products (forward: layers 2-4 and 6-8; data gradients: 7^T .. 1^T)"""
+    return ": %d on three fp16 products" % n if _MLP_ARITHMETIC[0] == "half" else ""
+
+
 def _layer_flop(pd: int, layer: int, P: int) -> int:
     return 2 * 256 * (256 + (ML.layout(pd).in_pts if layer == 5 else 0)) * P
 
@@ -266,9 +285,10 @@ def _fwd_split_piecewise(pd, P, tag, wpacked, planes, save, stage_call):
     with PROFILE.region("mlp_fwd_kernel<stage 1: encoding + layer 0>%s/P=%d" % (tag, P), 2 * 256 * lay.in_pts * P):
         _capi.check(stage_call(1), "forward stage 1")
     # (layers 1 .. 8 go out as one launch -- a chain -- when every persistent workgroup owns two blocks or more)
-    with PROFILE.region("layer_split_kernel<8 layers>%s/P=%d" % (tag, P), sum(_layer_flop(pd, l, P) for l in range(1, 9))):
-        _capi.check(lib.scnerf_layer_split_chain_fwd(pd, _p(planes), _p(wpacked), _p(save), P, _stream()),
-                    "scnerf_layer_split_chain_fwd")
+    with PROFILE.region("layer_split_kernel<8 layers%s>%s/P=%d" % (_half_note(6), tag, P),
+                        sum(_layer_flop(pd, l, P) for l in range(1, 9))):
+        _capi.check(lib.scnerf_layer_split_chain_fwd(pd, _p(planes), _p(wpacked), _p(save), _p(_amax(P, save.device)), P,
+                                                     _stream()), "scnerf_layer_split_chain_fwd")
     with PROFILE.region("mlp_fwd_kernel<stage 2: heads>%s/P=%d" % (tag, P), 2 * (128 * 283 + 3 * 128 + 256) * P):
         _capi.check(stage_call(2), "forward stage 2")
 
@@ -302,7 +322,7 @@ def mlp_fwd(pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked: Tensor
                 st = 0
             else:
                 st = _capi.load().scnerf_mlp_fwd_split(pd, _p(pts), vptr, vstride, int(samples_per_ray), _p(wpacked),
-                                                       _p(planes), _p(raw), _p(save), P, _stream())
+                                                       _p(planes), _p(raw), _p(save), _p(_amax(P, save.device)), P, _stream())
         _capi.check(st, "scnerf_mlp_fwd_split")
         return raw
     with PROFILE.region("mlp_fwd_kernel%s/P=%d/%s" % (tag, P, "train" if save is not None else "infer"),
@@ -351,7 +371,7 @@ def coarse_stage_fwd(rays: Tensor, t_vals: Tensor, t_rand: Optional[Tensor], lin
             st = _capi.load().scnerf_coarse_stage_fwd_split(
                 _p(rays), rays.shape[1], _p(t_vals), _p(t_rand), int(bool(lindisp)), _p(wpacked), _p(planes), _p(save),
                 _p(noise), int(bool(white_bkgd)), _p(z), _p(pts), _p(raw), _p(rgb), _p(disp), _p(acc), _p(depth), _p(w),
-                n, s, _stream())
+                _p(_amax(P, save.device)), n, s, _stream())
         _capi.check(st, "scnerf_coarse_stage_fwd_split")
         return z, pts, raw, rgb, disp, acc, w, depth
     with PROFILE.region("mlp_fwd_kernel/P=%d/%s" % (P, "train" if save is not None else "infer"), 2 * _MAC_PER_SAMPLE[3] * P):
@@ -378,9 +398,9 @@ def _bwd_split_piecewise(pd, P, tag, wpacked_bwd, planes, save, grads, d_raw, st
     alpha = wpacked_bwd.data_ptr() + lay.bwd_alpha_w * 4
     with PROFILE.region("mlp_bwd_kernel<stage 1: heads>%s/P=%d" % (tag, P), 2 * (128 * 283 + 3 * 128) * P):
         _capi.check(stage_call(1), "backward stage 1")
-    with PROFILE.region("layer_split_kernel<8 layers>%s/P=%d" % (tag, P), 8 * 2 * 256 * 256 * P):
-        _capi.check(lib.scnerf_layer_split_chain_bwd(pd, _p(planes), _p(wpacked_bwd), _p(save), _p(grads), _p(d_raw), P,
-                                                     _stream()), "scnerf_layer_split_chain_bwd")
+    with PROFILE.region("layer_split_kernel<8 layers%s>%s/P=%d" % (_half_note(7), tag, P), 8 * 2 * 256 * 256 * P):
+        _capi.check(lib.scnerf_layer_split_chain_bwd(pd, _p(planes), _p(wpacked_bwd), _p(save), _p(grads), _p(d_raw),
+                                                     _p(_amax(P, save.device)), P, _stream()), "scnerf_layer_split_chain_bwd")
     with PROFILE.region("mlp_bwd_kernel<stage 2: encoded-point end>%s/P=%d" % (tag, P), 2 * 2 * 256 * lay.in_pts * P):
         _capi.check(stage_call(2), "backward stage 2")
 
@@ -411,7 +431,7 @@ def mlp_bwd(d_raw: Tensor, pts: Tensor, viewdirs: Tensor, samples_per_ray: int, 
             else:
                 st = _capi.load().scnerf_mlp_bwd_split(pd, _p(d_raw), _p(pts), vptr, vstride, int(samples_per_ray),
                                                        _p(wpacked_bwd), _p(planes), _p(save), _p(grads), _p(d_pts),
-                                                       _p(d_views), P, _stream())
+                                                       _p(d_views), _p(_amax(P, save.device)), P, _stream())
         _capi.check(st, "scnerf_mlp_bwd_split")
         return grads, d_pts, d_views
     with PROFILE.region("mlp_bwd_kernel%s/P=%d" % ("" if pd == 3 else "/pd4", P), 2 * _MAC_PER_SAMPLE[pd] * P):

@@ -100,7 +100,7 @@ def gpu_sampling_state(ops, host_linspace, rays, net_c, t_rand, u, noise_c, sc, 
         flat = net_c.flat_parameters()
         # the same arithmetic the training forward under test used (ops.mlp_arithmetic): the coarse weights decide
         # where the fine samples go
-        split = ops.mlp_arithmetic() == "split"
+        split = ops.mlp_arithmetic() in ("split", "half")
         save = ops.save_workspace(rays.shape[0] * sc, dev) if split else None
         raw_c = ops.mlp_fwd(pts_c, rays[:, 8:11], sc, ops.pack_weights(flat, "fwd"), save,
                             planes=ops.pack_planes(flat) if split else None)

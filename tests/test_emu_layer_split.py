@@ -74,10 +74,17 @@ def test_layer_split_rejects_bad_arguments():
     assert lib.scnerf_layer_split(3, 2, H.ptr(s), H.ptr(z), H.ptr(z), None, H.ptr(z), None, 0, None) == 0      # nothing to do
 
 
+def _amax_ws(P, half):
+    """the per-sample maxima workspace that switches the layer GEMMs to three fp16 products (None: six bf16 products)"""
+    return np.full(H.lib().scnerf_layer_amax_floats(P), np.nan, np.float32) if half else None
+
+
+@pytest.mark.parametrize("half", [False, True])
 @pytest.mark.parametrize("pd,n_rays,spr", [(3, 3, 50), (4, 2, 70)])
-def test_staged_forward_equals_the_fused_forward(pd, n_rays, spr):
+def test_staged_forward_equals_the_fused_forward(pd, n_rays, spr, half):
     """scnerf_mlp_fwd_split (stage 1, eight layer GEMMs, stage 2) against scnerf_mlp_fwd: raw outputs and every
-    saved section the backward kernels read."""
+    saved section the backward kernels read -- on six bf16 products per product, and with the layers fed with
+    per-sample maxima on three fp16 products."""
     lay = ML.layout(pd)
     P = n_rays * spr
     p, wpk, save = _forward_with_save(pd, P, n_rays, spr, 21 + pd)
@@ -91,15 +98,16 @@ def test_staged_forward_equals_the_fused_forward(pd, n_rays, spr):
     H.call("scnerf_pack_split_planes", pd, flat_params(p, pd), planes, None)
     raw = np.full((P, 4), np.nan, np.float32)
     save2 = np.full(lay.save_floats(P), np.nan, np.float32)
-    H.call("scnerf_mlp_fwd_split", pd, pts, vd, 3, spr, wpk, planes, raw, save2, P, None)
+    H.call("scnerf_mlp_fwd_split", pd, pts, vd, 3, spr, wpk, planes, raw, save2, _amax_ws(P, half), P, None)
     np.testing.assert_allclose(raw, raw_ref, rtol=1e-5, atol=1e-5)
     a, b = save_views(save, P, pd), save_views(save2, P, pd)
     for name, _ in lay.save_sections:
         np.testing.assert_allclose(b[name], a[name], rtol=1e-5, atol=1e-5, err_msg=name)
 
 
+@pytest.mark.parametrize("half", [False, True])
 @pytest.mark.parametrize("pd,n_rays,spr", [(3, 3, 50), (4, 2, 70)])
-def test_staged_data_gradients_equal_the_fused_chain(pd, n_rays, spr):
+def test_staged_data_gradients_equal_the_fused_chain(pd, n_rays, spr, half):
     """scnerf_mlp_bwd_split (heads, eight transposed layer GEMMs, encoded-point end) against scnerf_mlp_bwd on the
     same forward workspace: every gradient section the weight-gradient GEMMs read, d pts, d viewdirs."""
     from tests.emu_mlp_util import grad_views, pack_backward
@@ -118,7 +126,9 @@ def test_staged_data_gradients_equal_the_fused_chain(pd, n_rays, spr):
         grads = np.full(ML.grad_floats(P), np.nan, np.float32)
         d_pts = np.zeros((P, pd), np.float32)
         d_views = np.zeros((P, 3), np.float32)
-        args = [pd, d_raw, pts, vd, 3, spr, wbk] + ([planes] if name.endswith("split") else []) + [save, grads, d_pts, d_views, P, None]
+        split = name.endswith("split")
+        args = [pd, d_raw, pts, vd, 3, spr, wbk] + ([planes] if split else []) + [save, grads, d_pts, d_views] + \
+               ([_amax_ws(P, half)] if split else []) + [P, None]
         H.call(name, *args)
         out[name] = (grad_views(grads, P), d_pts, d_views)
     (ga, pa, va), (gb, pb, vb) = out["scnerf_mlp_bwd"], out["scnerf_mlp_bwd_split"]
@@ -160,7 +170,8 @@ def test_render_rays_split_on_the_simt_interpreter():
         assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-9
 
 
-def test_chained_layers_equal_layer_by_layer_launches():
+@pytest.mark.parametrize("half", [False, True])
+def test_chained_layers_equal_layer_by_layer_launches(half):
     """Eight layers in ONE launch (every workgroup keeps its blocks from layer to layer; taken when a workgroup owns
     at least two blocks -- here forced by capping the persistent workgroups at one) against the layer-by-layer
     launches, forward and data-gradient chains: bit-identical workspaces."""
@@ -180,12 +191,12 @@ def test_chained_layers_equal_layer_by_layer_launches():
             assert H.lib().scnerf_layer_split_workgroups(cap) == cap
             s2 = save.copy()
             s2[np.isnan(s2)] = 0.0
-            H.call("scnerf_layer_split_chain_fwd", pd, planes, wpk, s2, P, None)
+            H.call("scnerf_layer_split_chain_fwd", pd, planes, wpk, s2, _amax_ws(P, half), P, None)
             grads = np.zeros(ML.grad_floats(P), np.float32)
             off, _ = ML.section_offsets(ML.GRAD_SECTIONS, P)
             Pp = ML.padded_samples(P)
             grads[off["dfeat"]: off["dfeat"] + 256 * Pp] = np.random.default_rng(3).standard_normal(256 * Pp).astype(np.float32)
-            H.call("scnerf_layer_split_chain_bwd", pd, planes, wbk, s2, grads, d_raw, P, None)
+            H.call("scnerf_layer_split_chain_bwd", pd, planes, wbk, s2, grads, d_raw, _amax_ws(P, half), P, None)
             out[cap] = (s2, grads)
     finally:
         H.lib().scnerf_layer_split_workgroups(256)

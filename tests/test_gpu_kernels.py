@@ -213,8 +213,18 @@ def test_split_weight_gradient_gemm_is_fp32_grade(ops):
     assert err["split"]["rms"] <= 2.0 * err["fp32"]["rms"], err
 
 
+@pytest.fixture(params=["split", "half"])
+def layers(request, ops):
+    """the two arithmetics of the layer GEMMs: six bf16 products everywhere, or three fp16 products where the input
+    comes with per-sample maxima (ops.mlp_arithmetic)"""
+    saved = ops.mlp_arithmetic()
+    ops.mlp_arithmetic(request.param)
+    yield request.param
+    ops.mlp_arithmetic(saved)
+
+
 @pytest.mark.parametrize("pd,n_rays,spr", [(3, 21, 50), (4, 17, 70), (3, 1024, 192)])
-def test_staged_split_forward_equals_the_fused_forward(ops, pd, n_rays, spr):
+def test_staged_split_forward_equals_the_fused_forward(ops, pd, n_rays, spr, layers):
     """Training forward with the eight 256-wide layers as split-arithmetic GEMMs (scnerf_mlp_fwd_split) against the
     fused fp32-MFMA kernel: raw outputs and every saved section the backward kernels read, to accumulation-order
     rounding; ReLU bit words may differ only where a pre-activation is within rounding of zero."""
@@ -257,7 +267,7 @@ def test_staged_split_forward_equals_the_fused_forward(ops, pd, n_rays, spr):
 
 
 @pytest.mark.parametrize("pd,n_rays,spr", [(3, 21, 50), (4, 17, 70), (3, 1024, 192)])
-def test_staged_split_data_gradients_equal_the_fused_chain(ops, pd, n_rays, spr):
+def test_staged_split_data_gradients_equal_the_fused_chain(ops, pd, n_rays, spr, layers):
     """scnerf_mlp_bwd_split (heads, eight transposed split-arithmetic layer GEMMs, encoded-point end) against the
     fused fp32-MFMA data-gradient kernel on the same forward workspace: every gradient section the weight-gradient
     GEMMs read, d pts and d viewdirs, to accumulation-order rounding."""
@@ -302,16 +312,21 @@ def test_split_layer_gemm_is_fp32_grade(ops):
     vd = dev(vd / vd.norm(dim=-1, keepdim=True))
     wf = ops.pack_weights(flat, "fwd")
     saves = {}
-    for mode, planes in (("fp32", None), ("split", ops.pack_planes(flat))):
-        saves[mode] = ops.save_workspace(P, "cuda").zero_()
-        ops.mlp_fwd(pts, vd, spr, wf, saves[mode], planes=planes)
+    saved_mode = ops.mlp_arithmetic()
+    try:
+        for mode, planes in (("fp32", None), ("split", ops.pack_planes(flat)), ("half", ops.pack_planes(flat))):
+            ops.mlp_arithmetic(mode)
+            saves[mode] = ops.save_workspace(P, "cuda").zero_()
+            ops.mlp_fwd(pts, vd, spr, wf, saves[mode], planes=planes)
+    finally:
+        ops.mlp_arithmetic(saved_mode)
     Pp = ML.padded_samples(P)
     off, _ = ML.section_offsets(lay.save_sections, P)
     rows = lambda save, name: save[off[name]: off[name] + 256 * Pp].view(Pp // 32, 8, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(Pp, 256)[:P]
     report = {}
     for layer in (2, 7):
         W, b = dev(p["pts_linears.%d.weight" % layer]), dev(p["pts_linears.%d.bias" % layer])
-        for mode in ("fp32", "split"):
+        for mode in ("fp32", "split", "half"):                        # (layers 2 and 7 are fp16 layers of "half")
             x = rows(saves[mode], "act%d" % (layer - 1))              # each path judged on ITS OWN input
             z = rows(saves[mode], "act%d" % layer)
             ref = torch.relu(x.double() @ W.double().T + b.double())
@@ -326,6 +341,8 @@ def test_split_layer_gemm_is_fp32_grade(ops):
     for layer, r in report.items():
         assert r["split"]["rms"] <= 2.0 * r["fp32"]["rms"] and r["split"]["max"] <= 3.0 * r["fp32"]["max"] + 1e-9, (layer, r)
         assert r["split"]["max"] < 1e-6, (layer, r)
+        assert r["half"]["rms"] <= 2.0 * r["fp32"]["rms"] and r["half"]["max"] <= 3.0 * r["fp32"]["max"] + 1e-9, (layer, r)
+        assert r["half"]["max"] < 1e-6, (layer, r)
 
 
 def test_profiled_piecewise_launches_equal_the_single_calls(ops):

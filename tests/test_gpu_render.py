@@ -67,14 +67,14 @@ def rays_within(got, ref, tol):
     return float((e <= tol).mean()), float(e.max())
 
 
-@pytest.fixture(params=["split", "fp32"])
+@pytest.fixture(params=["split", "fp32", "half"])
 def arithmetic(request):
     """the golden render_rays cases run in both arithmetic modes of the training step (ops.mlp_arithmetic /
     ops.wgrad_arithmetic): the default split-arithmetic layer GEMMs and the all-fp32-MFMA kernels"""
     from scnerf_amd import ops
     saved = (ops.mlp_arithmetic(), ops.wgrad_arithmetic())
     ops.mlp_arithmetic(request.param)
-    ops.wgrad_arithmetic(request.param)
+    ops.wgrad_arithmetic("split" if request.param == "half" else request.param)
     yield request.param
     ops.mlp_arithmetic(saved[0])
     ops.wgrad_arithmetic(saved[1])
