@@ -27,6 +27,7 @@ def emulated_device(mlp_arithmetic="fp32"):
     _capi.current_stream = lambda: None
     ops._index_cache.clear()
     ops._wgrad_ws.clear()
+    ops._amax_cache.clear()
     try:
         yield
     finally:
@@ -34,4 +35,5 @@ def emulated_device(mlp_arithmetic="fp32"):
         ops._canon_cache.clear()
         _capi._lib, _capi.on_device, _capi.current_stream = saved
         ops._index_cache.clear()
+        ops._amax_cache.clear()
         ops._wgrad_ws.clear()
