@@ -221,3 +221,44 @@ def test_chained_layers_equal_layer_by_layer_launches(half):
         H.lib().scnerf_layer_split_workgroups(256)
     np.testing.assert_array_equal(out[256][0].view(np.int32), out[1][0].view(np.int32))
     np.testing.assert_array_equal(out[256][1].view(np.int32), out[1][1].view(np.int32))
+
+
+def test_three_product_layers_across_forty_orders_of_magnitude():
+    """The data-gradient chain is linear in d_raw sample by sample.  With every sample's d_raw scaled by its own power
+    of ten between 1e-30 and 1e+10 -- far outside what fp16 holds -- the layers on three fp16 products (per-sample
+    power-of-two scales from the maxima the producing layer leaves) must reproduce the six-bf16-product chain row
+    by row, relative to each row's own size; an all-zero sample stays zero."""
+    from tests.emu_mlp_util import grad_views, pack_backward
+    pd, n_rays, spr = 3, 3, 50
+    P = n_rays * spr
+    p, wpk, save = _forward_with_save(pd, P, n_rays, spr, 51)
+    wbk = pack_backward(p, pd)
+    planes = np.zeros(H.lib().scnerf_split_planes_shorts(pd), np.int16)
+    H.call("scnerf_pack_split_planes", pd, flat_params(p, pd), planes, None)
+    g = torch.Generator().manual_seed(51)
+    pts = (torch.rand(P, pd, generator=g) * 2.4 - 1.2).numpy()
+    vd = torch.randn(n_rays, 3, generator=g)
+    vd = (vd / vd.norm(dim=-1, keepdim=True)).numpy()
+    d_raw = torch.randn(P, 4, generator=g).numpy()
+    decades = np.linspace(-30, 10, P).astype(np.float32)
+    np.random.default_rng(3).shuffle(decades)
+    d_raw = (d_raw * (10.0 ** decades)[:, None]).astype(np.float32)
+    d_raw[7] = 0.0
+    out = {}
+    for half in (False, True):
+        grads = np.full(ML.grad_floats(P), np.nan, np.float32)
+        d_pts = np.zeros((P, pd), np.float32)
+        d_views = np.zeros((P, 3), np.float32)
+        H.call("scnerf_mlp_bwd_split", pd, d_raw, pts, vd, 3, spr, wbk, planes, save, grads, d_pts, d_views,
+               _amax_ws(P, half), P, None)
+        out[half] = (grad_views(grads, P), d_pts)
+    (ga, pa), (gb, pb) = out[False], out[True]
+    for name in ga:
+        a, b = ga[name].astype(np.float64), gb[name].astype(np.float64)
+        assert np.isfinite(b).all(), name
+        size = np.abs(a).max(axis=1)
+        err = np.abs(a - b).max(axis=1)
+        assert (err <= 2e-5 * size + 1e-44).all(), (name, float((err / (size + 1e-300)).max()))
+        assert not b[7].any()
+    size = np.abs(pa).max(axis=1)
+    assert (np.abs(pa - pb).max(axis=1) <= 1e-4 * size + 1e-44).all()

@@ -374,3 +374,46 @@ def test_profiled_piecewise_launches_equal_the_single_calls(ops):
         assert any(k.startswith("layer_split_kernel") for k in names)
         for a, b in zip(*res):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+def test_three_product_layers_across_forty_orders_of_magnitude(ops):
+    """The data-gradient chain is linear in d_raw sample by sample.  With every sample's d_raw scaled by its own power
+    of ten between 1e-30 and 1e+10 -- far outside what fp16 holds -- the layers on three fp16 products (per-sample
+    power-of-two scales from the maxima the producing layer leaves; here as chains: 1024 x 192 samples) must reproduce
+    the six-bf16-product chain row by row, relative to each row's own size; all-zero samples stay zero."""
+    from tests.emu_mlp_util import network_params
+    pd, n_rays, spr = 3, 1024, 192
+    p = network_params(4, pd)
+    flat = dev(_flat(p, pd))
+    P = n_rays * spr
+    g = torch.Generator().manual_seed(16)
+    pts = dev(torch.rand(P, pd, generator=g) * 2.4 - 1.2)
+    vd = torch.randn(n_rays, 3, generator=g)
+    vd = dev(vd / vd.norm(dim=-1, keepdim=True))
+    decades = torch.rand(P, generator=g) * 40.0 - 30.0
+    d_raw = dev(torch.randn(P, 4, generator=g) * (10.0 ** decades)[:, None])
+    d_raw[::97] = 0.0
+    save = ops.save_workspace(P, "cuda", pd).zero_()
+    ops.mlp_fwd(pts, vd, spr, ops.pack_weights(flat, "fwd", pd=pd), save, pd=pd)
+    wb, planes = ops.pack_weights(flat, "bwd", pd=pd), ops.pack_planes(flat, pd)
+    out = {}
+    saved = ops.mlp_arithmetic()
+    try:
+        for mode in ("split", "half"):
+            ops.mlp_arithmetic(mode)
+            grads, d_pts, _ = ops.mlp_bwd(d_raw, pts, vd, spr, wb, save, pd=pd, planes=planes)
+            out[mode] = (grads.clone(), d_pts.clone())
+    finally:
+        ops.mlp_arithmetic(saved)
+    Pp = ML.padded_samples(P)
+    off, _ = ML.section_offsets(ML.GRAD_SECTIONS, P)
+    for name, w in ML.GRAD_SECTIONS:
+        rows = lambda t: t[off[name]: off[name] + w * Pp].view(Pp // 32, w // 32, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(Pp, w)[:P]
+        a, b = rows(out["split"][0]).double(), rows(out["half"][0]).double()
+        assert bool(torch.isfinite(b).all()), name
+        size = a.abs().amax(dim=1)
+        err = (a - b).abs().amax(dim=1)
+        assert bool((err <= 2e-5 * size + 1e-44).all()), (name, float((err / (size + 1e-300)).max()))
+        assert not bool(b[::97].any()), name
+    a, b = out["split"][1].double(), out["half"][1].double()
+    assert bool(((a - b).abs().amax(dim=1) <= 1e-4 * a.abs().amax(dim=1) + 1e-44).all())
