@@ -271,8 +271,10 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=512)
     ap.add_argument("--camera", action="store_true", help="rays from the learnable camera model also at N = 1")
     ap.add_argument("--mlp-arithmetic", choices=("split", "fp32", "half"), default=None,
-                    help="the eight 256-wide layers of the training forward and of the data-gradient chain: per-layer GEMMs on "
-                         "the bf16 matrix pipe with exactly cut fp32 operands (default) or inside the fused fp32-MFMA kernels")
+                    help="the eight 256-wide layers of the training forward and of the data-gradient chain: GEMMs over all "
+                         "samples on the 16-bit matrix pipe -- 'half' (default): three fp16 products where the input carries "
+                         "per-sample maxima, six bf16 products elsewhere; 'split': six bf16 products everywhere -- or "
+                         "'fp32': inside the fused fp32-MFMA kernels")
     ap.add_argument("--wgrad-arithmetic", choices=("split", "fp32"), default=None,
                     help="256 x 256 weight-gradient GEMMs: bf16 matrix pipe with exactly cut fp32 operands (default) "
                          "or the exact-fp32 MFMA")
