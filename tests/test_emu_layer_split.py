@@ -262,3 +262,37 @@ def test_three_product_layers_across_forty_orders_of_magnitude():
         assert not b[7].any()
     size = np.abs(pa).max(axis=1)
     assert (np.abs(pa - pb).max(axis=1) <= 1e-4 * size + 1e-44).all()
+
+
+@pytest.mark.parametrize("pd", [3, 4])
+def test_weight_planes_reassemble_the_weights(pd):
+    """scnerf_pack_split_planes: the three bf16 planes of a weight add up to it EXACTLY; the two fp16 planes add up to
+    weight x 2^k within 2^-21 of the layer's largest entry, 2^k the layer's power of two with max |w| 2^k in
+    [2^12, 2^13); the tail holds 1 / 2^k and 2^k.  Checked on layer 2 (plane order [slab][plane][T][lane][8]:
+    W[32 T + (lane & 31)][16 s + 8 (lane >> 5) + e])."""
+    p = network_params(5, pd)
+    n = H.lib().scnerf_split_planes_shorts(pd)
+    planes = np.zeros(n, np.int16)
+    H.call("scnerf_pack_split_planes", pd, flat_params(p, pd), planes, None)
+    half_words = (n - 32) // 2
+    slab_shorts = 3 * 8 * 64 * 8
+    tail = planes[2 * half_words:].view(np.float32)
+    W = p["pts_linears.2.weight"].numpy()                      # [256 out][256 in]
+    first = 16 * slab_shorts                                   # layer 1's 16 slabs come first
+    idx = np.arange(16 * 8 * 64 * 8)
+    e, lane, T, s = idx & 7, (idx >> 3) & 63, (idx >> 9) & 7, idx >> 12
+    want = W[32 * T + (lane & 31), 16 * s + 8 * (lane >> 5) + e].astype(np.float64)
+
+    def plane(base, q):
+        a = planes[base + first: base + first + 16 * slab_shorts].reshape(16, 3, 8 * 64 * 8)
+        return a[s, q, (T * 64 + lane) * 8 + e]
+    bf = lambda x: (x.astype(np.uint16).astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    assert np.array_equal(bf(plane(0, 0)) + bf(plane(0, 1)) + bf(plane(0, 2)), want)
+    scale, inv = float(tail[8 + 1]), float(tail[1])             # layer 2 -> slot 1
+    assert scale * inv == 1.0 and np.log2(scale) == round(np.log2(scale))
+    wmax = float(np.abs(W).max())
+    assert 2.0 ** 12 <= wmax * scale < 2.0 ** 13
+    h16 = lambda x: x.view(np.float16).astype(np.float64)
+    got = h16(plane(half_words, 0)) + h16(plane(half_words, 1))
+    assert float(np.abs(got - want * scale).max()) <= 2.0 ** -21 * wmax * scale
+    assert not plane(half_words, 2).any()
