@@ -18,6 +18,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long-running CPU test")
 
 
+def pytest_xdist_auto_num_workers(config):
+    """`-n auto` (pytest.ini) means: four workers for the CPU suite (the SIMT interpreter's long tests are serial),
+    none on the GPU box -- one GPU, and the two-process RCCL tests want it to themselves."""
+    expr = (config.getoption("markexpr", "") or "").strip()
+    return 4 if expr == "not gpu" and not torch.cuda.is_available() else 0
+
+
 def pytest_sessionfinish(session, exitstatus):
     try:
         from tests import parity_attribution

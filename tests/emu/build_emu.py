@@ -16,6 +16,18 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
 def build(verbose=False):
+    """(serialised across processes: pytest-xdist workers all ask for the library at start-up)"""
+    import fcntl
+    os.makedirs(OUTDIR, exist_ok=True)
+    with open(os.path.join(OUTDIR, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build(verbose=False):
     os.makedirs(OUTDIR, exist_ok=True)
     cxx = CLANG if os.path.isfile(CLANG) else "clang++"
     flags = ["-O2", "-g1", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-mfma",
