@@ -195,6 +195,8 @@ def pack_weights(flat_params: Tensor, kind: str = "fwd", out: Optional[Tensor] =
 
 
 _MLP_ARITHMETIC = [os.environ.get("SCNERF_MLP_ARITHMETIC", "half")]
+if _MLP_ARITHMETIC[0] not in ("fp32", "split", "half"):
+    raise ValueError("SCNERF_MLP_ARITHMETIC must be 'fp32', 'split' or 'half', not %r" % _MLP_ARITHMETIC[0])
 
 
 def mlp_arithmetic(mode: Optional[str] = None) -> str:
