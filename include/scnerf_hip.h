@@ -310,6 +310,33 @@ int scnerf_nerf_wgrad(int pt_dims, const float* save, const float* grads, const 
                       long long n_samples, int n_chunks, float* workspace, float* flat_grad,
                       int accumulate, void* stream);
 
+/* ------------------------------------------------------------------ resident arithmetic ---- */
+/* The whole network in ONE launch on three fp16 products per product with register-resident activations
+ * (csrc/mlp_h3.h): what scnerf_mlp_fwd / scnerf_coarse_stage_fwd / scnerf_mlp_bwd compute (run_network + Embedder +
+ * NeRF.forward, NeRF/create_nerf.py:18-32, NeRF/run_nerf_helpers.py:24-72, :105-128, and for the coarse stage
+ * NeRF/render.py:235-262), to the same workspaces.
+ *
+ * scnerf_h3_pack: flat parameters (reference registration order) -> the two fragment streams (fp16 planes of
+ * weight x the layer's power-of-two scale, in the order a wave consumes them) and the scale table [12][8] floats
+ * (per layer: Sw, 1 / Sw, largest row 1-norm A, largest |bias| B, largest column 1-norm A'); once per optimizer
+ * step.  jobs [12][4] ints (weight offset, rows, columns, bias offset), idx_* [frags * 512] ints (flat parameter
+ * index or -1), meta_* [frags] bytes (plane | layer << 1): the tables of scnerf_amd/mlp_layout.py (h3_plan,
+ * h3_scale_jobs), device pointers.  A direction with frags == 0 is skipped. */
+long long scnerf_h3_scale_floats(void);
+int scnerf_h3_pack(const float* flat_params, const int* jobs, const int* idx_fwd, const unsigned char* meta_fwd,
+                   long long frags_fwd, const int* idx_bwd, const unsigned char* meta_bwd, long long frags_bwd,
+                   short* stream_fwd, short* stream_bwd, float* scales, void* stream);
+/* wpacked: the packed fp32 buffer of scnerf_gather_f32 (its lane-vector tables: biases, density head); save == NULL:
+ * inference.  Arguments otherwise as scnerf_mlp_fwd / scnerf_coarse_stage_fwd. */
+int scnerf_mlp_fwd_h3(int pt_dims, const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
+                      const float* wpacked, const short* stream_fwd, const float* scales, float* raw, float* save,
+                      long long n_samples, void* stream);
+int scnerf_coarse_stage_fwd_h3(const float* rays, int ray_stride, const float* t_vals, const float* t_rand,
+                               int lindisp, const float* wpacked, const short* stream_fwd, const float* scales,
+                               float* save, const float* noise, int white_bkgd, float* z, float* pts, float* raw,
+                               float* rgb_map, float* disp_map, float* acc_map, float* depth_map, float* weights,
+                               int n_rays, int n_samples, void* stream);
+
 /* ------------------------------------------------------------------ PRD loss --------- */
 
 /* Projected-ray-distance loss, proj_ray_dist_loss_single (model/ray_dist_loss.py:22-246) after its

@@ -45,6 +45,39 @@ __device__ __forceinline__ float f16_value(unsigned bits) { return (float)__buil
 __device__ __forceinline__ unsigned low_halves(unsigned lo_word, unsigned hi_word) {
     return __builtin_amdgcn_perm(hi_word, lo_word, 0x05040100u);
 }
+// ---- two-way fp16 cut of an fp32 value x scaled by a power of two s:  x s = h + l + O(2^-22 |x s|) ----------------
+// {f16(a s), f16(b s)} in the low / high half of one word (v_fma_mixlo_f16 / v_fma_mixhi_f16: the product is exact,
+// one rounding to nearest even)
+__device__ __forceinline__ unsigned pack_f16_scaled(float a, float b, float s) {
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(d) : "v"(a), "v"(b), "v"(s));
+    return d;
+}
+// a s - (half HI of `packed`), exact (v_fma_mix_f32 with an fp16 third operand): what the low plane has to carry
+template <int HI>
+__device__ __forceinline__ float residual_f16(float a, float s, unsigned packed) {
+    float r;
+    if constexpr (HI) asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(s), "v"(packed));
+    else asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(s), "v"(packed));
+    return r;
+}
+// {f16(a), f16(b)}, round to nearest even (v_cvt_pk_f16_f32)
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {
+    unsigned d;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// max(m, a, b) and max(m, |a|, |b|) as one v_max3_f32
+__device__ __forceinline__ float max3(float m, float a, float b) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float max3_abs(float m, float a, float b) {
+    float r;
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
 // ds_read_b64_tr_b16: every lane names 8 bytes of LDS (4 x 16 bit, 8-byte aligned); the 16 lanes of a group
 // together name a [4 rows][16 columns] block (lane c: row c >> 2, columns 4 (c & 3) .. +3) and lane c
 // receives column c, rows 0 .. 3 -- the transpose an MFMA operand needs when the LDS image is k-major.

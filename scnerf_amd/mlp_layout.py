@@ -366,3 +366,185 @@ def backward_index() -> np.ndarray:
 
 def save_floats(P: int) -> int:
     return _STD.save_floats(P)
+
+
+# ================================================================================================
+# "resident" arithmetic (csrc/mlp_h3.h): the whole network on three fp16 products per product with the
+# activations register-resident as pre-cut fp16 planes.  The weights stream through LDS as 16-byte MFMA
+# A fragments (v_mfma_f32_32x32x16_f16: lane (n, g) holds row 32 T + n, contraction elements e = 0 .. 7 of
+# the slab's lane half g) in exactly the order a wave consumes them:
+#   part of output-tile PAIRS (T0, T0 + 1):  per pair, per K slab:  [Wh T0][Wh T0+1][Wl T0][Wl T0+1]
+#   part of ONE output tile:                 per two K slabs:       [Wh s][Wl s][Wh s+1][Wl s+1]
+# Either way four fragments (one "unit") feed six MFMAs; a 32 KB LDS chunk holds 8 units.
+# Contraction element (slab sl = 2 t + u, lane half g, e) of a register-resident operand is feature
+# 32 t + 16 u + 8 (e >> 2) + 4 g + (e & 3): the two 16-byte accumulator pieces (t, 2 u), (t, 2 u + 1) a lane
+# owns.  Encoded points / directions: slab u, element e = PE slot 8 u + e of lane half g (pe_col).
+H3_CHUNK_FRAGS = 32
+H3_LAYER_FEAT, H3_LAYER_VIEWS, H3_LAYER_RGB, H3_LAYER_ALPHA = 8, 9, 10, 11
+H3_SCALE_STRIDE = 8            # floats per layer in the scale table: Sw, 1/Sw, A, B, A', (3 spare)
+H3_N_LAYERS = 12
+
+
+def h3_feature_of(sl, g, e):
+    return 32 * (sl >> 1) + 16 * (sl & 1) + 8 * (e >> 2) + 4 * g + (e & 3)
+
+
+class H3Plan:
+    """Fragment stream of one direction: idx [n_frags, 64, 8] int32 (flat parameter index or -1),
+    meta [n_frags] uint8 (bit 0: plane 0 = h / 1 = l; bits 1..: layer slot of the scale table)."""
+
+    def __init__(self):
+        self.idx: List[np.ndarray] = []
+        self.meta: List[int] = []
+        self.part_units: List[Tuple[str, int]] = []
+
+    def _frag(self, elem, T, slab, plane, layer):
+        lane = np.arange(64)
+        n, g = lane & 31, lane >> 5
+        f = np.full((64, 8), -1, np.int32)
+        for e in range(8):
+            for ln in range(64):
+                f[ln, e] = elem(32 * T + int(n[ln]), slab, int(g[ln]), e)
+        self.idx.append(f)
+        self.meta.append(plane | (layer << 1))
+
+    def pair_part(self, name, n_tiles, slabs, elem, layer):
+        assert n_tiles % 2 == 0
+        for P in range(n_tiles // 2):
+            for sl in slabs:
+                for plane in (0, 1):
+                    for T in (2 * P, 2 * P + 1):
+                        self._frag(elem, T, sl, plane, layer)
+        self.part_units.append((name, (n_tiles // 2) * len(slabs)))
+
+    def single_part(self, name, T, slabs, elem, layer):
+        assert len(slabs) % 2 == 0
+        for sl in slabs:
+            for plane in (0, 1):
+                self._frag(elem, T, sl, plane, layer)
+        self.part_units.append((name, len(slabs) // 2))
+
+    def finish(self):
+        n = len(self.idx)
+        pad = (-n) % H3_CHUNK_FRAGS
+        total = n + pad + 2 * H3_CHUNK_FRAGS            # two chunks the loader may run ahead into
+        idx = np.full((total, 64, 8), -1, np.int32)
+        idx[:n] = np.stack(self.idx)
+        meta = np.zeros(total, np.uint8)
+        meta[:n] = np.array(self.meta, np.uint8)
+        return idx.reshape(-1), meta, n
+
+
+def _h3_forward(lay: "Layout") -> H3Plan:
+    po, IN, pd = lay.param_offsets, lay.in_pts, lay.pd
+    plan = H3Plan()
+    enc = [("e", u) for u in range(lay.e_slots // 8)]
+    trunk = [("t", sl) for sl in range(16)]
+
+    def kcol(slab, g, e, L, pdim, off_enc, off_feat):
+        kind, s = slab
+        if kind == "e":
+            c = pe_col(L, 8 * s + e, g, pdim)
+            return off_enc + c if c >= 0 else -1
+        return off_feat + h3_feature_of(s, g, e)
+
+    def dense(wname, ld, n_valid, L=L_PTS, pdim=pd, off_enc=0, off_feat=0):
+        base = po[wname]
+
+        def elem(o, slab, g, e):
+            c = kcol(slab, g, e, L, pdim, off_enc, off_feat)
+            return base + o * ld + c if (o < n_valid and c >= 0) else -1
+        return elem
+
+    plan.pair_part("L0", 8, enc, dense("pts_linears.0.weight", IN, W), 0)
+    for l in range(1, 8):
+        if l == 5:      # skip layer: [encoded point | h] (run_nerf_helpers.py:111-112); the encoded slabs first
+            plan.pair_part("L5", 8, enc + trunk, dense("pts_linears.5.weight", W + IN, W, off_feat=IN), 5)
+        else:
+            plan.pair_part("L%d" % l, 8, trunk, dense("pts_linears.%d.weight" % l, W, W), l)
+    plan.pair_part("LF", 8, trunk, dense("feature_linear.weight", W, W), H3_LAYER_FEAT)
+    venc = [("e", u) for u in range(E_VIEWS_SLOTS // 8)]
+    plan.pair_part("V", 4, trunk + venc,
+                   dense("views_linears.0.weight", W + IN_VIEWS, W // 2, L=L_VIEWS, pdim=3, off_enc=W), H3_LAYER_VIEWS)
+    plan.single_part("RGB", 0, [("t", sl) for sl in range(8)], dense("rgb_linear.weight", W // 2, 3), H3_LAYER_RGB)
+    return plan
+
+
+def _h3_backward(lay: "Layout") -> H3Plan:
+    """data-gradient stream: A = W^T -- output row o is an INPUT column of the layer, the contraction runs over the
+    layer's outputs (register-resident dZ)."""
+    po, IN, pd = lay.param_offsets, lay.in_pts, lay.pd
+    plan = H3Plan()
+    trunk = list(range(16))
+
+    def ident(limit, off=0):
+        return lambda o: (off + o) if o < limit else -1
+
+    def pe_rows(L, off=0, pdim=3, n_slots=None):
+        def f(o):
+            t, i = divmod(o, 32)
+            r, h = row_to_rh(i)
+            s = 16 * t + r
+            if n_slots is not None and s >= n_slots:
+                return -1
+            c = pe_col(L, s, h, pdim)
+            return off + c if c >= 0 else -1
+        return f
+
+    def dense_t(wname, ld, ocol, n_rows):
+        base = po[wname]
+
+        def elem(o, sl, g, e):
+            col = ocol(o)
+            row = h3_feature_of(sl, g, e)
+            return base + row * ld + col if (col >= 0 and row < n_rows) else -1
+        return elem
+
+    def rgbt(o, sl, g, e):        # contraction over the colour channel: lane half 0, elements 0 .. 2
+        return po["rgb_linear.weight"] + e * (W // 2) + o if (g == 0 and e < 3 and o < W // 2) else -1
+
+    plan.pair_part("RGBT", 4, [0], rgbt, H3_LAYER_RGB)
+    hv = list(range(8))
+    plan.pair_part("VTF", 8, hv, dense_t("views_linears.0.weight", W + IN_VIEWS, ident(W), W // 2), H3_LAYER_VIEWS)
+    plan.single_part("VTE", 0, hv, dense_t("views_linears.0.weight", W + IN_VIEWS,
+                                            pe_rows(L_VIEWS, off=W, n_slots=E_VIEWS_SLOTS), W // 2), H3_LAYER_VIEWS)
+    plan.pair_part("FT", 8, trunk, dense_t("feature_linear.weight", W, ident(W), W), H3_LAYER_FEAT)
+    e_tiles = 2 if pd == 3 else 4
+    for l in range(7, 0, -1):
+        if l == 5:
+            plan.pair_part("L5TH", 8, trunk, dense_t("pts_linears.5.weight", W + IN, ident(W, off=IN), W), 5)
+            plan.pair_part("L5TE", e_tiles, trunk,
+                           dense_t("pts_linears.5.weight", W + IN, pe_rows(L_PTS, pdim=pd, n_slots=lay.e_slots), W), 5)
+        else:
+            plan.pair_part("L%dT" % l, 8, trunk, dense_t("pts_linears.%d.weight" % l, W, ident(W), W), l)
+    plan.pair_part("L0T", e_tiles, trunk,
+                   dense_t("pts_linears.0.weight", IN, pe_rows(L_PTS, pdim=pd, n_slots=lay.e_slots), W), 0)
+    return plan
+
+
+_h3_cache: Dict[Tuple[int, str], tuple] = {}
+
+
+def h3_plan(pd: int, kind: str):
+    """(idx int32 [total_frags * 512], meta uint8 [total_frags], n_frags, part_units) of the forward / backward
+    fragment stream of network variant pd; total_frags = n_frags rounded up to a chunk + 2 chunks of run-ahead."""
+    key = (pd, kind)
+    if key not in _h3_cache:
+        plan = _h3_forward(layout(pd)) if kind == "fwd" else _h3_backward(layout(pd))
+        idx, meta, n = plan.finish()
+        _h3_cache[key] = (idx, meta, n, plan.part_units)
+    return _h3_cache[key]
+
+
+def h3_scale_jobs(pd: int) -> np.ndarray:
+    """[12, 4] int32: (weight offset, rows, row stride = columns, bias offset) of the layers in scale-table order
+    0 .. 7 trunk, feature, views, rgb, alpha."""
+    lay = layout(pd)
+    po = lay.param_offsets
+    names = ["pts_linears.%d" % l for l in range(8)] + ["feature_linear", "views_linears.0", "rgb_linear", "alpha_linear"]
+    shapes = dict(lay.param_shapes)
+    jobs = []
+    for n in names:
+        rows, cols = shapes[n + ".weight"]
+        jobs.append([po[n + ".weight"], rows, cols, po[n + ".bias"]])
+    return np.array(jobs, np.int32)

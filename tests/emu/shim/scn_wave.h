@@ -82,6 +82,12 @@ inline float f16_value(unsigned bits) {
     return (float)h;
 }
 inline unsigned low_halves(unsigned lo_word, unsigned hi_word) { return (lo_word & 0xffffu) | (hi_word << 16); }
+inline unsigned pack_f16_scaled(float a, float b, float s) { return (f16_bits(a * s) & 0xffffu) | (f16_bits(b * s) << 16); }
+template <int HI>
+inline float residual_f16(float a, float s, unsigned packed) { return std::fmaf(a, s, -f16_value(HI ? packed >> 16 : packed & 0xffffu)); }
+inline unsigned pack_f16(float a, float b) { return (f16_bits(a) & 0xffffu) | (f16_bits(b) << 16); }
+inline float max3(float m, float a, float b) { return std::fmax(m, std::fmax(a, b)); }
+inline float max3_abs(float m, float a, float b) { return std::fmax(m, std::fmax(std::fabs(a), std::fabs(b))); }
 inline f32x16 mfma_32x32x16_f16(s16x8 a, s16x8 b, f32x16 c) {
     uint64_t mine[4];
     std::memcpy(&mine[0], &a, 16);

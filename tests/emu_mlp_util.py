@@ -92,3 +92,19 @@ def oracle_activations(p, pts, viewdirs_per_sample):
     feat = F.linear(acts[-1], p["feature_linear.weight"], p["feature_linear.bias"])
     hv = F.relu(F.linear(torch.cat([feat, ev], -1), p["views_linears.0.weight"], p["views_linears.0.bias"]))
     return dict(e=e, ev=ev, acts=acts, feat=feat, hv=hv)
+
+
+def pack_h3(p, pd=3, directions=("fwd", "bwd")):
+    """(forward stream, backward stream, scale table) of the resident arithmetic (scnerf_h3_pack on the interpreter)"""
+    src = flat_params(p, pd)
+    jobs = np.ascontiguousarray(ML.h3_scale_jobs(pd))
+    scales = np.zeros(H.lib().scnerf_h3_scale_floats(), np.float32)
+    plans = {k: ML.h3_plan(pd, k) for k in directions}
+    streams = {k: np.zeros(plans[k][1].shape[0] * 512, np.int16) for k in directions}
+
+    def arg(k, i):
+        return plans[k][i] if k in plans else None
+    H.call("scnerf_h3_pack", src, jobs, arg("fwd", 0), arg("fwd", 1), plans["fwd"][1].shape[0] if "fwd" in plans else 0,
+           arg("bwd", 0), arg("bwd", 1), plans["bwd"][1].shape[0] if "bwd" in plans else 0,
+           streams.get("fwd"), streams.get("bwd"), scales, None)
+    return streams.get("fwd"), streams.get("bwd"), scales

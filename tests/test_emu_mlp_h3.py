@@ -1,0 +1,102 @@
+"""The resident arithmetic (csrc/mlp_h3.h: three fp16 products, register-resident activations, one launch) on the CPU
+SIMT interpreter against the oracle network and against the fused fp32 kernels' workspaces."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import scnerf_oracle as O
+from scnerf_amd import mlp_layout as ML
+from tests.emu import harness as H
+from tests.emu_mlp_util import network_params, pack_forward, pack_h3, save_views, oracle_activations, flat_params
+
+pytestmark = pytest.mark.emu
+
+
+@pytest.mark.parametrize("pd", [3, 4])
+def test_stream_tables_reference_every_weight_twice(pd):
+    lay = ML.layout(pd)
+    for kind in ("fwd", "bwd"):
+        idx, meta, n, parts = ML.h3_plan(pd, kind)
+        assert idx.shape[0] == meta.shape[0] * 512 and meta.shape[0] % ML.H3_CHUNK_FRAGS == 0
+        assert sum(u for _, u in parts) * 4 == n
+        cnt = np.bincount(idx[idx >= 0], minlength=lay.n_params)
+        po = lay.param_offsets
+        for name, shape in lay.param_shapes:
+            sl = slice(po[name], po[name] + int(np.prod(shape)))
+            want = 2 if (name.endswith(".weight") and not name.startswith("alpha")) else 0
+            assert cnt[sl].min() == want and cnt[sl].max() == want, (kind, name)
+
+
+def test_packed_planes_reassemble_the_weights():
+    p = network_params(0)
+    fwd, bwd, sc = pack_h3(p)
+    src = flat_params(p)
+    sc = sc.reshape(12, 8)
+    jobs = ML.h3_scale_jobs(3)
+    for l in range(12):
+        w = src[jobs[l, 0]: jobs[l, 0] + jobs[l, 1] * jobs[l, 2]].reshape(jobs[l, 1], jobs[l, 2])
+        b = src[jobs[l, 3]: jobs[l, 3] + jobs[l, 1]]
+        assert sc[l, 0] * sc[l, 1] == 1.0 and np.log2(sc[l, 0]) == np.round(np.log2(sc[l, 0]))
+        assert 2 ** 12 <= np.abs(w).max() * sc[l, 0] < 2 ** 13
+        assert np.abs(w).sum(1).max() <= sc[l, 2] <= np.abs(w).sum(1).max() * 1.001
+        assert sc[l, 3] == np.abs(b).max()
+        assert np.abs(w).sum(0).max() <= sc[l, 4] <= np.abs(w).sum(0).max() * 1.001
+    for kind, stream in (("fwd", fwd), ("bwd", bwd)):
+        idx, meta, n, _ = ML.h3_plan(3, kind)
+        vals = stream.view(np.float16).astype(np.float64).reshape(-1, 512)
+        idx = idx.reshape(-1, 512)
+        acc = np.zeros(src.shape[0])
+        for f in range(n):
+            ok = idx[f] >= 0
+            np.add.at(acc, idx[f][ok], vals[f][ok] / sc[meta[f] >> 1, 0])
+            assert np.all(vals[f][~ok] == 0)
+        used = np.zeros(src.shape[0], bool)
+        used[idx[idx >= 0]] = True
+        rel = np.abs(acc[used] - src[used]) / np.maximum(np.abs(src[used]), 1e-30)
+        big = np.abs(src[used]) * 1.0 > 0           # every weight: h + l within 2^-21 of the layer's largest
+        assert big.all()
+        lim = np.zeros(src.shape[0])
+        for l in range(12):
+            lim[jobs[l, 0]: jobs[l, 0] + jobs[l, 1] * jobs[l, 2]] = 2.0 ** -21 * sc[l, 5]
+        assert np.all(np.abs(acc[used] - src[used]) <= lim[used])
+
+
+@pytest.mark.parametrize("pd", [3, 4])
+@pytest.mark.parametrize("n_rays,spr,save", [(5, 32, True), (3, 64, False)])
+def test_resident_forward_matches_oracle(n_rays, spr, save, pd):
+    lay = ML.layout(pd)
+    IN = lay.in_pts
+    p = network_params(0 if pd == 3 else 777, pd)
+    wpk = pack_forward(p, pd)
+    fwd, _, sc = pack_h3(p, pd, directions=("fwd",))
+    P = n_rays * spr
+    g = torch.Generator().manual_seed(3)
+    pts = (torch.rand(P, pd, generator=g) * 3 - 1.5)
+    vd = torch.randn(n_rays, 3, generator=g)
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+    raw = np.full((P, 4), np.nan, np.float32)
+    sv = np.full(lay.save_floats(P), np.nan, np.float32) if save else None
+    H.call("scnerf_mlp_fwd_h3", pd, pts.numpy(), vd.numpy(), 3, spr, wpk, fwd, sc, raw, sv, P, None)
+    ref = O.query_network(p, pts.reshape(n_rays, spr, pd), vd).reshape(P, 4)
+    np.testing.assert_allclose(raw, ref.numpy(), rtol=2e-5, atol=2e-5)
+    if save:
+        vps = vd[:, None, :].expand(n_rays, spr, 3).reshape(P, 3)
+        oa = oracle_activations(p, pts, vps)
+        s = save_views(sv, P, pd)
+        np.testing.assert_allclose(s["epts"][:, :IN], oa["e"].numpy(), rtol=0, atol=2e-6)
+        assert np.all(s["epts"][:, IN:] == 0)
+        np.testing.assert_allclose(s["eviews"][:, :27], oa["ev"].numpy(), rtol=0, atol=2e-6)
+        for l in range(8):
+            np.testing.assert_allclose(s["act%d" % l], oa["acts"][l].numpy(), rtol=2e-5, atol=2e-5, err_msg="act%d" % l)
+        np.testing.assert_allclose(s["feat"], oa["feat"].numpy(), rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(s["hv"], oa["hv"].numpy(), rtol=2e-5, atol=2e-5)
+        for sec, got, ntile in [(l, s["act%d" % l], 8) for l in range(8)] + [(8, s["hv"], 4)]:
+            for p_ in (0, 31, 77, P - 1):
+                wt, m = divmod(p_, 32)
+                for hh in (0, 1):
+                    words = s["mask"][sec, wt, m + 32 * hh]
+                    for t_ in range(ntile):
+                        for r in range(16):
+                            i = 16 * t_ + r
+                            bit = (int(words[i >> 5]) >> (31 - (i & 31))) & 1
+                            assert bit == int(got[p_, ML.feat_of(t_, r, hh)] > 0)
