@@ -331,6 +331,10 @@ int scnerf_h3_pack(const float* flat_params, const int* jobs, const int* idx_fwd
 int scnerf_mlp_fwd_h3(int pt_dims, const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
                       const float* wpacked, const short* stream_fwd, const float* scales, float* raw, float* save,
                       long long n_samples, void* stream);
+/* scnerf_mlp_bwd in the resident arithmetic; wpacked_bwd: the packed fp32 backward buffer (its density-head table). */
+int scnerf_mlp_bwd_h3(int pt_dims, const float* d_raw, const float* pts, const float* viewdirs, int vd_stride,
+                      int samples_per_ray, const float* wpacked_bwd, const short* stream_bwd, const float* scales,
+                      const float* save, float* grads, float* d_pts, float* d_views, long long n_samples, void* stream);
 int scnerf_coarse_stage_fwd_h3(const float* rays, int ray_stride, const float* t_vals, const float* t_rand,
                                int lindisp, const float* wpacked, const short* stream_fwd, const float* scales,
                                float* save, const float* noise, int white_bkgd, float* z, float* pts, float* raw,

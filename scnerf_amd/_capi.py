@@ -80,6 +80,7 @@ PROTOTYPES = {
     "scnerf_layer_split": [I, I, P, P, P, P, P, P, LL, P],
     "scnerf_h3_pack": [P, P, P, P, LL, P, P, LL, P, P, P, P],
     "scnerf_mlp_fwd_h3": [I, P, P, I, I, P, P, P, P, P, LL, P],
+    "scnerf_mlp_bwd_h3": [I, P, P, P, I, I, P, P, P, P, P, P, P, LL, P],
     "scnerf_coarse_stage_fwd_h3": [P, I, P, P, I, P, P, P, P, P, I, P, P, P, P, P, P, P, P, I, I, P],
 }
 

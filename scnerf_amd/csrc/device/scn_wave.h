@@ -126,6 +126,9 @@ typedef __attribute__((address_space(1))) char* global_bytes_rw;
 __device__ __forceinline__ global_bytes_rw uniform_global_rw(void* p) {
     return const_cast<global_bytes_rw>(uniform_global(p));
 }
+__device__ __forceinline__ global_bytes_rw uniform_global_rw(global_bytes_rw p) {
+    return const_cast<global_bytes_rw>(uniform_global(static_cast<global_bytes>(p)));
+}
 template <typename V>
 __device__ __forceinline__ void store_at(global_bytes_rw base, unsigned lane_off, V v) {
     *reinterpret_cast<__attribute__((address_space(1))) V*>(base + lane_off) = v;
@@ -180,6 +183,12 @@ __device__ __forceinline__ const T* uniform_ptr(const T* p) {
 __device__ __forceinline__ float max_raw(float a, float b) {
     float r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// max(x, 0) with the zero as an inline constant (max_raw(x, 0.f) would park the constant in a register)
+__device__ __forceinline__ float relu_raw(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
     return r;
 }
 // a + b as ONE v_add_f32 (plain `+` on neighbouring values is SLP-packed into v_pk_add_f32, which is slower

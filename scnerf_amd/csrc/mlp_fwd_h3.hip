@@ -37,17 +37,25 @@ __device__ __forceinline__ void store_pe_rows(const float (&e)[NS], float* __res
 }
 
 // KIND 0: ReLU + mask bits;  1: the same + the density head's dot product (layer 7);  2: linear (feature layer)
+// members only some kinds use
+struct NoDensity {};
+struct Density {
+    float sg;                  // running dot product of the density head (this lane's half of the features)
+    const float* alpha;        // its weights, LDS lane-vector table + 4 h
+    f32x4 wq;
+};
+template <bool ON> struct MaskBits { unsigned bits0, bits1, words[4]; };
+template <> struct MaskBits<false> {};
+
 template <bool TRAIN, int KIND>
-struct FwdEpi {
-    float os, s_next, am, sg;
+struct FwdEpi : std::conditional_t<KIND == 1, Density, NoDensity>, MaskBits<TRAIN && KIND != 2> {
+    float os, s_next, am;
     const float* bias;         // LDS lane-vector table of the layer, + 4 h
-    const float* alpha;        // KIND 1: the density head's weights, LDS lane-vector table + 4 h
     global_bytes_rw save;      // this wave tile's block of the layer's section (TRAIN)
     unsigned lane16;
-    f32x4 bq, wq;
+    f32x4 bq;
     float v[4];
-    unsigned hp, bits0, bits1;
-    unsigned words[4];
+    unsigned hp;
 
     template <int P, int PIECE, int SUB, int NS>
     __device__ __forceinline__ void sub(f32x16 (&acc)[2], u32x4 (&oh)[NS], u32x4 (&ol)[NS]) {
@@ -56,15 +64,15 @@ struct FwdEpi {
         static_assert(sl < NS, "operand buffer too small for this tile");
         if constexpr (SUB == 0) {
             bq = *reinterpret_cast<const f32x4*>(bias + (4 * T + q) * 8);
-            if constexpr (KIND == 1) wq = *reinterpret_cast<const f32x4*>(alpha + (4 * T + q) * 8);
-            if constexpr (PIECE == 0) { bits0 = 0u; bits1 = 0u; }
+            if constexpr (KIND == 1) this->wq = *reinterpret_cast<const f32x4*>(this->alpha + (4 * T + q) * 8);
+            if constexpr (TRAIN && KIND != 2 && PIECE == 0) { this->bits0 = 0u; this->bits1 = 0u; }
         } else if constexpr (SUB <= 4) {
             constexpr int e = SUB - 1;
             const float z = __builtin_fmaf(acc[x][4 * q + e], os, bq[e]);
-            v[e] = KIND == 2 ? z : max_raw(z, 0.f);
+            v[e] = KIND == 2 ? z : relu_raw(z);
             if constexpr (TRAIN && KIND != 2) {
-                if constexpr (x == 0) bits0 = shift_in_positive(bits0, v[e]);
-                else bits1 = shift_in_positive(bits1, v[e]);
+                if constexpr (x == 0) this->bits0 = shift_in_positive(this->bits0, v[e]);
+                else this->bits1 = shift_in_positive(this->bits1, v[e]);
             }
         } else if constexpr (SUB == 5) {
             if constexpr (KIND == 2) { am = max3_abs(am, v[0], v[1]); am = max3_abs(am, v[2], v[3]); }
@@ -82,15 +90,17 @@ struct FwdEpi {
         } else if constexpr (SUB == 10) {
             if constexpr (TRAIN) {
 #ifndef SCN_H3_NO_STORE             // (timing experiment)
-                store_stream_at(save, lane16 + (unsigned)((4 * T + q) * 1024), f32x4{v[0], v[1], v[2], v[3]});
+                // (wave-uniform base + the lane's 32-bit offset: as 64-bit per-lane pointers the eight piece bases of a
+                //  layer are hoisted into sixteen long-lived registers)
+                store_stream_at(uniform_global_rw(save + (4 * T + q) * 1024), pinned_here(lane16), f32x4{v[0], v[1], v[2], v[3]});
 #endif
             }
         } else {
             if constexpr (KIND == 1) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sg = __builtin_fmaf(wq[e], v[e], sg);
+                for (int e = 0; e < 4; ++e) this->sg = __builtin_fmaf(this->wq[e], v[e], this->sg);
             }
-            if constexpr (TRAIN && KIND != 2 && PIECE == 7) words[P] = (bits0 << 16) | bits1;
+            if constexpr (TRAIN && KIND != 2 && PIECE == 7) this->words[P] = (this->bits0 << 16) | this->bits1;
         }
     }
 };
@@ -195,15 +205,13 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
         e.os = inv_pow2(s_in) * scale_of(l, kSwInv);
         e.s_next = 1.f;
         e.am = 0.f;
-        e.sg = 0.f;
         e.bias = tab_h + 256 * l;
-        e.alpha = tab_h;
         e.save = TRAIN ? section(kSaveAct + 256 * l, 256) : nullptr;
         e.lane16 = w.lane16;
         return e;
     };
-    auto store_mask = [&](const unsigned (&words)[4], int sect) {
-        if constexpr (TRAIN) store_at(mask_block(sect), w.lane16, u32x4{words[0], words[1], words[2], words[3]});
+    auto store_mask = [&](auto& epi, int sect) {
+        if constexpr (TRAIN) store_at(mask_block(sect), w.lane16, u32x4{epi.words[0], epi.words[1], epi.words[2], epi.words[3]});
     };
 
     // ---- layer 0: the encoded point (NE slabs) -> 256; the epilogues of pairs 0 .. 2 in the open, pair 3 under layer 1
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
         tile_pair<U0, NK>(w, acc[0], operand, [&](auto sg_tag) {
             epi_slot<Pend, 3, decltype(sg_tag)::value, NEF >= 4 ? 12 : 9>(pend, acc[1], bh[X], bl[X]);
         });
-        if (pend_mask_sect >= 0) store_mask(pend.words, pend_mask_sect);
+        if constexpr (std::is_base_of_v<MaskBits<true>, Pend>) store_mask(pend, pend_mask_sect);
         // the layer's input is complete: its measured maximum bounds this layer's output
         const float am = fmaxf(amax_of(pend.am), am_floor);
         cur.s_next = scale_for(fmaxf(__builtin_fmaf(scale_of(layer, kBoundA), am, scale_of(layer, kBoundB)), bound_floor));
@@ -296,8 +304,8 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
     trunk_layer(I<0>{}, I<0>{}, I<0>{}, prev, epi7, 6, 7, 0.f, 0.f);
     FwdEpi<TRAIN, 2> epif;
     epif.os = inv_pow2(epi7.s_next) * scale_of(kLayerFeat, kSwInv);
-    epif.s_next = 1.f; epif.am = 0.f; epif.sg = 0.f;
-    epif.bias = tab_h + kTabFeat; epif.alpha = tab_h;
+    epif.s_next = 1.f; epif.am = 0.f;
+    epif.bias = tab_h + kTabFeat;
     epif.save = TRAIN ? section(kSaveFeat, 256) : nullptr;
     epif.lane16 = w.lane16;
     // (the feature vector meets the encoded view direction in the views layer: one scale for both)
@@ -314,11 +322,11 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
     }
     Relu epiv;
     epiv.os = inv_pow2(epif.s_next) * scale_of(kLayerViews, kSwInv);
-    epiv.s_next = 1.f; epiv.am = 0.f; epiv.sg = 0.f;
-    epiv.bias = tab_h + kTabViews; epiv.alpha = tab_h;
+    epiv.s_next = 1.f; epiv.am = 0.f;
+    epiv.bias = tab_h + kTabViews;
     epiv.save = TRAIN ? section(kSaveHv, 128) : nullptr;
     epiv.lane16 = w.lane16;
-    epiv.words[2] = 0u; epiv.words[3] = 0u;
+    if constexpr (TRAIN) { epiv.words[2] = 0u; epiv.words[3] = 0u; }
     {
         auto operand = [&](auto s_tag, u32x4& xh, u32x4& xl) {
             constexpr int s = decltype(s_tag)::value;
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
             epi_slot<Relu, 0, decltype(sg_tag)::value, 12>(epiv, acc[0], bh[1], bl[1]);
         });
         epi_all<Relu, 1>(epiv, acc[1], bh[1], bl[1]);
-        store_mask(epiv.words, 8);
+        store_mask(epiv, 8);
     }
 
     // ---- rgb: one output tile over the 128 views-layer activations (stream units 36 .. 39) ----
@@ -482,11 +490,15 @@ extern "C" int scnerf_mlp_fwd_h3(int pt_dims, const float* pts, const float* vie
     SCN_RETURN_IF(samples_per_ray < 1 || vd_stride < 3 || n_samples < 0 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
     if (n_samples == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+#ifdef SCN_H3_ONLY_PD3_TRAIN        // (quick experimental builds: one instantiation)
+    return launch_fwd_h3<3, true>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, stream_fwd, scales, raw, save, n_samples, st);
+#else
     if (pt_dims == 3)
         return save ? launch_fwd_h3<3, true>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, stream_fwd, scales, raw, save, n_samples, st)
                     : launch_fwd_h3<3, false>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, stream_fwd, scales, raw, save, n_samples, st);
     return save ? launch_fwd_h3<4, true>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, stream_fwd, scales, raw, save, n_samples, st)
                 : launch_fwd_h3<4, false>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, stream_fwd, scales, raw, save, n_samples, st);
+#endif
 }
 
 extern "C" int scnerf_coarse_stage_fwd_h3(const float* rays, int ray_stride, const float* t_vals, const float* t_rand,
@@ -503,6 +515,10 @@ extern "C" int scnerf_coarse_stage_fwd_h3(const float* rays, int ray_stride, con
     hipStream_t st = (hipStream_t)stream;
     constexpr unsigned lds = fwd_lds_bytes<3>();
     const long P = (long)n_rays * kCoarseSamples;
+#ifdef SCN_H3_ONLY_PD3_TRAIN
+    (void)cs; (void)st; (void)lds; (void)P;
+    return SCN_ENOSUP;
+#else
     if (save) {
         SCN_LDS_OPT_IN((mlp_fwd_h3_kernel<3, true, true>), lds);
         hipLaunchKernelGGL((mlp_fwd_h3_kernel<3, true, true>), dim3(scn_ceil_div(P, kSamplesPerBlock)), dim3(kThreads), lds, st,
@@ -513,4 +529,5 @@ extern "C" int scnerf_coarse_stage_fwd_h3(const float* rays, int ray_stride, con
                            (const float*)nullptr, rays + 8, ray_stride, kCoarseSamples, wpacked, stream_fwd, scales, raw, save, P, cs);
     }
     return scn_launch_status();
+#endif
 }

@@ -123,7 +123,9 @@ __device__ __forceinline__ void stream_slot(Stream& ws, char* lds, unsigned tid1
     if constexpr (KAPPA == 30) block_sync();
 #ifndef SCN_H3_NO_STREAM
     if constexpr (KAPPA >= 24 && KAPPA % 3 == 0)
-        ws.stage[(KAPPA - 24) / 3] = load_f32x4(ws.g + ((KAPPA - 24) / 3) * 4096, tid16);
+        // (opaque wave-uniform base + the thread's 32-bit offset: `global_load v, v_off, s[base]`; left to itself the
+        //  compiler keeps a 64-bit per-lane pointer across the layer loop and spills it)
+        ws.stage[(KAPPA - 24) / 3] = load_f32x4(uniform_global(ws.g + ((KAPPA - 24) / 3) * 4096), pinned_here(tid16));
 #endif
     if constexpr (KAPPA == 47) {
         ws.cur = ws.next();
@@ -220,11 +222,14 @@ __device__ __forceinline__ void tile_single(Wave& w, f32x16 (&acc)[2], Operand&&
 // slots: the pair that must be done before the next layer's K loop reaches slab 12).
 template <class Epi, int P, int SIGMA, int SPP, int NS>
 __device__ __forceinline__ void epi_slot(Epi& e, f32x16 (&acc)[2], u32x4 (&oh)[NS], u32x4 (&ol)[NS]) {
-    static_assert(SPP == 12 || SPP == 9, "slots per piece");
+    static_assert(SPP == 12 || SPP == 9 || SPP == 6, "slots per piece");
     if constexpr (SIGMA < 8 * SPP) {
         constexpr int piece = SIGMA / SPP, k = SIGMA % SPP;
         if constexpr (SPP == 12) {
             e.template sub<P, piece, k>(acc, oh, ol);
+        } else if constexpr (SPP == 6) {       // (a pair of an 8-slab part: 48 slots, two sub-steps each)
+            e.template sub<P, piece, 2 * k>(acc, oh, ol);
+            e.template sub<P, piece, 2 * k + 1>(acc, oh, ol);
         } else {
             // 12 sub-steps over 9 slots: (0 1)(2)(3)(4)(5 6)(7)(8)(9)(10 11)
             constexpr int first = k == 0 ? 0 : k <= 3 ? k + 1 : k == 4 ? 5 : k + 2;

@@ -503,18 +503,20 @@ def _h3_backward(lay: "Layout") -> H3Plan:
     def rgbt(o, sl, g, e):        # contraction over the colour channel: lane half 0, elements 0 .. 2
         return po["rgb_linear.weight"] + e * (W // 2) + o if (g == 0 and e < 3 and o < W // 2) else -1
 
+    # (the parts that produce encoding gradients come FIRST within their layer: the part after them then starts with a
+    #  complete operand and the usual pending-epilogue structure carries on)
     plan.pair_part("RGBT", 4, [0], rgbt, H3_LAYER_RGB)
     hv = list(range(8))
-    plan.pair_part("VTF", 8, hv, dense_t("views_linears.0.weight", W + IN_VIEWS, ident(W), W // 2), H3_LAYER_VIEWS)
     plan.single_part("VTE", 0, hv, dense_t("views_linears.0.weight", W + IN_VIEWS,
                                             pe_rows(L_VIEWS, off=W, n_slots=E_VIEWS_SLOTS), W // 2), H3_LAYER_VIEWS)
+    plan.pair_part("VTF", 8, hv, dense_t("views_linears.0.weight", W + IN_VIEWS, ident(W), W // 2), H3_LAYER_VIEWS)
     plan.pair_part("FT", 8, trunk, dense_t("feature_linear.weight", W, ident(W), W), H3_LAYER_FEAT)
     e_tiles = 2 if pd == 3 else 4
     for l in range(7, 0, -1):
         if l == 5:
-            plan.pair_part("L5TH", 8, trunk, dense_t("pts_linears.5.weight", W + IN, ident(W, off=IN), W), 5)
             plan.pair_part("L5TE", e_tiles, trunk,
                            dense_t("pts_linears.5.weight", W + IN, pe_rows(L_PTS, pdim=pd, n_slots=lay.e_slots), W), 5)
+            plan.pair_part("L5TH", 8, trunk, dense_t("pts_linears.5.weight", W + IN, ident(W, off=IN), W), 5)
         else:
             plan.pair_part("L%dT" % l, 8, trunk, dense_t("pts_linears.%d.weight" % l, W, ident(W), W), l)
     plan.pair_part("L0T", e_tiles, trunk,

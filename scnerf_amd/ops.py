@@ -253,6 +253,58 @@ def pack_planes(flat_params: Tensor, pd: int = 3, out: Optional[Tensor] = None, 
     return out
 
 
+class ResidentWeights:
+    """What the resident arithmetic reads besides the packed fp32 tables: the two fp16 fragment streams and the
+    scale table (pack_resident)."""
+    __slots__ = ("fwd", "bwd", "scales", "pd")
+
+    def __init__(self, fwd, bwd, scales, pd):
+        self.fwd, self.bwd, self.scales, self.pd = fwd, bwd, scales, pd
+
+
+_h3_tables = {}
+
+
+def _h3_device_tables(pd: int, device):
+    key = (pd, str(device))
+    if key not in _h3_tables:
+        t = {"jobs": torch.from_numpy(np.ascontiguousarray(ML.h3_scale_jobs(pd))).to(device)}
+        for kind in ("fwd", "bwd"):
+            idx, meta, _, _ = ML.h3_plan(pd, kind)
+            t[kind] = (torch.from_numpy(idx).to(device), torch.from_numpy(meta).to(device), int(meta.shape[0]))
+        _h3_tables[key] = t
+    return _h3_tables[key]
+
+
+def pack_resident(flat_params: Tensor, pd: int = 3, out: Optional[ResidentWeights] = None, remap=None) -> ResidentWeights:
+    """flat parameter buffer (reference order) -> the fp16 fragment streams of the forward and the data-gradient chain
+    and the per-layer scale table of the resident arithmetic (csrc/mlp_h3.h); once per optimizer step.  `remap` as in
+    pack_planes."""
+    _f(flat_params, "flat_params")
+    lay = ML.layout(pd)
+    if flat_params.numel() != lay.n_params:
+        raise ValueError("expected %d parameters, got %d" % (lay.n_params, flat_params.numel()))
+    lib = _capi.load()
+    dev = flat_params.device
+    if remap is not None:
+        key = (remap[0], str(dev))
+        if key not in _canon_cache:
+            _canon_cache[key] = torch.from_numpy(np.asarray(remap[1], dtype=np.int32)).to(dev)
+        idx = _canon_cache[key]
+        canon = torch.empty(lay.n_params, dtype=torch.float32, device=dev)
+        _capi.check(lib.scnerf_gather_f32(_p(flat_params), _p(idx), _p(canon), idx.numel(), _stream()), "scnerf_gather_f32")
+        flat_params = canon
+    t = _h3_device_tables(pd, dev)
+    if out is None:
+        out = ResidentWeights(torch.empty(t["fwd"][2] * 512, dtype=torch.int16, device=dev),
+                              torch.empty(t["bwd"][2] * 512, dtype=torch.int16, device=dev),
+                              torch.empty(lib.scnerf_h3_scale_floats(), dtype=torch.float32, device=dev), pd)
+    st = lib.scnerf_h3_pack(_p(flat_params), _p(t["jobs"]), _p(t["fwd"][0]), _p(t["fwd"][1]), t["fwd"][2],
+                            _p(t["bwd"][0]), _p(t["bwd"][1]), t["bwd"][2], _p(out.fwd), _p(out.bwd), _p(out.scales), _stream())
+    _capi.check(st, "scnerf_h3_pack")
+    return out
+
+
 def _vd(viewdirs: Tensor):
     """(pointer, row stride) of a [n,3] fp32 view-direction tensor that may be a column slice
     of the packed ray batch (ray_batch[:, 8:11])."""
@@ -332,6 +384,30 @@ def mlp_fwd(pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked: Tensor
         st = _capi.load().scnerf_mlp_fwd(pd, _p(pts), vptr, vstride, int(samples_per_ray), _p(wpacked), _p(raw),
                                          _p(save), P, _stream())
     _capi.check(st, "scnerf_mlp_fwd")
+    return raw
+
+
+def mlp_fwd_resident(pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked: Tensor, rw: ResidentWeights,
+                     save: Optional[Tensor] = None) -> Tensor:
+    """mlp_fwd in the resident arithmetic: one launch, three fp16 products per product, activations register-resident
+    (csrc/mlp_fwd_h3.hip); save (training) receives the same workspace as mlp_fwd's."""
+    _f(pts, "pts"), _f(wpacked, "wpacked")
+    vptr, vstride = _vd(viewdirs)
+    pd = rw.pd
+    lay = ML.layout(pd)
+    P = pts.numel() // pd
+    if wpacked.numel() != lay.fwd_total:
+        raise ValueError("wpacked has the wrong size")
+    if save is not None:
+        _f(save, "save")
+        if save.numel() < lay.save_floats(P):
+            raise ValueError("activation workspace too small")
+    raw = torch.empty((P, 4), dtype=torch.float32, device=pts.device)
+    with PROFILE.region("mlp_fwd_h3_kernel%s/P=%d/%s" % ("" if pd == 3 else "/pd4", P, "train" if save is not None else "infer"),
+                        2 * _MAC_PER_SAMPLE[pd] * P):
+        st = _capi.load().scnerf_mlp_fwd_h3(pd, _p(pts), vptr, vstride, int(samples_per_ray), _p(wpacked), _p(rw.fwd),
+                                            _p(rw.scales), _p(raw), _p(save), P, _stream())
+    _capi.check(st, "scnerf_mlp_fwd_h3")
     return raw
 
 
@@ -440,6 +516,27 @@ def mlp_bwd(d_raw: Tensor, pts: Tensor, viewdirs: Tensor, samples_per_ray: int, 
         st = _capi.load().scnerf_mlp_bwd(pd, _p(d_raw), _p(pts), vptr, vstride, int(samples_per_ray),
                                          _p(wpacked_bwd), _p(save), _p(grads), _p(d_pts), _p(d_views), P, _stream())
     _capi.check(st, "scnerf_mlp_bwd")
+    return grads, d_pts, d_views
+
+
+def mlp_bwd_resident(d_raw: Tensor, pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked_bwd: Tensor,
+                     rw: ResidentWeights, save: Tensor):
+    """mlp_bwd in the resident arithmetic (csrc/mlp_bwd_h3.hip): one launch -> (grads workspace, d_pts, d_views)."""
+    _f(d_raw, "d_raw"), _f(pts, "pts"), _f(wpacked_bwd, "wpacked_bwd"), _f(save, "save")
+    vptr, vstride = _vd(viewdirs)
+    pd = rw.pd
+    lay = ML.layout(pd)
+    P = pts.numel() // pd
+    if wpacked_bwd.numel() != lay.bwd_total:
+        raise ValueError("wpacked_bwd has the wrong size")
+    dev = pts.device
+    grads = torch.empty(ML.grad_floats(P), dtype=torch.float32, device=dev)
+    d_pts = torch.empty((P, pd), dtype=torch.float32, device=dev)
+    d_views = torch.empty((P, 3), dtype=torch.float32, device=dev)
+    with PROFILE.region("mlp_bwd_h3_kernel%s/P=%d" % ("" if pd == 3 else "/pd4", P), 2 * _MAC_PER_SAMPLE[pd] * P):
+        st = _capi.load().scnerf_mlp_bwd_h3(pd, _p(d_raw), _p(pts), vptr, vstride, int(samples_per_ray), _p(wpacked_bwd),
+                                            _p(rw.bwd), _p(rw.scales), _p(save), _p(grads), _p(d_pts), _p(d_views), P, _stream())
+    _capi.check(st, "scnerf_mlp_bwd_h3")
     return grads, d_pts, d_views
 
 

@@ -132,6 +132,7 @@ inline unsigned long long shader_cycles() { return 0; }
 inline unsigned long long reference_ticks() { return 0; }
 typedef char* global_bytes_rw;
 inline global_bytes_rw uniform_global_rw(void* p) { return static_cast<char*>(p); }
+inline global_bytes_rw uniform_global_rw(global_bytes_rw p) { return p; }
 template <typename V>
 inline void store_at(global_bytes_rw base, unsigned lane_off, V v) { std::memcpy(base + lane_off, &v, sizeof(V)); }
 template <typename V>
@@ -195,6 +196,7 @@ inline int uniform(int v) { return v; }
 template <typename T> inline const T* uniform_ptr(const T* p) { return p; }
 inline float max_raw(float a, float b) { return a > b ? a : b; }
 inline float add_raw(float a, float b) { return a + b; }
+inline float relu_raw(float x) { return x > 0.f ? x : 0.f; }
 template <int POS> inline float keep_if_bit(float v, unsigned bits) { return ((bits >> POS) & 1u) ? v : 0.f; }
 inline unsigned shift_in_positive(unsigned bits, float v) { return bits + bits + (v > 0.f ? 1u : 0u); }
 template <int N> inline void sched_group_mfma() {}

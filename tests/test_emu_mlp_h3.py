@@ -100,3 +100,51 @@ def test_resident_forward_matches_oracle(n_rays, spr, save, pd):
                             i = 16 * t_ + r
                             bit = (int(words[i >> 5]) >> (31 - (i & 31))) & 1
                             assert bit == int(got[p_, ML.feat_of(t_, r, hh)] > 0)
+
+
+@pytest.mark.parametrize("pd", [3, 4])
+@pytest.mark.parametrize("n_rays,spr", [(5, 32), (1, 70)])
+def test_resident_dgrad_matches_autograd(n_rays, spr, pd):
+    from tests.test_emu_mlp_bwd import oracle_backward
+    from tests.emu_mlp_util import pack_backward, grad_views
+    lay = ML.layout(pd)
+    p = network_params(2 if pd == 3 else 778, pd)
+    wpk, wbk = pack_forward(p, pd), pack_backward(p, pd)
+    fwd, bwd, sc = pack_h3(p, pd)
+    P = n_rays * spr
+    g = torch.Generator().manual_seed(9)
+    pts = torch.rand(P, pd, generator=g) * 2.4 - 1.2
+    vd = torch.randn(n_rays, 3, generator=g)
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+    d_raw = torch.randn(P, 4, generator=g)
+    # per-sample magnitudes over many orders: the scales are per sample
+    d_raw = d_raw * (10.0 ** torch.randint(-12, 4, (P, 1), generator=g).float())
+    d_raw[3] = 0.0
+    raw = np.zeros((P, 4), np.float32)
+    save = np.full(lay.save_floats(P), np.nan, np.float32)
+    H.call("scnerf_mlp_fwd_h3", pd, pts.numpy(), vd.numpy(), 3, spr, wpk, fwd, sc, raw, save, P, None)
+    grads = np.full(ML.grad_floats(P), np.nan, np.float32)
+    d_pts = np.full((P, pd), np.nan, np.float32)
+    d_views = np.full((P, 3), np.nan, np.float32)
+    H.call("scnerf_mlp_bwd_h3", pd, d_raw.numpy(), pts.numpy(), vd.numpy(), 3, spr, wbk, bwd, sc, save, grads, d_pts, d_views, P, None)
+    ref = oracle_backward(p, pts, vd, spr, d_raw)
+    gv = grad_views(grads, P)
+
+    def close(a, b, what):
+        # row by row: every sample against its own size
+        scale = np.abs(b).reshape(P, -1).max(1, keepdims=True) + 1e-30
+        err = np.abs(a - b).reshape(P, -1)
+        bad = err > 3e-5 * scale + 1e-37
+        # (a ReLU gate the two sides decide differently changes whole rows: such rows are rare and checked loosely)
+        rows = bad.any(1)
+        assert rows.mean() <= 0.02, "%s: %d of %d rows off (worst %g of its row)" % (what, rows.sum(), P, float((err / scale).max()))
+
+    close(gv["dzv"], ref["dzv"].numpy(), "dzv")
+    close(gv["dfeat"], ref["dfeat"].numpy(), "dfeat")
+    for l in range(7, -1, -1):
+        close(gv["dz%d" % l], ref["dz"][l].numpy(), "dz%d" % l)
+    close(d_pts, ref["d_pts"].numpy(), "d_pts")
+    assert np.all(gv["dz0"][3] == 0) and np.all(d_pts[3] == 0)
+    got_vd = d_views.reshape(n_rays, spr, 3).sum(1)
+    sv = float(np.abs(ref["d_vd"].numpy()).max())
+    assert float(np.abs(got_vd - ref["d_vd"].numpy()).max()) <= 3e-5 * sv
