@@ -70,9 +70,9 @@ class RenderRaysFunction(torch.autograd.Function):
         flat_c = net_c.flat_parameters()
         wf_c = ops.pack_weights(flat_c, "fwd")
         save_c = ops.save_workspace(n * sc, dev) if train else None
-        # training forward with the 256-wide layers as split-arithmetic GEMMs (ops.mlp_arithmetic)
-        split = train and n > 0 and ops.mlp_arithmetic() in ("split", "half")
-        pl_c = ops.pack_planes(flat_c) if split else None
+        # what the arithmetic in force (ops.mlp_arithmetic) needs besides the packed fp32 buffer: nothing (the fused fp32
+        # kernels), the planes of the 256-wide layers (split-arithmetic GEMMs), or the resident kernels' streams
+        pl_c = ops.pack_for_arithmetic(flat_c, train) if n > 0 else None
         if sc == ops.COARSE_STAGE_SAMPLES and n > 0:
             # the whole coarse stage -- stratified depths, network, compositing -- is one launch
             z_c, pts_c, raw_c, rgb_c, disp_c, acc_c, w_c, depth_c = ops.coarse_stage_fwd(
@@ -104,7 +104,7 @@ class RenderRaysFunction(torch.autograd.Function):
         flat_f = fine_net.flat_parameters()
         wf_f = wf_c if fine_net is net_c else ops.pack_weights(flat_f, "fwd")
         save_f = ops.save_workspace(n * tot, dev) if train else None
-        pl_f = (pl_c if fine_net is net_c else ops.pack_planes(flat_f)) if split else None
+        pl_f = pl_c if fine_net is net_c else (ops.pack_for_arithmetic(flat_f, train) if n > 0 else None)
         raw_f = ops.mlp_fwd(pts_f, viewdirs, tot, wf_f, save_f, planes=pl_f).view(n, tot, 4)
         rgb_f, disp_f, acc_f, _, depth_f = ops.composite_fwd(raw_f, z_f, rays, _c(noise_f), cfg.white_bkgd,
                                                              want_weights=False)

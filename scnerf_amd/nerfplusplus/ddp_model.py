@@ -65,9 +65,8 @@ class _NerfNetFunction(torch.autograd.Function):
         save_f = ops.save_workspace(n * sf, dev, 3) if train else None
         save_b = ops.save_workspace(n * sb, dev, 4) if train else None
         # training: the 256-wide layers as split-arithmetic GEMMs (ops.mlp_arithmetic), as in the SCNeRF step
-        split = train and n > 0 and ops.mlp_arithmetic() in ("split", "half")
-        pl_f = ops.pack_planes(flat_f, 3, remap=fg_net.pack_remap()) if split else None
-        pl_b = ops.pack_planes(flat_b, 4, remap=bg_net.pack_remap()) if split else None
+        pl_f = ops.pack_for_arithmetic(flat_f, train, 3, remap=fg_net.pack_remap()) if n > 0 else None
+        pl_b = ops.pack_for_arithmetic(flat_b, train, 4, remap=bg_net.pack_remap()) if n > 0 else None
         raw_f = ops.mlp_fwd(fg_pts, views, sf, ops.pack_weights(flat_f, "fwd", pd=3, remap=fg_net.pack_remap()),
                             save_f, pd=3, planes=pl_f)
         raw_b = ops.mlp_fwd(bg_pts, views, sb, ops.pack_weights(flat_b, "fwd", pd=4, remap=bg_net.pack_remap()),

@@ -194,9 +194,10 @@ def pack_weights(flat_params: Tensor, kind: str = "fwd", out: Optional[Tensor] =
     return out
 
 
-_MLP_ARITHMETIC = [os.environ.get("SCNERF_MLP_ARITHMETIC", "half")]
-if _MLP_ARITHMETIC[0] not in ("fp32", "split", "half"):
-    raise ValueError("SCNERF_MLP_ARITHMETIC must be 'fp32', 'split' or 'half', not %r" % _MLP_ARITHMETIC[0])
+MLP_ARITHMETICS = ("fp32", "split", "half", "resident")
+_MLP_ARITHMETIC = [os.environ.get("SCNERF_MLP_ARITHMETIC", "resident")]
+if _MLP_ARITHMETIC[0] not in MLP_ARITHMETICS:
+    raise ValueError("SCNERF_MLP_ARITHMETIC must be one of %s, not %r" % ("|".join(MLP_ARITHMETICS), _MLP_ARITHMETIC[0]))
 
 
 def mlp_arithmetic(mode: Optional[str] = None) -> str:
@@ -205,13 +206,28 @@ def mlp_arithmetic(mode: Optional[str] = None) -> str:
     on the bf16 matrix pipe with exactly cut fp32 operands, six products per product (csrc/layer_split.h), between the
     fused kernels' end stages (encoding + layer 0 / heads; heads / encoded-point end); "half" -- the same, with the
     layers whose input comes with per-sample maxima (forward 2-4 and 6-8, data gradients 7^T .. 1^T) on THREE fp16
-    products: operands scaled by a power of two per sample / per layer and cut into two fp16 numbers.
+    products: operands scaled by a power of two per sample / per layer and cut into two fp16 numbers; "resident" (the
+    default) -- the WHOLE network, training and inference, forward and data gradients, as one launch each on three fp16
+    products with the activations register-resident as cut fp16 planes (csrc/mlp_h3.h): nothing is read back from the
+    activation workspace, which is only written for the weight-gradient GEMMs.
     Without an argument: the mode in force.  Environment preset: SCNERF_MLP_ARITHMETIC."""
     if mode is not None:
-        if mode not in ("fp32", "split", "half"):
-            raise ValueError("mlp_arithmetic is 'fp32', 'split' or 'half'")
+        if mode not in MLP_ARITHMETICS:
+            raise ValueError("mlp_arithmetic is one of " + ", ".join(MLP_ARITHMETICS))
         _MLP_ARITHMETIC[0] = mode
     return _MLP_ARITHMETIC[0]
+
+
+def pack_for_arithmetic(flat_params: Tensor, train: bool, pd: int = 3, remap=None):
+    """What mlp_fwd / coarse_stage_fwd / mlp_bwd take as `planes` in the arithmetic in force: None ("fp32", and
+    inference of "split" / "half": the fused fp32 kernels), the bf16 / fp16 planes of the 256-wide layers ("split",
+    "half"; training), or the ResidentWeights ("resident"; training and inference)."""
+    mode = _MLP_ARITHMETIC[0]
+    if mode == "resident":
+        return pack_resident(flat_params, pd, remap=remap)
+    if mode == "fp32" or not train:
+        return None
+    return pack_planes(flat_params, pd, remap=remap)
 
 
 _canon_cache = {}
@@ -361,6 +377,10 @@ def mlp_fwd(pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked: Tensor
         _f(save, "save")
         if save.numel() < lay.save_floats(P):
             raise ValueError("activation workspace too small")
+    if isinstance(planes, ResidentWeights):
+        if planes.pd != pd:
+            raise ValueError("resident weights of another network variant")
+        return mlp_fwd_resident(pts, viewdirs, samples_per_ray, wpacked, planes, save)
     raw = torch.empty((P, 4), dtype=torch.float32, device=pts.device)
     tag = "" if pd == 3 else "/pd4"
     if planes is not None:
@@ -440,6 +460,17 @@ def coarse_stage_fwd(rays: Tensor, t_vals: Tensor, t_rand: Optional[Tensor], lin
     depth = torch.empty((n,), dtype=torch.float32, device=dev)
     w = torch.empty((n, s), dtype=torch.float32, device=dev)
     P = n * s
+    if isinstance(planes, ResidentWeights):
+        if planes.pd != 3:
+            raise ValueError("the coarse stage samples 3-D points")
+        with PROFILE.region("mlp_fwd_h3_kernel<coarse stage>/P=%d/%s" % (P, "train" if save is not None else "infer"),
+                            2 * _MAC_PER_SAMPLE[3] * P):
+            st = _capi.load().scnerf_coarse_stage_fwd_h3(
+                _p(rays), rays.shape[1], _p(t_vals), _p(t_rand), int(bool(lindisp)), _p(wpacked), _p(planes.fwd),
+                _p(planes.scales), _p(save), _p(noise), int(bool(white_bkgd)), _p(z), _p(pts), _p(raw), _p(rgb), _p(disp),
+                _p(acc), _p(depth), _p(w), n, s, _stream())
+        _capi.check(st, "scnerf_coarse_stage_fwd_h3")
+        return z, pts, raw, rgb, disp, acc, w, depth
     if planes is not None:
         if save is None:
             raise ValueError("the split-arithmetic forward runs through the activation workspace (training mode)")
@@ -487,6 +518,10 @@ def mlp_bwd(d_raw: Tensor, pts: Tensor, viewdirs: Tensor, samples_per_ray: int, 
             save: Tensor, pd: int = 3, planes: Optional[Tensor] = None):
     """-> (grads workspace, d_pts [P,pd], d_views [P,3]).  `planes` (pack_planes): the 256-wide transposed layers
     run as split-arithmetic GEMMs."""
+    if isinstance(planes, ResidentWeights):
+        if planes.pd != pd:
+            raise ValueError("resident weights of another network variant")
+        return mlp_bwd_resident(d_raw, pts, viewdirs, samples_per_ray, wpacked_bwd, planes, save)
     _f(d_raw, "d_raw"), _f(pts, "pts"), _f(wpacked_bwd, "wpacked_bwd"), _f(save, "save")
     vptr, vstride = _vd(viewdirs)
     lay = ML.layout(pd)

@@ -28,6 +28,7 @@ def emulated_device(mlp_arithmetic="fp32"):
     ops._index_cache.clear()
     ops._wgrad_ws.clear()
     ops._amax_cache.clear()
+    ops._h3_tables.clear()
     try:
         yield
     finally:
@@ -37,3 +38,4 @@ def emulated_device(mlp_arithmetic="fp32"):
         ops._index_cache.clear()
         ops._amax_cache.clear()
         ops._wgrad_ws.clear()
+        ops._h3_tables.clear()

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 # everything the parity tests measured; tests/conftest.py writes it at the end of the session to
-# gpurun_out/parity_r02.json (travels back from the GPU box; the copy committed under profiles/ is this file)
+# gpurun_out/parity_r03.json (travels back from the GPU box; the copy committed under profiles/ is this file)
 # and to profiles/ in the tree the tests ran in
 REPORT = {}
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,7 +29,7 @@ def write_report():
         return
     merged = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "parity_r02.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "parity_r03.json")) as f:
             merged = json.load(f)
     except (OSError, ValueError):
         pass
@@ -37,7 +37,7 @@ def write_report():
     for d in ("gpurun_out", "profiles"):
         try:
             os.makedirs(os.path.join(ROOT, d), exist_ok=True)
-            with open(os.path.join(ROOT, d, "parity_r02.json"), "w") as f:
+            with open(os.path.join(ROOT, d, "parity_r03.json"), "w") as f:
                 json.dump(merged, f, indent=1, sort_keys=True)
         except OSError:
             pass
@@ -100,10 +100,9 @@ def gpu_sampling_state(ops, host_linspace, rays, net_c, t_rand, u, noise_c, sc, 
         flat = net_c.flat_parameters()
         # the same arithmetic the training forward under test used (ops.mlp_arithmetic): the coarse weights decide
         # where the fine samples go
-        split = ops.mlp_arithmetic() in ("split", "half")
-        save = ops.save_workspace(rays.shape[0] * sc, dev) if split else None
-        raw_c = ops.mlp_fwd(pts_c, rays[:, 8:11], sc, ops.pack_weights(flat, "fwd"), save,
-                            planes=ops.pack_planes(flat) if split else None)
+        planes = ops.pack_for_arithmetic(flat, True)
+        save = ops.save_workspace(rays.shape[0] * sc, dev) if planes is not None else None
+        raw_c = ops.mlp_fwd(pts_c, rays[:, 8:11], sc, ops.pack_weights(flat, "fwd"), save, planes=planes)
         rgb0, _, _, w_c, _ = ops.composite_fwd(raw_c.view(rays.shape[0], sc, 4), z_c, rays, noise_c, white_bkgd)
         z_f, _, z_s, _, inds, cdf = ops.fine_sample(rays, z_c, w_c, u, True, True)
     return dict(z_c=z_c, w_c=w_c, rgb0=rgb0, inds=inds, cdf=cdf, z_s=z_s, z_f=z_f)

@@ -139,11 +139,13 @@ def test_staged_data_gradients_equal_the_fused_chain(pd, n_rays, spr, half):
     assert float(np.abs(va - vb).max()) <= 2e-5 * float(np.abs(va).max())
 
 
-def test_render_rays_split_on_the_simt_interpreter():
-    """render_rays forward + backward through the mirrored API in the default arithmetic of the training step (forward
-    stages, layer GEMMs on three fp16 / six bf16 products with the per-sample maxima workspace, data-gradient stages,
-    bf16 weight gradients) against the same call on the fused fp32 kernels: outputs, ray gradients and every
-    parameter gradient."""
+@pytest.mark.parametrize("other", ["half", "resident"])
+def test_render_rays_split_on_the_simt_interpreter(other):
+    """render_rays forward + backward through the mirrored API in the 16-bit arithmetics of the training step ("half":
+    forward stages, layer GEMMs on three fp16 / six bf16 products with the per-sample maxima workspace, data-gradient
+    stages; "resident", the default: the fused coarse stage, the fine forward and both data-gradient chains as one
+    launch each on three fp16 products; bf16 weight gradients in both) against the same call on the fused fp32
+    kernels: outputs, ray gradients and every parameter gradient."""
     from scnerf_amd import create_nerf as cn, render, run_nerf_helpers as h, synthetic as synth
     from tests.emu.host_on_emu import emulated_device
     n, sc, sf = 3, 64, 8
@@ -152,7 +154,7 @@ def test_render_rays_split_on_the_simt_interpreter():
     from scnerf_amd import ops
     res, fine_pts = {}, {}
     orig_fwd = ops.mlp_fwd
-    for mode in ("fp32", "half"):
+    for mode in ("fp32", other):
         with emulated_device(mlp_arithmetic=mode):
             def recording_fwd(*a, **kw):                       # the fine samples this run's network saw
                 fine_pts[mode] = a[0].detach().clone()
@@ -173,10 +175,10 @@ def test_render_rays_split_on_the_simt_interpreter():
                 ops.mlp_fwd = orig_fwd
             res[mode] = (out["rgb_map"].detach().clone(), rays.grad.clone(),
                          [p.grad.clone() for net in nets for p in net.parameters()])
-    (rgb_a, gr_a, gp_a), (rgb_b, gr_b, gp_b) = res["fp32"], res["half"]
+    (rgb_a, gr_a, gp_a), (rgb_b, gr_b, gp_b) = res["fp32"], res[other]
     assert float((rgb_a - rgb_b).abs().max()) <= 2e-5
     # Same fine samples in both runs (the sampler's discontinuities did not fire on this data) ...
-    moved = (fine_pts["fp32"] - fine_pts["half"]).abs().view(n, sc + sf, 3).amax(dim=(1, 2))
+    moved = (fine_pts["fp32"] - fine_pts[other]).abs().view(n, sc + sf, 3).amax(dim=(1, 2))
     assert float(moved.max()) <= 1e-5, moved
     # ... but a pre-activation within rounding of zero may land on either side: its ReLU gate -- and with it the
     # gradient of that one sample, amplified by the encoding's 2^9 frequency -- then differs between two arithmetics

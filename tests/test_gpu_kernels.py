@@ -90,10 +90,12 @@ def _flat(p, pd=3):
     return torch.cat([p[name].reshape(-1) for name, _ in ML.layout(pd).param_shapes])
 
 
+@pytest.mark.parametrize("resident", [False, True], ids=["fused_fp32", "resident"])
 @pytest.mark.parametrize("pd", [3, 4])
 @pytest.mark.parametrize("n_rays,spr,save", [(37, 64, True), (16, 192, False)])
-def test_mlp_forward_matches_oracle(ops, n_rays, spr, save, pd):
-    """pd = 3: the SCNeRF network; pd = 4: NeRF++'s background network (points x, y, z, 1/r)."""
+def test_mlp_forward_matches_oracle(ops, n_rays, spr, save, pd, resident):
+    """pd = 3: the SCNeRF network; pd = 4: NeRF++'s background network (points x, y, z, 1/r); the fused fp32 kernel and
+    the resident-arithmetic kernel (three fp16 products, csrc/mlp_fwd_h3.hip), training and inference instantiations."""
     from tests.emu_mlp_util import network_params, oracle_activations
     lay = ML.layout(pd)
     p = network_params(0 if pd == 3 else 777, pd)
@@ -107,7 +109,8 @@ def test_mlp_forward_matches_oracle(ops, n_rays, spr, save, pd):
     vd = torch.randn(n_rays, 3, generator=g)
     vd = vd / vd.norm(dim=-1, keepdim=True)
     sv = torch.full((lay.save_floats(P),), float("nan"), device="cuda") if save else None
-    raw = ops.mlp_fwd(dev(pts), dev(vd), spr, wpk, sv, pd=pd).cpu()
+    planes = ops.pack_resident(dev(_flat(p, pd)), pd) if resident else None
+    raw = ops.mlp_fwd(dev(pts), dev(vd), spr, wpk, sv, pd=pd, planes=planes).cpu()
     ref = O.query_network(p, pts.reshape(n_rays, spr, pd), vd).reshape(P, 4)
     np.testing.assert_allclose(raw.numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
     if save:
@@ -124,9 +127,11 @@ def test_mlp_forward_matches_oracle(ops, n_rays, spr, save, pd):
         np.testing.assert_allclose(s["hv"], oa["hv"].numpy(), rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("resident", [False, True], ids=["fused_fp32", "resident"])
 @pytest.mark.parametrize("pd", [3, 4])
-def test_mlp_backward_and_weight_gradients_match_autograd(ops, pd):
-    """train forward -> dgrad -> 12 wgrad GEMMs for both network variants vs torch autograd on the oracle."""
+def test_mlp_backward_and_weight_gradients_match_autograd(ops, pd, resident):
+    """train forward -> dgrad -> 12 wgrad GEMMs for both network variants vs torch autograd on the oracle; forward and
+    data gradients on the fused fp32 kernels or on the resident-arithmetic ones."""
     from tests.emu_mlp_util import network_params
     lay = ML.layout(pd)
     p = {k: v.clone().requires_grad_(True) for k, v in network_params(4 if pd == 3 else 779, pd).items()}
@@ -139,9 +144,10 @@ def test_mlp_backward_and_weight_gradients_match_autograd(ops, pd):
     vd = (vd / vd.norm(dim=-1, keepdim=True)).requires_grad_(True)
     d_raw = torch.randn(P, 4, generator=g)
     save = ops.save_workspace(P, "cuda", pd)
-    raw = ops.mlp_fwd(dev(pts.detach()), dev(vd.detach()), spr, ops.pack_weights(flat, "fwd", pd=pd), save, pd=pd)
+    planes = ops.pack_resident(flat, pd) if resident else None
+    raw = ops.mlp_fwd(dev(pts.detach()), dev(vd.detach()), spr, ops.pack_weights(flat, "fwd", pd=pd), save, pd=pd, planes=planes)
     grads, d_pts, d_views = ops.mlp_bwd(dev(d_raw), dev(pts.detach()), dev(vd.detach()), spr,
-                                        ops.pack_weights(flat, "bwd", pd=pd), save, pd=pd)
+                                        ops.pack_weights(flat, "bwd", pd=pd), save, pd=pd, planes=planes)
     fg = ops.nerf_wgrad(save, grads, dev(d_raw), P, pd=pd).cpu().numpy()
     out = O.query_network(p, pts.reshape(n_rays, spr, pd), vd).reshape(P, 4)
     np.testing.assert_allclose(raw.cpu().numpy(), out.detach().numpy(), rtol=2e-5, atol=2e-5)
@@ -343,6 +349,114 @@ def test_split_layer_gemm_is_fp32_grade(ops):
         assert r["split"]["max"] < 1e-6, (layer, r)
         assert r["half"]["rms"] <= 2.0 * r["fp32"]["rms"] and r["half"]["max"] <= 3.0 * r["fp32"]["max"] + 1e-9, (layer, r)
         assert r["half"]["max"] < 1e-6, (layer, r)
+
+
+def test_resident_layers_are_fp32_grade(ops):
+    """Every layer of the resident-arithmetic forward (three fp16 products, per-sample scale from the row 1-norm bound;
+    csrc/mlp_h3.h) over 131 072 samples against fp64 ON ITS OWN INPUT (what the kernel saved for the layer below),
+    beside the fused fp32-MFMA kernel judged the same way: the error relative to sum |w x| + |b| must be that of the
+    exact-fp32 path (accumulation-order noise), for layer 0 (encoded point), the trunk, the skip layer, the linear
+    feature layer and the views layer alike.  Also: the scales never overflow fp16 (no inf / nan anywhere) on inputs
+    whose magnitude varies over 2^20 between samples."""
+    from tests import parity_attribution as PA
+    from tests.emu_mlp_util import network_params
+    lay = ML.layout(3)
+    p = network_params(4, 3)
+    flat = dev(_flat(p, 3))
+    n_rays, spr = 2048, 64
+    P = n_rays * spr
+    g = torch.Generator().manual_seed(8)
+    pts = torch.rand(P, 3, generator=g) * 2.4 - 1.2
+    pts[: P // 8] *= torch.exp2(torch.randint(-10, 10, (P // 8, 1), generator=g).float())      # far / tiny points
+    pts = dev(pts)
+    vd = torch.randn(n_rays, 3, generator=g)
+    vd = dev(vd / vd.norm(dim=-1, keepdim=True))
+    wf = ops.pack_weights(flat, "fwd")
+    saves = {"fp32": ops.save_workspace(P, "cuda").zero_(), "resident": ops.save_workspace(P, "cuda").zero_()}
+    raw32 = ops.mlp_fwd(pts, vd, spr, wf, saves["fp32"])
+    raw16 = ops.mlp_fwd(pts, vd, spr, wf, saves["resident"], planes=ops.pack_resident(flat))
+    assert bool(torch.isfinite(raw16).all()) and bool(torch.isfinite(saves["resident"][: lay.save_floats_per_sample * ML.padded_samples(P)]).all())
+    Pp = ML.padded_samples(P)
+    off, _ = ML.section_offsets(lay.save_sections, P)
+
+    def rows(save, name, width=256):
+        blk = save[off[name]: off[name] + width * Pp]
+        if name in ML.TILED_SECTIONS:
+            return blk.view(Pp // 32, width // 32, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(Pp, width)[:P]
+        return blk.view(Pp, width)[:P]
+
+    def layer_io(save, l):
+        e = rows(save, "epts", lay.e_width)[:, :lay.in_pts]
+        if l == "feat":
+            return rows(save, "act7"), dev(p["feature_linear.weight"]), dev(p["feature_linear.bias"]), rows(save, "feat"), False
+        if l == "views":
+            x = torch.cat([rows(save, "feat"), rows(save, "eviews", 32)[:, :27]], 1)
+            return x, dev(p["views_linears.0.weight"]), dev(p["views_linears.0.bias"]), rows(save, "hv", 128), True
+        x = e if l == 0 else (torch.cat([e, rows(save, "act4")], 1) if l == 5 else rows(save, "act%d" % (l - 1)))
+        return x, dev(p["pts_linears.%d.weight" % l]), dev(p["pts_linears.%d.bias" % l]), rows(save, "act%d" % l), True
+
+    report = {}
+    for l in (0, 1, 2, 5, 7, "feat", "views"):
+        for mode in ("fp32", "resident"):
+            x, W, b, z, relu = layer_io(saves[mode], l)
+            ref = x.double() @ W.double().T + b.double()
+            if relu:
+                ref = torch.relu(ref)
+            scale = x.double().abs() @ W.double().abs().T + b.double().abs()
+            e = (z.double() - ref).abs() / scale
+            report.setdefault("layer_%s" % l, {})[mode] = {"max": float(e.max()), "rms": float((e * e).mean().sqrt())}
+    e_raw = (raw16 - raw32).abs().max(1)[0] / raw32.abs().max(1)[0].clamp_min(1.0)
+    report["raw_vs_fused_fp32_relative_max"] = float(e_raw.max())
+    PA.REPORT["resident_layer_arithmetic_131072_samples_error_over_sum_abs_products_vs_fp64"] = report
+    for layer, r in report.items():
+        if not isinstance(r, dict):
+            continue
+        assert r["resident"]["rms"] <= 2.0 * r["fp32"]["rms"] and r["resident"]["max"] <= 3.0 * r["fp32"]["max"] + 1e-9, (layer, r)
+        assert r["resident"]["max"] < 1e-6, (layer, r)
+    assert report["raw_vs_fused_fp32_relative_max"] <= 2e-5, report
+
+
+def test_resident_data_gradients_follow_the_fused_chain_row_by_row(ops):
+    """The resident data-gradient chain against the fused fp32 chain on the SAME saved activations, with every
+    sample's incoming gradient scaled by its own power of ten between 1e-30 and 1e+10 (and some exactly zero): every
+    gradient section agrees row by row to 2e-5 of the row's size -- the per-sample scales carry forty orders of
+    magnitude -- and zero rows stay exactly zero."""
+    from tests.emu_mlp_util import network_params
+    lay = ML.layout(3)
+    p = network_params(4, 3)
+    flat = dev(_flat(p, 3))
+    n_rays, spr = 1024, 192
+    P = n_rays * spr
+    g = torch.Generator().manual_seed(18)
+    pts = dev(torch.rand(P, 3, generator=g) * 2.4 - 1.2)
+    vd = torch.randn(n_rays, 3, generator=g)
+    vd = dev(vd / vd.norm(dim=-1, keepdim=True))
+    d_raw = torch.randn(P, 4, generator=g) * 10.0 ** torch.randint(-30, 11, (P, 1), generator=g).float()
+    d_raw[::97] = 0.0
+    d_raw = dev(d_raw)
+    rw = ops.pack_resident(flat)
+    save = ops.save_workspace(P, "cuda")
+    ops.mlp_fwd(pts, vd, spr, ops.pack_weights(flat, "fwd"), save, planes=rw)
+    wb = ops.pack_weights(flat, "bwd")
+    ga, pa, va = ops.mlp_bwd(d_raw, pts, vd, spr, wb, save)
+    gb, pb, vb = ops.mlp_bwd(d_raw, pts, vd, spr, wb, save, planes=rw)
+    Pp = ML.padded_samples(P)
+    goff, _ = ML.section_offsets(ML.GRAD_SECTIONS, P)
+
+    def rows(gr, name, width):
+        return gr[goff[name]: goff[name] + width * Pp].view(Pp // 32, width // 32, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(Pp, width)[:P]
+    zero = (d_raw.abs().sum(1) == 0)
+    for name, width in ML.GRAD_SECTIONS:
+        a, b = rows(ga, name, width).double(), rows(gb, name, width).double()
+        assert bool(torch.isfinite(b).all()), name
+        size = a.abs().max(1)[0]
+        err = (a - b).abs().max(1)[0]
+        assert bool((err <= 2e-5 * size + 1e-45).all()), (name, float((err / size.clamp_min(1e-300)).max()))
+        assert bool((b[zero] == 0).all()), name
+    for a, b, what in ((pa, pb, "d pts"), (va, vb, "d viewdirs")):
+        size = a.double().abs().max(1)[0]
+        err = (a.double() - b.double()).abs().max(1)[0]
+        assert bool((err <= 1e-4 * size + 1e-45).all()), (what, float((err / size.clamp_min(1e-300)).max()))
 
 
 def test_profiled_piecewise_launches_equal_the_single_calls(ops):

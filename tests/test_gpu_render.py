@@ -67,14 +67,14 @@ def rays_within(got, ref, tol):
     return float((e <= tol).mean()), float(e.max())
 
 
-@pytest.fixture(params=["split", "fp32", "half"])
+@pytest.fixture(params=["split", "fp32", "half", "resident"])
 def arithmetic(request):
     """the golden render_rays cases run in both arithmetic modes of the training step (ops.mlp_arithmetic /
     ops.wgrad_arithmetic): the default split-arithmetic layer GEMMs and the all-fp32-MFMA kernels"""
     from scnerf_amd import ops
     saved = (ops.mlp_arithmetic(), ops.wgrad_arithmetic())
     ops.mlp_arithmetic(request.param)
-    ops.wgrad_arithmetic("split" if request.param == "half" else request.param)
+    ops.wgrad_arithmetic("fp32" if request.param == "fp32" else "split")
     yield request.param
     ops.mlp_arithmetic(saved[0])
     ops.wgrad_arithmetic(saved[1])
@@ -254,8 +254,29 @@ def test_run_network_matches_oracle_with_grads(R):
         grad_close(prm.grad, p[name].grad.numpy(), name, q=0.999, tol_q=1e-3)
 
 
-def test_headline_size_against_oracle(R):
-    """4096 rays x (64 + 128): the BASELINE.json configuration, against the CPU oracle on the same seeded inputs.
+_HEADLINE_ORACLE = {}
+
+
+def _headline_oracle(n, sc, sf):
+    """fp32 and fp64 runs of the CPU oracle on the headline inputs (shared by the arithmetics under test)"""
+    if not _HEADLINE_ORACLE:
+        pc, pf = synth.network_params(seed=0), synth.network_params(seed=1)
+        rays = synth.ray_batch(n, seed=1)
+        rnd = synth.render_randoms(n, sc, sf, seed=3)
+        torch.set_num_threads(max(1, min(64, torch.get_num_threads())))
+        with torch.no_grad():
+            o32 = O.render_rays(rays, pc, pf, sc, sf, rnd["t_rand"], rnd["u"], rnd["noise_c"], rnd["noise_f"], rowsum="aten")
+            dd = lambda d_: {k: v.double() for k, v in d_.items()}
+            o64 = O.render_rays(rays.double(), dd(pc), dd(pf), sc, sf, rnd["t_rand"].double(), rnd["u"].double(),
+                                rnd["noise_c"].double(), rnd["noise_f"].double())
+        _HEADLINE_ORACLE.update(o32=o32, o64=o64)
+    return _HEADLINE_ORACLE["o32"], _HEADLINE_ORACLE["o64"]
+
+
+@pytest.mark.parametrize("mode", ["resident", "half", "split", "fp32"])
+def test_headline_size_against_oracle(R, mode):
+    """4096 rays x (64 + 128): the BASELINE.json configuration, against the CPU oracle on the same seeded inputs, in
+    every arithmetic of the training step (the report carries the moved-ray counts of each).
 
     Coarse outputs: every ray within 1e-4.  Fine outputs (rgb, acc absolute; disparity relative): every ray whose
     128 new samples sit where the oracle puts them is within 1e-4; each ray beyond the bar owns a sample the
@@ -263,20 +284,23 @@ def test_headline_size_against_oracle(R):
     fp32 sides, tests/parity_attribution.py) -- and re-rendering exactly those rays' fine stage on the GPU from the
     ORACLE's merged depths brings every one of them within 1e-4.  The distribution goes to profiles/parity_r02.json."""
     from scnerf_amd.functional import host_linspace
+    saved_mode = R["ops"].mlp_arithmetic()
+    R["ops"].mlp_arithmetic(mode)
+    try:
+        _headline_case(R, mode, host_linspace)
+    finally:
+        R["ops"].mlp_arithmetic(saved_mode)
+
+
+def _headline_case(R, mode, host_linspace):
     n, sc, sf = 4096, 64, 128
     net_c, net_f = make_net(R, 0), make_net(R, 1)
-    pc, pf = synth.network_params(seed=0), synth.network_params(seed=1)
     rays = synth.ray_batch(n, seed=1)
     rnd = synth.render_randoms(n, sc, sf, seed=3)
     rnd_d = {k: v.cuda() for k, v in rnd.items()}
     ret = R["render"].render_rays(rays.cuda(), net_c, make_query(R), sc, retraw=True, perturb=1.0,
                                   N_importance=sf, network_fine=net_f, raw_noise_std=1.0, _randoms=rnd_d)
-    torch.set_num_threads(max(1, min(64, torch.get_num_threads())))
-    with torch.no_grad():
-        o32 = O.render_rays(rays, pc, pf, sc, sf, rnd["t_rand"], rnd["u"], rnd["noise_c"], rnd["noise_f"], rowsum="aten")
-        dd = lambda d_: {k: v.double() for k, v in d_.items()}
-        o64 = O.render_rays(rays.double(), dd(pc), dd(pf), sc, sf, rnd["t_rand"].double(), rnd["u"].double(),
-                            rnd["noise_c"].double(), rnd["noise_f"].double())
+    o32, o64 = _headline_oracle(n, sc, sf)
     st = PA.gpu_sampling_state(R["ops"], host_linspace, rays.cuda(), net_c, rnd_d["t_rand"], rnd_d["u"], rnd_d["noise_c"], sc)
     np.testing.assert_array_equal(st["z_c"].cpu().numpy(), o32["z_coarse"].numpy())          # stratified depths: bit-exact
     z_c = o32["z_coarse"]
@@ -287,7 +311,8 @@ def test_headline_size_against_oracle(R):
               "rays_illcond": int(cls["illcond"].sum()),
               "coarse_rerun_bit_identical": bool(torch.equal(st["rgb0"], ret["rgb0"])),
               "sample_indices_equal_fraction": float((st["inds"].cpu() == o32["inds"]).float().mean())}
-    REPORT["headline_4096x(64+128)"] = report                # filled in below; written even if an assertion trips
+    key = "headline_4096x(64+128)" + ("" if mode == "resident" else "/" + mode)      # (the default arithmetic: plain key)
+    REPORT[key] = report                                     # filled in below; written even if an assertion trips
     for name in ("rgb0", "acc0"):                                                        # coarse: strict
         err = PA.per_ray_error(ret[name], o32[name])
         report[name] = PA.summary(err, cls)
@@ -320,8 +345,8 @@ def test_headline_size_against_oracle(R):
             assert e.max() <= 1e-4, ("re-rendered from the oracle's samples", name, float(e.max()))
         report["flagged_rays_rerendered_from_oracle_samples_max"] = redo
     assert float((ret["z_std"].cpu() - o32["z_std"]).abs()[~torch.from_numpy(moved)].max()) < 1e-5
-    REPORT["headline_4096x(64+128)"] = report
-    print("\nheadline parity report:", json.dumps(report))
+    REPORT[key] = report
+    print("\nheadline parity report (%s):" % mode, json.dumps(report))
 
 
 def test_weight_gradients_accumulate_into_attached_flat_buffers(R):

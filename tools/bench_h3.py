@@ -66,6 +66,28 @@ def main():
     run("resident infer", lambda: ops.mlp_fwd_resident(pts, vd, a.spr, wpk, rw, None))
     run("pack_resident", lambda: ops.pack_resident(flat, out=rw))
 
+    # ---- data-gradient chain ----
+    d_raw = torch.randn(P, 4, generator=g).to(dev) * 1e-3
+    ops.mlp_fwd(pts, vd, a.spr, wpk, save_a)
+    run("fused fp32 dgrad", lambda: ops.mlp_bwd(d_raw, pts, vd, a.spr, wbk, save_a))
+    run("split(half) dgrad", lambda: ops.mlp_bwd(d_raw, pts, vd, a.spr, wbk, save_a, planes=planes))
+    run("resident dgrad", lambda: ops.mlp_bwd_resident(d_raw, pts, vd, a.spr, wbk, rw, save_a))
+    ga, dpa, dva = ops.mlp_bwd(d_raw, pts, vd, a.spr, wbk, save_a)
+    gb, dpb, dvb = ops.mlp_bwd_resident(d_raw, pts, vd, a.spr, wbk, rw, save_a)
+    torch.cuda.synchronize()
+    bpar = {"d_pts": {"max_abs_diff": float((dpa - dpb).abs().max()), "max": float(dpa.abs().max())},
+            "d_views": {"max_abs_diff": float((dva - dvb).abs().max()), "max": float(dva.abs().max())}}
+    goff, _ = ML.section_offsets(ML.GRAD_SECTIONS, P)
+    Ppg = ML.padded_samples(P)
+    for name, wd in ML.GRAD_SECTIONS:
+        xa = ga[goff[name]: goff[name] + wd * Ppg]
+        xb = gb[goff[name]: goff[name] + wd * Ppg]
+        bpar[name] = {"max_abs_diff": float((xa - xb).abs().max()), "max": float(xa.abs().max()),
+                      "rms_diff": float((xa - xb).pow(2).mean().sqrt()), "rms": float(xa.pow(2).mean().sqrt())}
+    out["parity_dgrad_vs_fused_fp32"] = bpar
+    print(json.dumps(bpar, indent=1))
+    del ga, gb
+
     # parity: resident vs fused fp32 (both against each other; the oracle comparison lives in tests/)
     raw_a = ops.mlp_fwd(pts, vd, a.spr, wpk, save_a)
     raw_b = ops.mlp_fwd_resident(pts, vd, a.spr, wpk, rw, save_b)
