@@ -29,20 +29,86 @@ sys.path.insert(0, ROOT)
 FLOP_PER_SAMPLE_FWD = 2 * 593408
 S_C, S_F = 64, 128
 PEAK_F32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md "Peak FP32 (matrix)"
-PEAK_BF16_MFMA_TFLOPS = 2500.0            # ibid., dense bf16
-# the weight-gradient GEMMs in "split" arithmetic spend 6 bf16 MFMA products per fp32 product
-PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
-# ... and 3 fp16 MFMA products (same matrix-pipe rate) where the "half" arithmetic applies
-PEAK_HALF_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
+PEAK_16BIT_MFMA_TFLOPS = 2500.0           # ibid., dense bf16 / fp16
+PEAK_HBM_GBS = 8000.0                     # ibid., HBM3E spec (6290 measured with a float4 copy)
+MEASURED_HBM_GBS = 6290.0
 
 
-def _layer_region_peak(name):
-    """ceiling of a `layer_split_kernel<8 layers[: n on three fp16 products]>` region: the eight layers' time at the
-    matrix pipe's dense rate, n of them at three products per product and 8 - n at six"""
+def csrc_sha16():
+    """identity of the kernel sources: a counter summary taken at other sources is refused as stale"""
+    import hashlib
+    d = os.path.join(ROOT, "scnerf_amd", "csrc")
+    h = hashlib.sha256()
+    for sub in ("", "device"):
+        dd = os.path.join(d, sub)
+        for f in sorted(os.listdir(dd)):
+            if f.endswith((".hip", ".h")):
+                h.update(f.encode() + b"\0" + open(os.path.join(dd, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def region_model(name):
+    """What a timed region must do at least, from its name: algorithmic fp32 FLOP, matrix-pipe products per fp32
+    product (None: the exact-fp32 MFMA), algorithmic HBM bytes per launch.  DESIGN.md section 5 states the per-sample
+    figures: forward 2 x 593 408 FLOP; training forward writes the activation workspace ((2528 + 72) floats per sample
+    for 3-D points) + raw, reads the point; the data-gradient chain writes the gradient workspace (2432 floats), reads
+    the ReLU bit words and d raw; the weight gradients read both workspaces."""
     import re
-    m = re.search(r": (\d) on three fp16 products", name)
-    n16 = int(m.group(1)) if m else 0
-    return 8.0 / ((8 - n16) / PEAK_SPLIT_TFLOPS + n16 / PEAK_HALF_TFLOPS)
+    from scnerf_amd import mlp_layout as ML
+    m = re.search(r"/P=(\d+)", name)
+    if not m:
+        return None
+    P = int(m.group(1))
+    pd = 4 if "/pd4" in name else 3
+    lay = ML.layout(pd)
+    mac = 593408 + (2 * 256 * 21 if pd == 4 else 0)
+    save_b = (lay.save_floats_per_sample + ML.MASK_WORDS_PER_SAMPLE) * 4
+    grad_b = ML.GRAD_FLOATS_PER_SAMPLE * 4
+    fwd_io = 4 * pd + 16                               # the point in, raw out
+    if name.startswith("mlp_fwd_h3_kernel") or name.startswith("mlp_fwd_kernel"):
+        products = 3 if "_h3_" in name else None
+        b = fwd_io + (save_b if "/train" in name else 0) + (16 if "coarse stage" in name else 0)
+        return dict(flop=2 * mac * P, products=products, bytes=b * P)
+    if name.startswith("mlp_bwd_h3_kernel") or name.startswith("mlp_bwd_kernel"):
+        return dict(flop=2 * mac * P, products=3 if "_h3_" in name else None,
+                    bytes=(grad_b + ML.MASK_WORDS_PER_SAMPLE * 4 + 16 + 4 * pd + 4 * pd + 12) * P)
+    if name.startswith("wgrad256_kernel"):
+        return dict(flop=8 * 2 * 256 * 256 * P, products=6 if "split" in name else None, bytes=16 * 256 * 4 * P)
+    if name.startswith("wgrad("):
+        # 8 of the 12 GEMMs (87 % of the FLOP) are the 256 x 256 ones; the rest runs on the fp32 MFMA
+        return dict(flop=2 * mac * P, products=None, bytes=(lay.save_floats_per_sample * 4 + grad_b) * P,
+                    mixed=(8 * 2 * 256 * 256 * P, 6))
+    if name.startswith("layer_split_kernel"):
+        m2 = re.search(r": (\d) on three fp16 products", name)
+        n16 = int(m2.group(1)) if m2 else 0
+        return dict(flop=8 * 2 * 256 * 256 * P, products=(3 * n16 + 6 * (8 - n16)) / 8.0, bytes=8 * 2 * 256 * 4 * P)
+    return None
+
+
+def floors(name, avg_ms, wgrad_split=True):
+    """both floors of a region and which one binds: MFMA (FLOP x products / dense 16-bit rate, or FLOP / the fp32 MFMA
+    rate) and HBM (algorithmic bytes / 8 TB/s)"""
+    md = region_model(name)
+    if md is None or not avg_ms:
+        return None
+    if md.get("mixed") and wgrad_split:
+        f16, pr = md["mixed"]
+        t_mfma = f16 * pr / (PEAK_16BIT_MFMA_TFLOPS * 1e12) + (md["flop"] - f16) / (PEAK_F32_MFMA_TFLOPS * 1e12)
+        pipe = "bf16 MFMA x6 on the eight 256 x 256 GEMMs, fp32 MFMA on the narrow ones"
+    elif md["products"]:
+        t_mfma = md["flop"] * md["products"] / (PEAK_16BIT_MFMA_TFLOPS * 1e12)
+        pipe = "%s MFMA x%g (fp32 operands cut into 16-bit planes, fp32 accumulate)" % (
+            "fp16" if md["products"] == 3 else "bf16" if md["products"] == 6 else "fp16 / bf16", md["products"])
+    else:
+        t_mfma = md["flop"] / (PEAK_F32_MFMA_TFLOPS * 1e12)
+        pipe = "fp32 MFMA"
+    t_hbm = md["bytes"] / (PEAK_HBM_GBS * 1e9)
+    t = avg_ms * 1e-3
+    return {"pipe": pipe, "flop_per_launch": md["flop"], "algorithmic_bytes_per_launch": md["bytes"],
+            "floor_mfma_ms": t_mfma * 1e3, "floor_hbm_ms": t_hbm * 1e3,
+            "bound": "mfma" if t_mfma >= t_hbm else "hbm", "frac_mfma": t_mfma / t, "frac_hbm": t_hbm / t,
+            "frac": max(t_mfma, t_hbm) / t,
+            "tflops": md["flop"] / t / 1e12, "gbytes_per_s": md["bytes"] / t / 1e9}
 
 
 def cpu_baseline(n_rays, iters=3):
@@ -109,26 +175,16 @@ IMG_H, IMG_W, N_CAMS = 378, 504, 17      # LLFF 'fern' at factor 8: the image si
 
 
 def _kernel_table(kern, steps):
-    """tflops = algorithmic fp32 FLOP / time; `peak` names the matrix-pipe ceiling of the arithmetic the entry
-    runs in (the wgrad group: 8 of its 12 GEMMs, 87 % of its FLOPs, are the 256 x 256 ones)"""
+    """per timed region: launches, average time, and both floors (MFMA at the dense rate of the pipe the region runs
+    on, HBM at 8 TB/s over its algorithmic bytes) with the binding one named"""
     from scnerf_amd import ops
     split = ops.wgrad_arithmetic() == "split"
     out = {}
     for k, v in kern.items():
-        e = {"avg_ms": v["avg_ms"], "launches_per_step": v["launches"] / steps,
-             "tflops": v["flop_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12 if v["flop_per_launch"] else None}
-        if e["tflops"]:
-            on_split = (split and k.startswith("wgrad(")) or "layer GEMMs" in k or k.startswith("layer_split_kernel")
-            e["peak"] = PEAK_SPLIT_TFLOPS if on_split else PEAK_F32_MFMA_TFLOPS
-            e["pipe"] = ("bf16 MFMA x6 (fp32 operands cut into 3 bf16, fp32 accumulate)" +
-                         ("; encoding + layer 0 and the heads on the fp32 MFMA" if "layer GEMMs" in k else "")) if on_split else "fp32 MFMA"
-            if k.startswith("layer_split_kernel") and "fp16" in k:
-                e["peak"] = _layer_region_peak(k)
-                e["pipe"] = ("fp16 MFMA x3 (fp32 operands scaled by a power of two per sample / layer and cut into 2 fp16, fp32 "
-                             "accumulate) on the layers named, bf16 MFMA x6 on the others")
-            elif "layer GEMMs" in k and ops.mlp_arithmetic() == "half":
-                e["pipe"] = e["pipe"].replace("bf16 MFMA x6 (fp32 operands cut into 3 bf16, fp32 accumulate)",
-                                              "fp16 MFMA x3 on 6 / 7 of the 8 layer GEMMs, bf16 MFMA x6 on the others")
+        e = {"avg_ms": v["avg_ms"], "launches_per_step": v["launches"] / steps}
+        f = floors(k, v["avg_ms"], split)
+        if f:
+            e.update(f)
         out[k] = e
     return out
 
@@ -270,11 +326,11 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=512)
     ap.add_argument("--camera", action="store_true", help="rays from the learnable camera model also at N = 1")
-    ap.add_argument("--mlp-arithmetic", choices=("split", "fp32", "half"), default=None,
-                    help="the eight 256-wide layers of the training forward and of the data-gradient chain: GEMMs over all "
-                         "samples on the 16-bit matrix pipe -- 'half' (default): three fp16 products where the input carries "
-                         "per-sample maxima, six bf16 products elsewhere; 'split': six bf16 products everywhere -- or "
-                         "'fp32': inside the fused fp32-MFMA kernels")
+    ap.add_argument("--mlp-arithmetic", choices=("resident", "split", "fp32", "half"), default=None,
+                    help="forward and data-gradient chain: 'resident' (default): the whole network as one launch each on "
+                         "three fp16 products with register-resident activations; 'half' / 'split': the eight 256-wide "
+                         "layers as GEMMs over all samples (three fp16 / six bf16 products) between the fused kernels' end "
+                         "stages; 'fp32': the fused fp32-MFMA kernels")
     ap.add_argument("--wgrad-arithmetic", choices=("split", "fp32"), default=None,
                     help="256 x 256 weight-gradient GEMMs: bf16 matrix pipe with exactly cut fp32 operands (default) "
                          "or the exact-fp32 MFMA")
@@ -337,70 +393,81 @@ def main():
         dt = float(tt.item())
     ms = dt / a.steps * 1e3
 
+    # the same K steps without the event pairs (outside the reported figure)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    ms_off = (time.perf_counter() - t0) / a.steps * 1e3
+
     if rank == 0:
         kern = ops.PROFILE.summary()
-        # dominant kernel family by total time
-        single = {k: v for k, v in kern.items() if not v["group"]}
+        table = _kernel_table(kern, a.steps)
+        # dominant kernel: the single launch with the largest time per step
+        single = {k: v for k, v in kern.items() if not v["group"] and region_model(k)}
         dom = max(single, key=lambda k: single[k]["total_ms"]) if single else None
         roof = None
         if dom:
-            k = kern[dom]
-            ach = k["flop_per_launch"] / (k["avg_ms"] * 1e-3) / 1e12
-            split_kernel = dom.startswith("layer_split_kernel")
-            peak = (_layer_region_peak(dom) if split_kernel else PEAK_F32_MFMA_TFLOPS)
-            roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak,
-                    "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            k, f = kern[dom], table[dom]
+            hbm = f["bound"] == "hbm"
+            products = region_model(dom)["products"]
+            peak = PEAK_HBM_GBS if hbm else (PEAK_16BIT_MFMA_TFLOPS / products if products else PEAK_F32_MFMA_TFLOPS)
+            ach = f["gbytes_per_s"] if hbm else f["tflops"]
+            roof = {"bound": f["bound"], "kernel": dom, "achieved": ach, "peak": peak, "unit": "GB/s" if hbm else "TFLOP/s",
+                    "frac": ach / peak, "traffic": None, "frac_mfma": f["frac_mfma"], "frac_hbm": f["frac_hbm"],
+                    "floor_mfma_ms": f["floor_mfma_ms"], "floor_hbm_ms": f["floor_hbm_ms"],
+                    "frac_hbm_of_measured_copy_rate": f["frac_hbm"] * PEAK_HBM_GBS / MEASURED_HBM_GBS,
                     "avg_launch_ms": k["avg_ms"], "launches_per_step": k["launches"] / a.steps,
-                    "flop_per_launch": k["flop_per_launch"]}
-            if split_kernel:
-                roof["peak_note"] = ("fp32 products per second; peak = dense bf16 / fp16 MFMA rate (2500) over the partial "
-                                     "products per fp32 product: 6 (three-way bf16 cut) on the layers that run on bf16, 3 "
-                                     "(two-way fp16 cut) on those the kernel name counts -- 416.7 for a pass all on bf16")
-                roof["achieved_over_fp32_mfma_peak"] = ach / PEAK_F32_MFMA_TFLOPS
-                roof["measured"] = ("HIP events around each of the launches of this size inside the timed region: one launch "
-                                    "runs the eight 256-wide layers of a pass (forward layers 1-8, or the eight transposed "
-                                    "layers of the data-gradient chain); flop_per_launch is the mean of the two")
-                roof["note"] = ("power-bound: matrix pipe busy 68-70 % of the cycles at a shader clock of 1.7 GHz, against the "
-                                "2.4 GHz the peak is quoted at (clock read inside the kernel, profiles/r02f_layer_split_lab.txt; "
-                                "counters, profiles/r02f_pmc_kernels.txt; DESIGN.md 4.2b): at the clock it is given the kernel "
-                                "delivers frac x 2.4 / 1.73 of the matrix pipe's rate")
-                if "fp16" in dom:
-                    roof["note"] = ("six (forward) / seven (data gradients) of the eight layers on three fp16 products: half the "
-                                    "matrix-pipe work of the all-bf16 pass -- the launch is bound by its non-MFMA work now "
-                                    "(epilogue 26 %, loads / cuts / scalar work in the slab loop 27 % of the cycles of an fp16 "
-                                    "layer; profiles/r02g_layer_split_lab.txt, DESIGN.md 4.2b)")
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+                    "flop_per_launch": f["flop_per_launch"], "algorithmic_bytes_per_launch": f["algorithmic_bytes_per_launch"],
+                    "pipe": f["pipe"],
+                    "peak_note": ("TFLOP/s are algorithmic fp32 products per second; the MFMA peak is the dense 16-bit rate "
+                                  "(2500) over the partial products per fp32 product (3: two-way fp16 cut, 6: three-way bf16 "
+                                  "cut), or the fp32 MFMA's 157.3; the HBM peak is the 8 TB/s spec over the ALGORITHMIC bytes "
+                                  "of the launch.  `bound` names the larger of the two floors, `frac` = that floor / the "
+                                  "measured time; frac_mfma and frac_hbm are both given"),
+                    "measured": ("HIP events on the launch stream around each launch of this kernel inside the timed region "
+                                 "(ops.PROFILE; the eight 256 x 256 weight-gradient GEMMs: events recorded by the C entry point "
+                                 "around its one launch, scnerf_wgrad_profile_events)")}
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic_r03.json")
             if os.path.isfile(pmc):
                 rec = json.load(open(pmc))
-                roof["traffic"] = rec.get(dom)
-                roof["traffic_source"] = rec.get("_source", "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command)")
+                if rec.get("_csrc_sha16") == csrc_sha16():
+                    roof["traffic"] = rec.get("bytes_per_launch", {}).get(dom)
+                    roof["traffic_source"] = rec.get("_source")
+                    if roof["traffic"]:
+                        roof["traffic_over_algorithmic"] = roof["traffic"] / f["algorithmic_bytes_per_launch"]
+                else:
+                    roof["traffic_source"] = ("profiles/pmc_traffic_r03.json was taken at other kernel sources (%s, now %s): "
+                                              "refused as stale" % (rec.get("_csrc_sha16"), csrc_sha16()))
         source = ("rays from the learnable camera model (%d views, %dx%d; configs[2..3] ray source), camera parameters "
                   "in the all-reduced flat buffer" % (N_CAMS, IMG_H, IMG_W)) if with_camera else \
             "precomputed rays of a fixed camera"
         out = {
             "metric": "rays/sec (64+128 samples/ray) train-step", "value": n * world / (ms * 1e-3),
             "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
+            "ms_per_step_events_off": ms_off,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "arithmetic": {
-                "training forward and data gradients, the eight 256-wide layers": (
-                    "per-layer GEMMs, fp32 operands cut EXACTLY into 3 bf16 numbers each (weights once per step, "
-                    "activations / gradients in registers), 6 of the 9 partial products on v_mfma_f32_32x32x16_bf16, fp32 "
-                    "accumulate; per-layer error vs fp64 1.3x the fp32 MFMA's rms (profiles/parity_r02.json "
-                    "layer_gemm_arithmetic_*; --mlp-arithmetic fp32 keeps them inside the fused fp32-MFMA kernels)")
-                if ops.mlp_arithmetic() == "split" else (
-                    "GEMMs over all samples; forward layers 2-4 and 6-8 and the data-gradient layers 7^T .. 1^T: fp32 operands "
-                    "scaled by a power of two (per sample from the maxima the producing layer leaves, per layer for the "
-                    "weights) and cut into 2 fp16 numbers, 3 partial products on v_mfma_f32_32x32x16_f16, fp32 accumulate; "
-                    "layer 1, the skip layer and feature_linear^T: 3 bf16 numbers, 6 products (--mlp-arithmetic split: "
-                    "all of them); per-layer error vs fp64 that of the fp32 MFMA (profiles/parity_r02.json "
-                    "layer_gemm_arithmetic_*)")
-                if ops.mlp_arithmetic() == "half" else "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32 (fused kernels)",
-                "encoding + layer 0, heads, inference forward, narrow weight gradients": "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32",
+                "forward and data gradients": {
+                    "resident": "the whole network as ONE launch per pass (csrc/mlp_h3.h): every operand scaled by a power of "
+                                "two (per sample from the row / column 1-norm bound x the measured input maximum; per layer for "
+                                "the weights) and cut into 2 fp16 numbers, 3 partial products on v_mfma_f32_32x32x16_f16, fp32 "
+                                "accumulate; activations register-resident from layer to layer; per-layer error vs fp64 = the "
+                                "fp32 MFMA's (profiles/parity_r03.json resident_layer_arithmetic_*)",
+                    "half": "fused fp32 end stages around GEMMs over all samples: three fp16 products where the input carries "
+                            "per-sample maxima, six bf16 products elsewhere (csrc/layer_split.h)",
+                    "split": "fused fp32 end stages around GEMMs over all samples on six bf16 products (csrc/layer_split.h)",
+                    "fp32": "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32 (fused kernels)"}[ops.mlp_arithmetic()],
                 "256x256 weight gradients": (
                     "fp32 operands cut EXACTLY into 3 bf16 numbers each, 6 of the 9 partial products on "
                     "v_mfma_f32_32x32x16_bf16, fp32 accumulate; error vs fp64 = the fp32 MFMA kernel's "
-                    "(profiles/parity_r02.json wgrad256_arithmetic_*; --wgrad-arithmetic fp32 selects the latter)")
-                if ops.wgrad_arithmetic() == "split" else "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32"},
+                    "(profiles/parity_r03.json wgrad256_arithmetic_*; --wgrad-arithmetic fp32 selects the latter)")
+                if ops.wgrad_arithmetic() == "split" else "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32",
+                "narrow weight gradients": "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32"},
+            "timed_region": ("exactly the product path: every region of `kernels` is ONE C call of the host layer between "
+                             "two HIP events on the launch stream (no piecewise re-issue); ms_per_step_events_off is the same "
+                             "loop without the events"),
             "data": "synthetic",
             "config": {"workload": "configs[1]: %d rays x (64 coarse + 128 fine), coarse+fine NeRF (D=8, W=256), "
                                    "fwd+bwd of render_rays per GPU, perturb=1, raw_noise_std=1; %s" % (n, source),
@@ -408,7 +475,7 @@ def main():
                        "parallelism": "ray-parallel x%d, 1 %s all-reduce/step of %d floats" % (
                            world, "RCCL" if a.backend == "nccl" else a.backend, int(reducer.flat.numel()))},
             "roofline": roof,
-            "kernels": _kernel_table(kern, a.steps),
+            "kernels": table,
             "step_flop_algorithmic": 3 * FLOP_PER_SAMPLE_FWD * (S_C + S_C + S_F) * n,
             "step_tflops": 3 * FLOP_PER_SAMPLE_FWD * (S_C + S_C + S_F) * n / (ms * 1e-3) / 1e12,
         }

@@ -304,6 +304,9 @@ int scnerf_layer_split(int pt_dims, int layer, const short* planes, const float*
  * whatever sgemm the build links.) */
 int scnerf_wgrad_arithmetic(int mode);
 long long scnerf_nerf_wgrad_workspace_floats(int n_chunks);
+/* Measurement hook (bench.py): two hipEvent_t (created by the caller) that the NEXT scnerf_nerf_wgrad records on its
+ * stream right before and after its one launch of the eight 256 x 256 GEMMs; cleared after use.  NULLs switch it off. */
+int scnerf_wgrad_profile_events(void* before, void* after);
  /* accumulate != 0: flat_grad += the gradients (autograd's accumulation into an attached flat .grad
  * buffer without 48 separate add kernels); 0: overwrite. */
 int scnerf_nerf_wgrad(int pt_dims, const float* save, const float* grads, const float* d_raw,
@@ -474,6 +477,12 @@ int scnerf_npp_camera_rays_bwd(const long long* select, const float* dist2, int 
 int scnerf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                      long long n, double lr, double beta1, double beta2, double eps,
                      double weight_decay, long long step, void* stream);
+/* The same with the weight decay restricted to elements [decay_lo, decay_hi) of the segment (whole tensors at the
+ * segment's end: the reference's decayed tail, :219-226, may begin at a tensor boundary that is not 16-byte aligned --
+ * e.g. rgb_linear.weight of the fine network while every camera tensor is frozen -- so the segment is not split). */
+int scnerf_adam_step_range(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                           long long n, double lr, double beta1, double beta2, double eps,
+                           double weight_decay, long long decay_lo, long long decay_hi, long long step, void* stream);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,7 @@ PROTOTYPES = {
     "scnerf_npp_camera_rays_bwd": [P, P, I, P, P, P, F, I, P, P, F, I, P, F, P, F, I, I, I, I, P, P, P, P, P, P, P,
                                    P, P, I, P],
     "scnerf_adam_step": [P, P, P, P, LL, D, D, D, D, D, LL, P],
+    "scnerf_adam_step_range": [P, P, P, P, LL, D, D, D, D, D, LL, LL, LL, P],
     "scnerf_composite_fwd": [P, P, P, I, P, I, P, P, P, P, P, I, I, P],
     "scnerf_composite_bwd": [P, P, P, I, P, I, P, P, P, P, P, P, P, I, I, P],
     "scnerf_ray_reduce": [P, P, P, P, P, I, I, I, I, P],
@@ -67,6 +68,7 @@ PROTOTYPES = {
     "scnerf_wgrad": [P, I, I, I, I, P, I, I, I, I, LL, I, P, P, I, I, P, P],
     "scnerf_vecmat": [P, P, I, LL, I, P, P, P, P],
     "scnerf_wgrad_arithmetic": [I],
+    "scnerf_wgrad_profile_events": [P, P],
     "scnerf_pack_split_planes": [I, P, P, P],
     "scnerf_mlp_fwd_split": [I, P, P, I, I, P, P, P, P, P, LL, P],
     "scnerf_mlp_fwd_stage": [I, I, P, P, I, I, P, P, P, LL, P],

@@ -390,7 +390,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
 __global__ __launch_bounds__(256) void h3_scale_kernel(const float* __restrict__ params, const int* __restrict__ jobs,
                                                        float* __restrict__ table) {
     float* red = dynamic_lds<float>();                      // 256 floats
-    const int l = blockIdx.x, tid = threadIdx.x;
+    const int l = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const float* wt = params + jobs[4 * l];
     const int rows = jobs[4 * l + 1], cols = jobs[4 * l + 2];
     const float* bs = params + jobs[4 * l + 3];
@@ -405,17 +405,21 @@ __global__ __launch_bounds__(256) void h3_scale_kernel(const float* __restrict__
         block_sync();
         return r;
     };
-    float mx = 0.f, rowsum = 0.f, colsum = 0.f, bmax = 0.f;
-    for (int r = tid; r < rows; r += 256) {
+    // a wave per row (coalesced along the row), the row's 1-norm by a fixed-order wave reduction; a thread per column
+    // (coalesced across the threads): everything in a fixed order -- the scales must not change from run to run
+    float mx = 0.f, rowsum = 0.f, bmax = 0.f;
+    for (int r = wave; r < rows; r += 4) {
         float s = 0.f;
-        for (int c = 0; c < cols; ++c) {
+        for (int c = lane; c < cols; c += 64) {
             const float a = fabsf(wt[(long)r * cols + c]);
             s += a;
             mx = fmaxf(mx, a);
         }
+        for (int o = 32; o > 0; o >>= 1) s += shfl_xor(s, o);
         rowsum = fmaxf(rowsum, s);
         bmax = fmaxf(bmax, fabsf(bs[r]));
     }
+    float colsum = 0.f;
     for (int c = tid; c < cols; c += 256) {
         float s = 0.f;
         for (int r = 0; r < rows; ++r) s += fabsf(wt[(long)r * cols + c]);
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(256) void h3_scale_kernel(const float* __restrict__
         float* t = table + l * kScaleStride;
         t[kSw] = sw;
         t[kSwInv] = scn::h3::inv_pow2(sw);
-        // (sums of up to 339 fp32 terms: a relative 2^-15 covers their rounding)
+        // (sums of up to 339 fp32 terms in any order: a relative 1e-4 covers their rounding)
         t[kBoundA] = rowsum * 1.0001f;
         t[kBoundB] = bmax;
         t[kBoundAT] = colsum * 1.0001f;

@@ -508,6 +508,9 @@ extern "C" int scnerf_nerf_param_count(int pt_dims) {
 }
 
 namespace {
+// bench.py's per-kernel timing: an event pair recorded around the next launch of the eight 256 x 256 GEMMs
+hipEvent_t g_profile_events[2] = {nullptr, nullptr};
+
 // the GEMM slabs behind the vecmat partials stay 16-byte aligned (the persistent kernel stores them as float4)
 long long vecmat_ws_floats(long long n_chunks) { return (257 * n_chunks + 3) / 4 * 4; }
 
@@ -560,8 +563,11 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
     SCN_WG(d_raw, 4, 4, 3, 0, S(kSaveHv), 128, 128, 128, 1, P, n_chunks, ws, g + V::kWRGB, 128, 0, g + V::kBRGB)
 #undef SCN_WG
     if (big.n_jobs > 0) {
+        if (g_profile_events[0]) SCN_HIP(hipEventRecord(g_profile_events[0], st));
         rc = launch_wgrad256(big, n_chunks, st);
         if (rc != 0) return rc;
+        if (g_profile_events[1]) SCN_HIP(hipEventRecord(g_profile_events[1], st));
+        g_profile_events[0] = g_profile_events[1] = nullptr;
     }
     // one launch finishes all twelve GEMMs (fixed-order sums: deterministic)
     int blocks = 0;
@@ -582,6 +588,12 @@ extern "C" int scnerf_nerf_wgrad(int pt_dims, const float* save, const float* gr
     SCN_RETURN_IF(pt_dims != 3 && pt_dims != 4, SCN_EINVAL);
     if (pt_dims == 3) return nerf_wgrad<3>(save, grads, d_raw, n_samples, n_chunks, workspace, flat_grad, accumulate, stream);
     return nerf_wgrad<4>(save, grads, d_raw, n_samples, n_chunks, workspace, flat_grad, accumulate, stream);
+}
+
+extern "C" int scnerf_wgrad_profile_events(void* before, void* after) {
+    g_profile_events[0] = (hipEvent_t)before;
+    g_profile_events[1] = (hipEvent_t)after;
+    return 0;
 }
 
 extern "C" int scnerf_wgrad_arithmetic(int mode) {

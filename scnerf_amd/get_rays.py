@@ -26,10 +26,14 @@ class _DeferredKeypointCheck:
     memory asynchronously and looked at when the NEXT ray-generation call comes in -- by then it has long
     arrived, so nothing waits.  An out-of-range batch therefore raises the reference's AssertionError one call
     late; the kernels clamp the pixel they read the noise grids at, so the late report is the only
-    difference.  `flush()` (also run by tests) waits for whatever is pending.  CPU tensors are checked at once."""
+    difference.  `flush()` waits for whatever is pending: the host layer calls it where a training loop reaches a
+    boundary anyway -- optimizer checkpoints (FusedAdam.state_dict), full-image renders (render_path) -- and at
+    interpreter exit (reported on stderr there), so the last batches of a run are checked too; the message names the
+    call it belongs to.  CPU tensors are checked at once."""
 
     def __init__(self):
         self.pending = []          # (event, pinned flag, message)
+        self.calls = 0
 
     def _raise_if_set(self, flag, message):
         assert not bool(flag.item()), message
@@ -49,15 +53,25 @@ class _DeferredKeypointCheck:
     def flush(self):
         self.poll(block=True)
 
+    def flush_at_exit(self):
+        import sys
+        try:
+            self.flush()
+        except AssertionError as e:             # (raising inside atexit would only print a traceback after the fact)
+            sys.stderr.write("scnerf_amd.get_rays: %s (found at interpreter exit)\n" % e)
+        except Exception:
+            pass
+
     def submit(self, kps_list, H, W):
         self.poll()
+        self.calls += 1
         if kps_list.numel() == 0:
             return
         xy = kps_list[:, :2]
         limit = torch.tensor([W, H], dtype=xy.dtype).to(xy.device, non_blocking=True) if not xy.is_cuda else \
             self._limit(W, H, xy)
         bad = ((xy >= limit) | (xy < 0)).any()
-        message = "key points outside the %d x %d image" % (W, H)
+        message = "key points outside the %d x %d image (ray-generation call #%d of this process)" % (W, H, self.calls)
         if not bad.is_cuda:
             self._raise_if_set(bad, message)
             return
@@ -79,6 +93,8 @@ class _DeferredKeypointCheck:
 
 
 KEYPOINT_CHECK = _DeferredKeypointCheck()
+import atexit as _atexit  # noqa: E402
+_atexit.register(KEYPOINT_CHECK.flush_at_exit)
 
 
 def _assert_inside_image(kps_list, H, W):

@@ -48,6 +48,14 @@ class _Profile:
     def region(self, name, flop=0, group=False):
         return _Profile._Region(self, name, flop, group)
 
+    def raw_pair(self, name, flop=0):
+        """two events the C side records itself (their raw handles exist once recorded here)"""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        e1.record()
+        self.records.setdefault(name, []).append((e0, e1, flop, False))
+        return e0, e1
+
     def summary(self):
         torch.cuda.synchronize()
         out = {}
@@ -604,10 +612,13 @@ def nerf_wgrad(save: Tensor, grads: Tensor, d_raw: Tensor, P: int, flat_grad: Op
         flat_grad = torch.empty(ML.layout(pd).n_params, dtype=torch.float32, device=save.device)
     elif flat_grad.numel() != ML.layout(pd).n_params or flat_grad.dtype != torch.float32 or not flat_grad.is_contiguous():
         raise ValueError("flat_grad must be a contiguous fp32 buffer of %d elements" % ML.layout(pd).n_params)
-    with PROFILE.region("wgrad(12 GEMMs + reduces)%s/P=%d" % ("" if pd == 3 else "/pd4", P),
-                        2 * _MAC_PER_SAMPLE[pd] * P, group=True):
-        if accumulate and flat_grad is None:
-            raise ValueError("accumulate needs the buffer to add to")
+    tag = "" if pd == 3 else "/pd4"
+    with PROFILE.region("wgrad(12 GEMMs + reduces)%s/P=%d" % (tag, P), 2 * _MAC_PER_SAMPLE[pd] * P, group=True):
+        inner = None
+        if PROFILE.enabled:
+            # the dominant launch inside this C call -- the eight 256 x 256 GEMMs -- between two events of its own
+            inner = PROFILE.raw_pair("wgrad256_kernel<8 GEMMs, %s>%s/P=%d" % (wgrad_arithmetic(), tag, P), 8 * 2 * 256 * 256 * P)
+            lib.scnerf_wgrad_profile_events(inner[0].cuda_event, inner[1].cuda_event)
         st = lib.scnerf_nerf_wgrad(pd, _p(save), _p(grads), _p(d_raw), P, chunks, _p(_wgrad_ws[key]),
                                    _p(flat_grad), int(bool(accumulate)), _stream())
     _capi.check(st, "scnerf_nerf_wgrad")

@@ -26,11 +26,13 @@ def decayed_lr(lrate: float, lrate_decay: float, global_step: int) -> float:
 
 
 class _Segment:
-    """A run of parameters that tile one contiguous fp32 range and share a step count and a decay flag:
-    one flat view of the parameters, one slice of the optimizer's gradient arena, one pair of moment buffers,
-    one kernel launch per step."""
+    """A run of parameters that tile one contiguous fp32 range and share a step count: one flat view of the
+    parameters, one slice of the optimizer's gradient arena, one pair of moment buffers, one kernel launch per step.
+    `decay` = (lo, hi): the element range the weight decay applies to (whole tensors; empty when lo == hi) -- a
+    decayed tail that starts in the middle of a network's buffer does NOT split the segment (the boundary need not
+    be 16-byte aligned, and a split would also break the one-buffer-per-network gradient accumulation)."""
 
-    def __init__(self, params: List[torch.nn.Parameter], decay: bool, step: int, flat_grad: torch.Tensor):
+    def __init__(self, params: List[torch.nn.Parameter], decay, step: int, flat_grad: torch.Tensor):
         self.params = params
         self.decay = decay
         self.step = step
@@ -125,28 +127,31 @@ class FusedAdam(torch.optim.Optimizer):
             decayed = set(active) if wd != 0 else set()
         else:
             decayed = set(active[len(active) - self._decay_tail:]) if self._decay_tail > 0 else set()
-        runs, cur, cur_key = [], [], None
+        runs, cur, cur_key, cur_idx = [], [], None, []
         for i, p in enumerate(plist):
             if not p.requires_grad:
                 if cur:
-                    runs.append((cur, cur_key))
-                    cur, cur_key = [], None
+                    runs.append((cur, cur_key, cur_idx))
+                    cur, cur_key, cur_idx = [], None, []
                 continue
             if not _capi.on_device(p):
                 raise RuntimeError("FusedAdam needs GPU parameters (scnerf_amd has no CPU path)")
             contiguous = bool(cur) and p.data_ptr() == cur[-1].data_ptr() + 4 * cur[-1].numel()
-            # tensors with different step counts (bias corrections differ) cannot share a launch
-            key = (p.device, i in decayed, carried[id(p)][0] if id(p) in carried else 0)
-            if cur and contiguous and cur_key == key:
+            # tensors with different step counts (bias corrections differ) cannot share a launch; neither can a
+            # decayed tensor FOLLOWED by an undecayed one (the kernel takes one decayed element range per segment)
+            key = (p.device, carried[id(p)][0] if id(p) in carried else 0)
+            gap = bool(cur) and (cur_idx[-1] in decayed) and (i not in decayed)
+            if cur and contiguous and cur_key == key and not gap:
                 cur.append(p)
+                cur_idx.append(i)
             else:
                 if cur:
-                    runs.append((cur, cur_key))
-                cur, cur_key = [p], key
+                    runs.append((cur, cur_key, cur_idx))
+                cur, cur_key, cur_idx = [p], key, [i]
         if cur:
-            runs.append((cur, cur_key))
+            runs.append((cur, cur_key, cur_idx))
         # one gradient arena; every segment's slice starts on a 16-byte boundary
-        sizes = [sum(p.numel() for p in ps) for ps, _ in runs]
+        sizes = [sum(p.numel() for p in ps) for ps, _, _ in runs]
         starts, total = [], 0
         for n in sizes:
             starts.append(total)
@@ -154,8 +159,12 @@ class FusedAdam(torch.optim.Optimizer):
         dev = runs[0][0][0].device if runs else torch.device("cpu")
         self._arena = torch.zeros(total, dtype=torch.float32, device=dev)
         segs = []
-        for (ps, key), st, n in zip(runs, starts, sizes):
-            seg = _Segment(ps, key[1], key[2], self._arena[st:st + n])
+        placed = set()
+        for (ps, key, idxs), st, n in zip(runs, starts, sizes):
+            # the decayed tensors of a run are its last ones (see `gap` above)
+            lo = sum(p.numel() for p, i in zip(ps, idxs) if i not in decayed)
+            seg = _Segment(ps, (lo, n), key[1], self._arena[st:st + n])
+            placed.update(id(p) for p in ps)
             o = 0
             for p in ps:                                  # moments follow their parameter through a rebuild
                 got = carried.get(id(p))
@@ -171,7 +180,8 @@ class FusedAdam(torch.optim.Optimizer):
                 raise RuntimeError("parameter segment is not 16-byte aligned")
             segs.append(seg)
         self._segments = segs
-        self._loaded = {}
+        # state of parameters that sit in no segment right now (frozen): kept for the day they are unfrozen
+        self._loaded = {pid: (st_, m.clone(), v.clone()) for pid, (st_, m, v) in carried.items() if pid not in placed}
         self._req = [p.requires_grad for p in plist]
 
     def segments(self):
@@ -186,6 +196,8 @@ class FusedAdam(torch.optim.Optimizer):
         """Same layout as torch.optim.Adam / the reference's CustomAdamOptimizer (`state[i] = {step,
         exp_avg, exp_avg_sq}` per parameter index that has been stepped, `param_groups`): checkpoints
         are interchangeable with the reference's (run_nerf.py:626-641, create_nerf.py:142-172)."""
+        from .get_rays import KEYPOINT_CHECK
+        KEYPOINT_CHECK.flush()                   # a checkpoint boundary: report any out-of-range key-point batch now
         self.state.clear()
         by_id = {id(p): p for p in self.param_groups[0]["params"]}
         for pid, (step, m, v) in self._per_parameter_state().items():
@@ -246,11 +258,11 @@ class FusedAdam(torch.optim.Optimizer):
             self.grad_sync.all_reduce()          # ray-parallel ranks: one collective on the arena, then step
         for s in segs:
             s.step += 1
-            wd = g["weight_decay"] if s.decay else 0.0
-            st = lib.scnerf_adam_step(s.flat_param.data_ptr(), s.flat_grad.data_ptr(), s.exp_avg.data_ptr(),
-                                      s.exp_avg_sq.data_ptr(), s.n, float(g["lr"]), float(beta1), float(beta2),
-                                      float(g["eps"]), float(wd), s.step, stream)
-            _capi.check(st, "scnerf_adam_step")
+            lo, hi = s.decay
+            st = lib.scnerf_adam_step_range(s.flat_param.data_ptr(), s.flat_grad.data_ptr(), s.exp_avg.data_ptr(),
+                                            s.exp_avg_sq.data_ptr(), s.n, float(g["lr"]), float(beta1), float(beta2),
+                                            float(g["eps"]), float(g["weight_decay"]), lo, hi, s.step, stream)
+            _capi.check(st, "scnerf_adam_step_range")
         return loss
 
 

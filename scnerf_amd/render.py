@@ -307,6 +307,8 @@ def render_path(render_poses, hwf, chunk, render_kwargs, mode, gt_imgs=None, arg
     Forward only (no activation workspaces); finished images leave the GPU through pinned buffers on a
     copy stream, so rendering image i+1 overlaps the transfer (and PNG encoding) of image i."""
     H, W, _ = hwf
+    from .get_rays import KEYPOINT_CHECK
+    KEYPOINT_CHECK.flush()          # an evaluation boundary: report any out-of-range key-point batch of the training steps
     ring = None
     rgbs, disps = [], []
     try:

@@ -193,16 +193,18 @@ class NeRF(nn.Module):
         The fused kernels encode points themselves, so this entry takes the RAW point and direction out of the
         encodings' leading columns (include_input puts them at [0:3] and [input_ch : input_ch + 3]) and evaluates
         the network on those -- exact whenever `x` IS the positional encoding of its own leading columns, which is
-        how every caller in the reference builds it (create_nerf.py:18-32); that is checked on a handful of rows
-        the first time.  Gradient: d x is placed on those leading columns (it already contains the encoding's
-        chain rule), so embed -> forward differentiates correctly end to end."""
+        how every caller in the reference builds it (create_nerf.py:18-32); that is checked on sixteen rows of EVERY
+        call (two small reductions: this entry is off the render path, which never materialises encodings), so a
+        perturbed or partly zeroed encoding raises instead of silently returning the result for other inputs.
+        Gradient: d x is placed on those leading columns ONLY (it already contains the encoding's chain rule), so
+        embed -> forward differentiates correctly end to end, while x.grad of the sin / cos columns stays zero."""
         self.require_standard()
         if x.shape[-1] != self.input_ch + self.input_ch_views:
             raise ValueError("expected %d columns, got %d" % (self.input_ch + self.input_ch_views, x.shape[-1]))
         lead = x.shape[:-1]
         flat = x.reshape(-1, x.shape[-1])
         pts, views = flat[:, 0:3], flat[:, self.input_ch:self.input_ch + 3]
-        if not getattr(self, "_forward_input_checked", False) and flat.shape[0] > 0:
+        if flat.shape[0] > 0:
             rows = flat[:: max(1, flat.shape[0] // 16)][:16].detach()
             want_p = get_embedder(ML.L_PTS, 0)[0](rows[:, 0:3].contiguous())
             want_v = get_embedder(ML.L_VIEWS, 0)[0](rows[:, self.input_ch:self.input_ch + 3].contiguous())
@@ -211,7 +213,6 @@ class NeRF(nn.Module):
             if not err <= 1e-3:
                 raise ValueError("NeRF.forward: x is not the positional encoding (multires %d / %d, include_input) of "
                                  "its own leading columns (max deviation %g)" % (ML.L_PTS, ML.L_VIEWS, err))
-            self._forward_input_checked = True
         from .create_nerf import _QueryFunction
         raw = _QueryFunction.apply(pts.reshape(-1, 1, 3), views, self, *self.ordered_parameters())
         return raw.reshape(*lead, 4)

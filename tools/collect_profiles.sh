@@ -4,7 +4,7 @@
 # 1. kernel trace of the default bench workload (per-kernel durations; --kernel-trace only)
 # 2. counters, ONE per pass (--pmc with --kernel-trace only, as the pool requires), of tools/profile_kernels.py
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -12,12 +12,12 @@ rocprofv3 --kernel-trace -d $OUT/trace -o bench -- python bench.py --steps 10 --
 python tools/rocpd_summary.py $(find $OUT/trace -name "*.db" | head -1) > $OUT/kernel_trace_bench.txt
 rm -rf $OUT/trace
 mkdir -p $OUT/pmc
-for c in GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT FETCH_SIZE WRITE_SIZE; do
+for c in GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES FETCH_SIZE WRITE_SIZE; do
   REPS=2 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc/$c -o $c -- python tools/profile_kernels.py > /dev/null 2> $OUT/pmc_$c.err
   f=$(find $OUT/pmc/$c -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/pmc/${c}_counter_collection.csv
   rm -rf $OUT/pmc/$c
 done
-python tools/pmc_summary.py $OUT/pmc > $OUT/pmc_kernels.txt
+python tools/pmc_summary.py $OUT/pmc --json $OUT/pmc_traffic_r03.json > $OUT/pmc_kernels.txt
 rm -rf $OUT/pmc
 tail -n +1 $OUT/pmc_kernels.txt | head -80

@@ -9,7 +9,48 @@ import glob
 import os
 import sys
 
-KEEP = ("mlp_fwd_kernel", "mlp_bwd_kernel", "wgrad256_kernel", "wgrad256_split_kernel", "layer_split_kernel", "wgrad_tiles_kernel", "wgrad_reduce_multi_kernel")
+KEEP = ("mlp_fwd_kernel", "mlp_bwd_kernel", "mlp_fwd_h3_kernel", "mlp_bwd_h3_kernel", "wgrad256_kernel", "wgrad256_split_kernel",
+        "layer_split_kernel", "wgrad_tiles_kernel", "wgrad_reduce_multi_kernel", "wgrad_kernel", "vecmat_kernel", "elementwise_kernel")
+
+# bench.py's region names of the kernels whose HBM traffic goes into profiles/pmc_traffic_r03.json (P = 786432)
+REGIONS = {"mlp_fwd_h3_kernel<3, true, false>": "mlp_fwd_h3_kernel/P=786432/train",
+           "mlp_fwd_h3_kernel<3, false, false>": "mlp_fwd_h3_kernel/P=786432/infer",
+           "mlp_bwd_h3_kernel<3>": "mlp_bwd_h3_kernel/P=786432",
+           "wgrad256_split_kernel<0>": "wgrad256_kernel<8 GEMMs, split>/P=786432"}
+
+
+def traffic_json(agg, out_path, source):
+    """bytes per launch = WRITE_SIZE KB x 1024 + 2 x FETCH_SIZE KB x 1024 (gfx950 tallies wide coalesced reads at half
+    their size: MI355X_MICROARCH.md, HBM section), with the calibration copy of known size beside it"""
+    import hashlib
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    def mean(k, c):
+        v = agg[k].get(c)
+        return sum(v) / len(v) if v else None
+    per, by_region = {}, {}
+    for k in agg:
+        f, w = mean(k, "FETCH_SIZE"), mean(k, "WRITE_SIZE")
+        if f is None or w is None:
+            continue
+        short = k.replace("void ", "").replace("scn::wg256s::", "")
+        per[short] = {"fetch_kb_raw": f, "write_kb": w, "bytes": int(w * 1024 + 2 * f * 1024)}
+        for pat, region in REGIONS.items():
+            if pat in short:
+                by_region[region] = per[short]["bytes"]
+    cal = [v for k, v in per.items() if "elementwise_kernel" in k]
+    rec = {"_csrc_sha16": bench.csrc_sha16(), "_source": source, "bytes_per_launch": by_region, "per_kernel": per}
+    if cal:
+        c = max(cal, key=lambda v: v["bytes"])
+        rec["calibration_copy_1GiB_read_1GiB_written"] = {
+            "fetch_kb_raw": c["fetch_kb_raw"], "write_kb": c["write_kb"],
+            "read_bytes_counted_x2_over_known": 2 * c["fetch_kb_raw"] * 1024 / float(1 << 30),
+            "write_bytes_counted_over_known": c["write_kb"] * 1024 / float(1 << 30)}
+    with open(out_path, "w") as fh:
+        json.dump(rec, fh, indent=1, sort_keys=True)
 
 
 def main():
@@ -25,6 +66,10 @@ def main():
             if key not in seen:
                 seen.add(key)
                 dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    if "--json" in sys.argv:
+        traffic_json(agg, sys.argv[sys.argv.index("--json") + 1],
+                     "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, one counter each, --kernel-trace only) of "
+                     "tools/profile_kernels.py at P = 786432 (tools/collect_profiles.sh)")
     print("# rocprofv3 --pmc summary of %s (values are per-dispatch means; counters from separate passes)" % d)
     print("# gfx950 notes (MI355X_MICROARCH.md): SQ_* cycle counters are quad-cycles summed over waves; "
           "FETCH_SIZE / WRITE_SIZE are KB; FETCH_SIZE under-reports wide coalesced reads by 2x;")
