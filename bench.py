@@ -313,7 +313,71 @@ def extras_single_gpu(w, dev, sync):
     from tools import bench_infer, bench_nerfpp
     out["full_image_inference"] = bench_infer.run(images=3)
     out["config5_nerfpp"] = bench_nerfpp.run(rays=2048, steps=5, warmup=2)
+    # the headline step with EVERYTHING on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the arithmetic of round 1
+    from scnerf_amd import ops
+    saved = (ops.mlp_arithmetic(), ops.wgrad_arithmetic())
+    try:
+        ops.mlp_arithmetic("fp32")
+        ops.wgrad_arithmetic("fp32")
+        red = FlatGradAllReduce([w["net_c"], w["net_f"]], 1)
+        ms, kern = _timed(fixed_camera_step(w, red), 5, 2, sync)
+        out["all_fp32_mfma_step"] = {"ms_per_step": ms, "rays_per_s": w["n"] / (ms * 1e-3),
+                                     "step_tflops_over_fp32_mfma_peak": 3 * FLOP_PER_SAMPLE_FWD * (S_C + S_C + S_F) * w["n"]
+                                     / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "kernels": kern}
+    finally:
+        ops.mlp_arithmetic(saved[0])
+        ops.wgrad_arithmetic(saved[1])
+    # PSNR vs reference: 300 training steps on the procedural scene against the CPU oracle's trajectory of the same run
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import psnr_trajectory
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "psnr_oracle.json")))
+        t0 = time.perf_counter()
+        curve = psnr_trajectory.run_gpu(gold["steps"], 25, saved[0])
+        want = {c["step"]: c["psnr"] for c in gold["curve"]}
+        out["psnr_vs_reference"] = {
+            "workload": "procedural scene, %d steps of %d rays x (%d + %d), Adam lr %g, identical init / batches / randoms on "
+                        "both sides; PSNR of the fine render on 2048 held-out rays (tools/psnr_trajectory.py)"
+                        % (gold["steps"], gold["n_rand"], gold["samples"][0], gold["samples"][1], gold["lr"]),
+            "arithmetic": saved[0], "final_psnr_gpu": curve[-1]["psnr"], "final_psnr_cpu_oracle": gold["final_psnr"],
+            "max_abs_psnr_difference_along_the_curve": max(abs(c["psnr"] - want[c["step"]]) for c in curve if c["step"] in want),
+            "seconds_gpu": time.perf_counter() - t0, "seconds_cpu_oracle": gold["seconds"]}
+    except Exception as e:                       # (reported, never fatal to the headline line)
+        out["psnr_vs_reference"] = {"error": repr(e)}
     return out
+
+
+def rccl_allreduce_probe(dev, n_floats, dist_mod=None):
+    """RCCL exercised on hardware in the single-GPU run too: a process group of ONE rank (backend nccl = RCCL), the
+    step's collective -- one all-reduce of the flat fp32 gradient buffer (networks + camera) -- timed over 20 calls."""
+    import torch.distributed as dist
+    own = False
+    try:
+        if not dist.is_initialized():
+            import socket
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+            s.close()
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+            own = True
+        buf = torch.zeros(n_floats, dtype=torch.float32, device=dev)
+        for _ in range(3):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            dist.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        return {"ms_per_all_reduce": e0.elapsed_time(e1) / 20, "floats": n_floats, "world_size": dist.get_world_size(),
+                "backend": dist.get_backend()}
+    except Exception as e:
+        return {"error": repr(e)}
+    finally:
+        if own and dist.is_initialized():
+            dist.destroy_process_group()
 
 
 def main():
@@ -387,10 +451,16 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     ops.PROFILE.enabled = False
+    per_rank_ms, allreduce_info = None, None
     if world > 1:
+        mine = torch.tensor([dt / a.steps * 1e3], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [float(x.item()) for x in every]
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        allreduce_info = rccl_allreduce_probe(dev, int(reducer.flat.numel()))       # the step's collective on its own
     ms = dt / a.steps * 1e3
 
     # the same K steps without the event pairs (outside the reported figure)
@@ -479,8 +549,13 @@ def main():
             "step_flop_algorithmic": 3 * FLOP_PER_SAMPLE_FWD * (S_C + S_C + S_F) * n,
             "step_tflops": 3 * FLOP_PER_SAMPLE_FWD * (S_C + S_C + S_F) * n / (ms * 1e-3) / 1e12,
         }
+        if per_rank_ms is not None:
+            out["per_rank_ms_per_step"] = per_rank_ms
+            out["all_reduce_alone"] = allreduce_info
         if world == 1 and not a.no_extras:
             out["extras"] = extras_single_gpu(w, dev, sync)
+            if a.backend == "nccl":
+                out["extras"]["rccl_allreduce_single_rank"] = rccl_allreduce_probe(dev, 1202945)
         if world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(a.cpu_rays)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -131,13 +131,27 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
     using V = Var<PD>;
     constexpr int ES = V::kES, NE = ES / 8;
     float* const save = TRAIN ? save_arg : nullptr;
-    const int lane = lane_id();
-    const int m = lane & 31, h = lane >> 5;
     const long wave_tile = (long)blockIdx.x * 4 + wave_id();
-    const long p = wave_tile * kSamplesPerWave + m;
-    const bool live = p < P;
-    const long pc = live ? p : P - 1;
     const long Ppad = padded_samples(P);
+    // Which sample a lane works on is needed at the start (the point), before the views layer (the direction) and at the
+    // end (raw, compositing): derived afresh each time from an opaque copy of the lane number -- kept alive across the
+    // trunk these 64-bit indices cost six registers of a file that is full (the coarse-stage instantiation spilled).
+    struct Lane { int lane, m, h; long p, pc; bool live; };
+    auto lane_now = [&]() {
+        Lane L;
+        L.lane = (int)pinned_here((unsigned)lane_id());
+        L.m = L.lane & 31;
+        L.h = L.lane >> 5;
+        L.p = wave_tile * kSamplesPerWave + L.m;
+        L.live = L.p < P;
+        L.pc = L.live ? L.p : P - 1;
+        return L;
+    };
+    const Lane L0 = lane_now();
+    const int lane = L0.lane, m = L0.m, h = (int)(pinned_here((unsigned)lane_id()) >> 5);
+    const long p = L0.p, pc = L0.pc;
+    const bool live = L0.live;
+    (void)m;
 
     Wave w;
     w.lds = dynamic_lds<char>();
@@ -150,15 +164,15 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
 
     // ---- the point, its encoding (parked in LDS for the skip layer), the first operand ----
     float px, py, pz, pw = 0.f;
-    auto coarse_depth_of_sample = [&]() {
-        const float* r = cs.rays + (pc >> 6) * cs.ray_stride;
-        return ray::coarse_z(r[6], r[7], cs.t_vals, (int)(pc & 63), kCoarseSamples, cs.lindisp, cs.t_rand != nullptr,
-                             cs.t_rand ? cs.t_rand[pc] : 0.f);
+    auto coarse_depth_at = [&](long q) {             // the stratified depth of sample q (cheap to redo at the end)
+        const float* r = cs.rays + (q >> 6) * cs.ray_stride;
+        return ray::coarse_z(r[6], r[7], cs.t_vals, (int)(q & 63), kCoarseSamples, cs.lindisp, cs.t_rand != nullptr,
+                             cs.t_rand ? cs.t_rand[q] : 0.f);
     };
     if constexpr (COARSE) {
         static_assert(PD == 3, "the coarse stage samples 3-D points");
         const float* r = cs.rays + (pc >> 6) * cs.ray_stride;
-        const float z = coarse_depth_of_sample();
+        const float z = coarse_depth_at(pc);
         px = r[0] + r[3] * z;
         py = r[1] + r[4] * z;
         pz = r[2] + r[5] * z;
@@ -291,7 +305,8 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
     // ---- layer 7 (its epilogue also forms the density head's dot product), then the linear feature layer ----
     float vx, vy, vz;
     {
-        const long ray = pc / samples_per_ray;
+        const Lane L = lane_now();
+        const long ray = L.pc / samples_per_ray;
         vx = viewdirs[ray * vd_stride + 0]; vy = viewdirs[ray * vd_stride + 1]; vz = viewdirs[ray * vd_stride + 2];
     }
     const float m_ev = fmaxf(fmaxf(1.f, fabsf(vx)), fmaxf(fabsf(vy), fabsf(vz)));
@@ -316,7 +331,10 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
     {
         float ev[16];
         pe_slots<3, 4, 16>(vx, vy, vz, 0.f, h, ev);
-        if (save) store_pe_rows<3, 4, 16>(ev, save + (long)kSaveEviews * Ppad, pc, 32, h, live);
+        if (save) {
+            const Lane L = lane_now();
+            store_pe_rows<3, 4, 16>(ev, save + (long)kSaveEviews * Ppad, L.pc, 32, h, L.live);
+        }
         cut8(ev, epif.s_next, vh[0], vl[0]);
         cut8(ev + 8, epif.s_next, vh[1], vl[1]);
     }
@@ -357,15 +375,16 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
     const f32x4 brgb = *reinterpret_cast<const f32x4*>(tables + kTabRgb);
     const f32x4 o = {__builtin_fmaf(accc[0][0] + accc[1][0], os_rgb, brgb[0]), __builtin_fmaf(accc[0][1] + accc[1][1], os_rgb, brgb[1]),
                      __builtin_fmaf(accc[0][2] + accc[1][2], os_rgb, brgb[2]), sigma};
-    if (live && h == 0) *reinterpret_cast<f32x4*>(raw + p * 4) = o;
+    const Lane LE = lane_now();
+    if (LE.live && LE.h == 0) *reinterpret_cast<f32x4*>(raw + LE.p * 4) = o;
     if constexpr (COARSE) {
         // the parked-encoding area of the LDS is free (last read before the skip layer)
         float* sraw = reinterpret_cast<float*>(w.lds + kStreamLds + kTableFloats * 4);      // [128 samples][4]
         float* sz = sraw + kSamplesPerBlock * 4;                                            // [128]
-        const int local = wave_id() * kSamplesPerWave + m;
-        if (h == 0) {
+        const int local = wave_id() * kSamplesPerWave + LE.m;
+        if (LE.h == 0) {
             *reinterpret_cast<f32x4*>(sraw + local * 4) = o;
-            sz[local] = coarse_depth_of_sample();
+            sz[local] = coarse_depth_at(LE.pc);
         }
         block_sync();
         if (wave_id() < kSamplesPerBlock / kCoarseSamples) {                  // one wave per ray, lane = sample
@@ -379,7 +398,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
                 *zi = sz[slot * kCoarseSamples + i];
             };
             ray::composite_ray(fetch, kCoarseSamples, norm, cs.noise ? cs.noise + ray * kCoarseSamples : nullptr,
-                               cs.white_bkgd, ray_live, lane, cs.rgb + ray * 3, cs.disp + ray, cs.acc + ray,
+                               cs.white_bkgd, ray_live, LE.lane, cs.rgb + ray * 3, cs.disp + ray, cs.acc + ray,
                                cs.depth ? cs.depth + ray : nullptr, cs.weights ? cs.weights + ray * kCoarseSamples : nullptr);
         }
     }

@@ -32,10 +32,11 @@ _host_cache = {}
 
 def host_linspace(n: int, device) -> Tensor:
     """torch.linspace(0, 1, n) computed on the HOST (the reference path under test is the CPU one
-    and ATen's CPU / GPU linspace kernels may differ in the last bit), cached per device."""
+    and ATen's CPU / GPU linspace kernels may differ in the last bit; `device="cpu"` is explicit because the reference
+    script makes CUDA the default tensor type, run_nerf.py:1046), cached per device."""
     key = (n, str(device))
     if key not in _host_cache:
-        _host_cache[key] = torch.linspace(0.0, 1.0, steps=n, dtype=torch.float32).to(device)
+        _host_cache[key] = torch.linspace(0.0, 1.0, steps=n, dtype=torch.float32, device="cpu").to(device)
     return _host_cache[key]
 
 

@@ -68,14 +68,14 @@ class _DeferredKeypointCheck:
         if kps_list.numel() == 0:
             return
         xy = kps_list[:, :2]
-        limit = torch.tensor([W, H], dtype=xy.dtype).to(xy.device, non_blocking=True) if not xy.is_cuda else \
+        limit = torch.tensor([W, H], dtype=xy.dtype, device="cpu") if not xy.is_cuda else \
             self._limit(W, H, xy)
         bad = ((xy >= limit) | (xy < 0)).any()
         message = "key points outside the %d x %d image (ray-generation call #%d of this process)" % (W, H, self.calls)
         if not bad.is_cuda:
             self._raise_if_set(bad, message)
             return
-        host = torch.empty((), dtype=torch.bool, pin_memory=True)
+        host = torch.empty((), dtype=torch.bool, device="cpu", pin_memory=True)      # (explicit: the reference script makes CUDA the default tensor type)
         host.copy_(bad, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()

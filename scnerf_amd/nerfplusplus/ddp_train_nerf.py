@@ -117,7 +117,7 @@ def sample_pdf(bins, weights, N_samples, det=False, _u=None):
     if _u is not None:
         u = _u
     elif det:
-        u = torch.linspace(0., 1., N_samples).to(bins.device)        # host linspace: CPU rounding of the knots
+        u = torch.linspace(0., 1., N_samples, device="cpu").to(bins.device)        # host linspace: CPU rounding of the knots
         u = u.view([1] * len(dots_sh) + [N_samples]).expand(dots_sh + [N_samples])
     else:
         u = torch.rand(*(dots_sh + [N_samples]), device=bins.device)
@@ -165,7 +165,7 @@ def render_single_image(rank, world_size, models, ray_sampler, chunk_size, camer
                     fg_far_depth = intersect_sphere(ray_o, ray_d)
                     step = (fg_far_depth - min_depth) / (N_samples - 1)
                     fg_depth = torch.stack([min_depth + i * step for i in range(N_samples)], dim=-1)
-                    bg_depth = torch.linspace(0., 1., N_samples).view([1] * len(dots_sh) + [N_samples]) \
+                    bg_depth = torch.linspace(0., 1., N_samples, device="cpu").view([1] * len(dots_sh) + [N_samples]) \
                         .expand(dots_sh + [N_samples]).to(device)
                 else:
                     fg_mid = .5 * (fg_depth[..., 1:] + fg_depth[..., :-1])

@@ -26,7 +26,7 @@ class Embedder(nn.Module):
         self.include_input = include_input
         self.N_freqs = N_freqs
         self.out_dim = input_dim + input_dim * N_freqs * 2
-        self.freq_bands = (2. ** torch.linspace(0., max_freq_log2, N_freqs)).numpy().tolist()
+        self.freq_bands = (2. ** torch.linspace(0., max_freq_log2, N_freqs, device="cpu")).numpy().tolist()
 
     def forward(self, input):
         raise NotImplementedError("the encoding is fused into the network kernels (scnerf_mlp_fwd)")

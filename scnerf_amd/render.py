@@ -275,7 +275,7 @@ class _HostRing:
         hosts = []
         with torch.cuda.stream(self.stream):
             for t in tensors:
-                h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                h = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
                 h.copy_(t, non_blocking=True)
                 t.record_stream(self.stream)
                 hosts.append(h)

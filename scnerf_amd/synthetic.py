@@ -237,3 +237,57 @@ def camera_model(H: int, W: int, n_cams=17, seed=4, key="pinhole_rot_noise_10k_r
         if cm.ray_o_noise.data_ptr() != cm.ray_d_noise.data_ptr():
             cm.ray_d_noise.copy_(spec["ray_d_noise"])
     return cm, spec
+
+
+# ---- a procedural scene with analytic density and colour (PSNR trajectories: tools/psnr_trajectory.py) -------------
+def procedural_field(x: Tensor, d: Tensor):
+    """density [..] and colour [.., 3] of a smooth synthetic scene at points x [.., 3] seen along unit directions d:
+    three Gaussian blobs of different colour inside the unit ball, a mild view-dependent tint."""
+    centres = torch.tensor([[0.35, 0.1, 0.0], [-0.3, -0.25, 0.2], [0.0, 0.35, -0.3]], dtype=x.dtype)
+    widths = torch.tensor([0.28, 0.22, 0.25], dtype=x.dtype)
+    peaks = torch.tensor([18.0, 25.0, 14.0], dtype=x.dtype)
+    base = torch.tensor([[0.9, 0.25, 0.2], [0.2, 0.8, 0.3], [0.25, 0.35, 0.9]], dtype=x.dtype)
+    r2 = ((x[..., None, :] - centres) ** 2).sum(-1)                       # [.., 3]
+    w = peaks * torch.exp(-0.5 * r2 / widths ** 2)
+    sigma = w.sum(-1)
+    colour = (w[..., None] * base).sum(-2) / (sigma[..., None] + 1e-9)
+    tint = 0.1 * torch.sin(3.0 * x + 2.0 * d)                             # view dependence
+    return sigma, (colour + tint).clamp(0.02, 0.98)
+
+
+def procedural_rays(n_views=24, res=32, seed=11, near=2.5, far=5.5) -> Tensor:
+    """[n_views * res * res, 11] ray batch (o, d, near, far, unit view direction): pinhole cameras on a sphere of radius
+    4 looking at the origin."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for v in range(n_views):
+        c = torch.randn(3, generator=g, dtype=torch.float64)
+        c = 4.0 * c / c.norm()
+        fwd = -c / c.norm()
+        up = torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64)
+        right = torch.linalg.cross(fwd, up)
+        right = right / right.norm()
+        up = torch.linalg.cross(right, fwd)
+        ii, jj = torch.meshgrid(torch.linspace(-0.35, 0.35, res, dtype=torch.float64),
+                                torch.linspace(-0.35, 0.35, res, dtype=torch.float64), indexing="ij")
+        d = fwd + ii[..., None] * right + jj[..., None] * up
+        d = d.reshape(-1, 3)
+        o = c.expand_as(d)
+        vd = d / d.norm(dim=-1, keepdim=True)
+        nf = torch.tensor([near, far], dtype=torch.float64).expand(d.shape[0], 2)
+        out.append(torch.cat([o, d, nf, vd], -1))
+    return torch.cat(out).float()
+
+
+def procedural_targets(rays: Tensor, n_quad=768) -> Tensor:
+    """the scene's pixel colours: the volume-rendering integral by a dense fp64 quadrature along every ray"""
+    r = rays.double()
+    o, d, near, far, vd = r[:, 0:3], r[:, 3:6], r[:, 6:7], r[:, 7:8], r[:, 8:11]
+    t = torch.linspace(0.0, 1.0, n_quad, dtype=torch.float64)
+    z = near * (1 - t) + far * t
+    pts = o[:, None, :] + d[:, None, :] * z[..., None]
+    sigma, colour = procedural_field(pts, vd[:, None, :].expand_as(pts))
+    delta = torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], 1e10)], -1) * d.norm(dim=-1, keepdim=True)
+    alpha = 1.0 - torch.exp(-sigma * delta)
+    trans = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-10], -1), -1)[:, :-1]
+    return ((alpha * trans)[..., None] * colour).sum(-2).float()

@@ -1,0 +1,58 @@
+"""The hot kernels must not spill: the built library's gfx950 code objects are disassembled and the kernels that carry
+the training step and the full-image render are required to contain no scratch_ instruction and to declare no private
+segment (a scratch reload waits on vmcnt behind every store in flight)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from scnerf_amd import _capi
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+HOT = ("mlp_fwd_h3_kernel", "mlp_bwd_h3_kernel", "wgrad256_split_kernel", "wgrad256_kernel", "wgrad_tiles_kernel")
+
+
+def _code_objects(tmp_path):
+    if not os.path.isfile(_capi.LIB_PATH):
+        from scnerf_amd.csrc import build
+        build.build(verbose=False)
+    so = os.path.join(str(tmp_path), "lib.so")
+    shutil.copy(_capi.LIB_PATH, so)
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", so], check=True, capture_output=True, cwd=str(tmp_path))
+    return sorted(os.path.join(str(tmp_path), f) for f in os.listdir(str(tmp_path)) if "amdgcn" in f)
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(LLVM, "llvm-objdump")), reason="needs the ROCm LLVM tools")
+def test_hot_kernels_have_no_scratch(tmp_path):
+    objs = _code_objects(tmp_path)
+    assert objs, "no gfx950 code object found in the library"
+    seen = {}
+    for obj in objs:
+        dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", obj], check=True,
+                             capture_output=True, text=True).stdout
+        name = None
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                name = m.group(1)
+                if any(h in name for h in HOT):
+                    seen.setdefault(name, 0)
+                continue
+            if name in seen and "scratch_" in line:
+                seen[name] += 1
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", obj], check=True, capture_output=True,
+                               text=True).stdout
+        # kernel metadata: .name / .private_segment_fixed_size pairs
+        for blk in notes.split("- .agpr_count:")[1:]:
+            nm = re.search(r"\.name:\s+(\S+)", blk)
+            pv = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
+            if nm and pv and any(h in nm.group(1) for h in HOT):
+                assert int(pv.group(1)) == 0, (nm.group(1), "private segment", pv.group(1))
+    # every variant of the resident kernels and of the big weight-gradient GEMM is there and clean
+    for want in ("mlp_fwd_h3_kernelILi3ELb1ELb0", "mlp_fwd_h3_kernelILi3ELb1ELb1", "mlp_fwd_h3_kernelILi3ELb0ELb0",
+                 "mlp_fwd_h3_kernelILi4ELb1ELb0", "mlp_bwd_h3_kernelILi3E", "mlp_bwd_h3_kernelILi4E", "wgrad256_split_kernel"):
+        assert any(want in k for k in seen), (want, sorted(seen))
+    dirty = {k: v for k, v in seen.items() if v}
+    assert not dirty, dirty
