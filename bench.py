@@ -73,11 +73,12 @@ def region_model(name):
         return dict(flop=2 * mac * P, products=3 if "_h3_" in name else None,
                     bytes=(grad_b + ML.MASK_WORDS_PER_SAMPLE * 4 + 16 + 4 * pd + 4 * pd + 12) * P)
     if name.startswith("wgrad256_kernel"):
-        return dict(flop=8 * 2 * 256 * 256 * P, products=6 if "split" in name else None, bytes=16 * 256 * 4 * P)
+        return dict(flop=8 * 2 * 256 * 256 * P, products=3 if "half" in name else 6 if "split" in name else None,
+                    bytes=16 * 256 * 4 * P)
     if name.startswith("wgrad("):
         # 8 of the 12 GEMMs (87 % of the FLOP) are the 256 x 256 ones; the rest runs on the fp32 MFMA
         return dict(flop=2 * mac * P, products=None, bytes=(lay.save_floats_per_sample * 4 + grad_b) * P,
-                    mixed=(8 * 2 * 256 * 256 * P, 6))
+                    mixed=8 * 2 * 256 * 256 * P)
     if name.startswith("layer_split_kernel"):
         m2 = re.search(r": (\d) on three fp16 products", name)
         n16 = int(m2.group(1)) if m2 else 0
@@ -85,16 +86,16 @@ def region_model(name):
     return None
 
 
-def floors(name, avg_ms, wgrad_split=True):
+def floors(name, avg_ms, wgrad_products=3):
     """both floors of a region and which one binds: MFMA (FLOP x products / dense 16-bit rate, or FLOP / the fp32 MFMA
     rate) and HBM (algorithmic bytes / 8 TB/s)"""
     md = region_model(name)
     if md is None or not avg_ms:
         return None
-    if md.get("mixed") and wgrad_split:
-        f16, pr = md["mixed"]
-        t_mfma = f16 * pr / (PEAK_16BIT_MFMA_TFLOPS * 1e12) + (md["flop"] - f16) / (PEAK_F32_MFMA_TFLOPS * 1e12)
-        pipe = "bf16 MFMA x6 on the eight 256 x 256 GEMMs, fp32 MFMA on the narrow ones"
+    if md.get("mixed") and wgrad_products:
+        f16 = md["mixed"]
+        t_mfma = f16 * wgrad_products / (PEAK_16BIT_MFMA_TFLOPS * 1e12) + (md["flop"] - f16) / (PEAK_F32_MFMA_TFLOPS * 1e12)
+        pipe = "%s on the eight 256 x 256 GEMMs, fp32 MFMA on the narrow ones" % ("fp16 MFMA x3" if wgrad_products == 3 else "bf16 MFMA x6")
     elif md["products"]:
         t_mfma = md["flop"] * md["products"] / (PEAK_16BIT_MFMA_TFLOPS * 1e12)
         pipe = "%s MFMA x%g (fp32 operands cut into 16-bit planes, fp32 accumulate)" % (
@@ -178,11 +179,11 @@ def _kernel_table(kern, steps):
     """per timed region: launches, average time, and both floors (MFMA at the dense rate of the pipe the region runs
     on, HBM at 8 TB/s over its algorithmic bytes) with the binding one named"""
     from scnerf_amd import ops
-    split = ops.wgrad_arithmetic() == "split"
+    products = {"fp32": 0, "split": 6, "half": 3 if ops.mlp_arithmetic() == "resident" else 6}[ops.wgrad_arithmetic()]
     out = {}
     for k, v in kern.items():
         e = {"avg_ms": v["avg_ms"], "launches_per_step": v["launches"] / steps}
-        f = floors(k, v["avg_ms"], split)
+        f = floors(k, v["avg_ms"], products)
         if f:
             e.update(f)
         out[k] = e
@@ -381,6 +382,10 @@ def rccl_allreduce_probe(dev, n_floats, dist_mod=None):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON record: everything else that writes to file descriptor 1 (RCCL prints a
+    # version banner there when its first communicator comes up, progress bars, ...) is sent to stderr
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -395,9 +400,10 @@ def main():
                          "three fp16 products with register-resident activations; 'half' / 'split': the eight 256-wide "
                          "layers as GEMMs over all samples (three fp16 / six bf16 products) between the fused kernels' end "
                          "stages; 'fp32': the fused fp32-MFMA kernels")
-    ap.add_argument("--wgrad-arithmetic", choices=("split", "fp32"), default=None,
-                    help="256 x 256 weight-gradient GEMMs: bf16 matrix pipe with exactly cut fp32 operands (default) "
-                         "or the exact-fp32 MFMA")
+    ap.add_argument("--wgrad-arithmetic", choices=("half", "split", "fp32"), default=None,
+                    help="256 x 256 weight-gradient GEMMs: three fp16 products with a scale per operand and workgroup chunk "
+                         "(default; with the resident kernels), six bf16 products with exactly cut fp32 operands, or the "
+                         "exact-fp32 MFMA")
     ap.add_argument("--backend", default=os.environ.get("SCNERF_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend (nccl = RCCL; gloo for a functional check of N ranks on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0 (functional check, with --backend gloo)")
@@ -529,11 +535,14 @@ def main():
                             "per-sample maxima, six bf16 products elsewhere (csrc/layer_split.h)",
                     "split": "fused fp32 end stages around GEMMs over all samples on six bf16 products (csrc/layer_split.h)",
                     "fp32": "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32 (fused kernels)"}[ops.mlp_arithmetic()],
-                "256x256 weight gradients": (
-                    "fp32 operands cut EXACTLY into 3 bf16 numbers each, 6 of the 9 partial products on "
-                    "v_mfma_f32_32x32x16_bf16, fp32 accumulate; error vs fp64 = the fp32 MFMA kernel's "
-                    "(profiles/parity_r03.json wgrad256_arithmetic_*; --wgrad-arithmetic fp32 selects the latter)")
-                if ops.wgrad_arithmetic() == "split" else "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32",
+                "256x256 weight gradients": {
+                    "half": "fp32 operands scaled by one power of two per operand and workgroup chunk (the chunk maxima come "
+                            "from the resident kernels) and cut into 2 fp16 numbers, 3 partial products on "
+                            "v_mfma_f32_32x32x16_f16, fp32 accumulate (csrc/wgrad256_half.h); error vs fp64 = the fp32 MFMA "
+                            "kernel's (profiles/parity_r03.json wgrad256_arithmetic_*)",
+                    "split": "fp32 operands cut EXACTLY into 3 bf16 numbers each, 6 of the 9 partial products on "
+                             "v_mfma_f32_32x32x16_bf16, fp32 accumulate (csrc/wgrad256_split.h)",
+                    "fp32": "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32"}[ops.wgrad_arithmetic()],
                 "narrow weight gradients": "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32"},
             "timed_region": ("exactly the product path: every region of `kernels` is ONE C call of the host layer between "
                              "two HIP events on the launch stream (no piecewise re-issue); ms_per_step_events_off is the same "
@@ -559,7 +568,8 @@ def main():
         if world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(a.cpu_rays)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if world > 1:
         dist.destroy_process_group()
 

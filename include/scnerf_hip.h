@@ -298,12 +298,25 @@ int scnerf_layer_split(int pt_dims, int layer, const short* planes, const float*
 
 /* Arithmetic of the 256 x 256 weight-gradient GEMMs (87 % of the weight-gradient FLOPs).  mode 1 (default):
  * bf16 matrix pipe, every fp32 operand cut exactly into three bf16 numbers, six partial products per product,
- * fp32 accumulation -- the error against fp64 equals the exact-fp32 kernel's; mode 0: v_mfma_f32_32x32x2_f32.
+ * fp32 accumulation -- the error against fp64 equals the exact-fp32 kernel's; mode 0: v_mfma_f32_32x32x2_f32; mode 2
+ * (the default): three fp16 products where the operands' chunk maxima are known (scnerf_nerf_wgrad_h3), else as 1.
  * Any other value only queries.  Returns the mode in force.  Environment preset:
  * SCNERF_WGRAD_ARITHMETIC=fp32 | split.  (No reference counterpart: torch.autograd computes these GEMMs with
  * whatever sgemm the build links.) */
 int scnerf_wgrad_arithmetic(int mode);
 long long scnerf_nerf_wgrad_workspace_floats(int n_chunks);
+/* scnerf_nerf_wgrad with the eight 256 x 256 GEMMs on THREE fp16 products (csrc/wgrad256_half.h) when the chunk maxima
+ * of their operands are given -- amax_x / amax_z [8][n_chunks], left by scnerf_mlp_fwd_h3 / scnerf_coarse_stage_fwd_h3
+ * and scnerf_mlp_bwd_h3 for the same n_chunks -- and the arithmetic in force is 2 (the default); otherwise as
+ * scnerf_nerf_wgrad.  scnerf_wgrad_chunk_samples: the samples per workgroup chunk both sides use.
+ * scnerf_wgrad256_half: one such GEMM with given maxima [n_chunks] (accuracy tests); workspace n_chunks * (65536 + 256). */
+long long scnerf_wgrad_chunk_samples(long long n_samples, int n_chunks);
+int scnerf_nerf_wgrad_h3(int pt_dims, const float* save, const float* grads, const float* d_raw,
+                         long long n_samples, int n_chunks, float* workspace, float* flat_grad,
+                         int accumulate, const float* amax_x, const float* amax_z, void* stream);
+int scnerf_wgrad256_half(const float* dz_tiled, const float* x_tiled, long long n_samples, int n_chunks,
+                         float* workspace, float* dW, float* db, const float* amax_dz, const float* amax_x,
+                         void* stream);
 /* Measurement hook (bench.py): two hipEvent_t (created by the caller) that the NEXT scnerf_nerf_wgrad records on its
  * stream right before and after its one launch of the eight 256 x 256 GEMMs; cleared after use.  NULLs switch it off. */
 int scnerf_wgrad_profile_events(void* before, void* after);
@@ -331,18 +344,23 @@ int scnerf_h3_pack(const float* flat_params, const int* jobs, const int* idx_fwd
                    short* stream_fwd, short* stream_bwd, float* scales, void* stream);
 /* wpacked: the packed fp32 buffer of scnerf_gather_f32 (its lane-vector tables: biases, density head); save == NULL:
  * inference.  Arguments otherwise as scnerf_mlp_fwd / scnerf_coarse_stage_fwd. */
+/* chunk_amax (or NULL; training): [8][n_chunks] floats, zeroed by the caller -- the kernel leaves there, per
+ * weight-gradient workgroup chunk of chunk_samples samples (scnerf_wgrad_chunk_samples), the largest |value| of the X
+ * operand of each of the eight 256 x 256 weight-gradient GEMMs (scnerf_nerf_wgrad_h3). */
 int scnerf_mlp_fwd_h3(int pt_dims, const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
                       const float* wpacked, const short* stream_fwd, const float* scales, float* raw, float* save,
-                      long long n_samples, void* stream);
+                      long long n_samples, float* chunk_amax, int n_chunks, long long chunk_samples, void* stream);
 /* scnerf_mlp_bwd in the resident arithmetic; wpacked_bwd: the packed fp32 backward buffer (its density-head table). */
 int scnerf_mlp_bwd_h3(int pt_dims, const float* d_raw, const float* pts, const float* viewdirs, int vd_stride,
                       int samples_per_ray, const float* wpacked_bwd, const short* stream_bwd, const float* scales,
-                      const float* save, float* grads, float* d_pts, float* d_views, long long n_samples, void* stream);
+                      const float* save, float* grads, float* d_pts, float* d_views, long long n_samples,
+                      float* chunk_amax, int n_chunks, long long chunk_samples, void* stream);
 int scnerf_coarse_stage_fwd_h3(const float* rays, int ray_stride, const float* t_vals, const float* t_rand,
                                int lindisp, const float* wpacked, const short* stream_fwd, const float* scales,
                                float* save, const float* noise, int white_bkgd, float* z, float* pts, float* raw,
                                float* rgb_map, float* disp_map, float* acc_map, float* depth_map, float* weights,
-                               int n_rays, int n_samples, void* stream);
+                               int n_rays, int n_samples, float* chunk_amax, int n_chunks, long long chunk_samples,
+                               void* stream);
 
 /* ------------------------------------------------------------------ PRD loss --------- */
 

@@ -81,9 +81,11 @@ PROTOTYPES = {
     "scnerf_coarse_stage_fwd_split": [P, I, P, P, I, P, P, P, P, I, P, P, P, P, P, P, P, P, P, I, I, P],
     "scnerf_layer_split": [I, I, P, P, P, P, P, P, LL, P],
     "scnerf_h3_pack": [P, P, P, P, LL, P, P, LL, P, P, P, P],
-    "scnerf_mlp_fwd_h3": [I, P, P, I, I, P, P, P, P, P, LL, P],
-    "scnerf_mlp_bwd_h3": [I, P, P, P, I, I, P, P, P, P, P, P, P, LL, P],
-    "scnerf_coarse_stage_fwd_h3": [P, I, P, P, I, P, P, P, P, P, I, P, P, P, P, P, P, P, P, I, I, P],
+    "scnerf_mlp_fwd_h3": [I, P, P, I, I, P, P, P, P, P, LL, P, I, LL, P],
+    "scnerf_mlp_bwd_h3": [I, P, P, P, I, I, P, P, P, P, P, P, P, LL, P, I, LL, P],
+    "scnerf_coarse_stage_fwd_h3": [P, I, P, P, I, P, P, P, P, P, I, P, P, P, P, P, P, P, P, I, I, P, I, LL, P],
+    "scnerf_nerf_wgrad_h3": [I, P, P, P, LL, I, P, P, I, P, P, P],
+    "scnerf_wgrad256_half": [P, P, LL, I, P, P, P, P, P, P],
 }
 
 
@@ -94,6 +96,7 @@ SIZE_FUNCS = {"scnerf_mlp_save_floats": [I, LL], "scnerf_mlp_grad_floats": [LL],
               "scnerf_split_planes_shorts": [I],
               "scnerf_layer_amax_floats": [LL],
               "scnerf_h3_scale_floats": [],
+              "scnerf_wgrad_chunk_samples": [LL, I],
               "scnerf_camera_bwd_workspace_floats": [I]}
 
 

@@ -224,6 +224,10 @@ __device__ __forceinline__ T* dynamic_lds() {
 }
 
 __device__ __forceinline__ float atomic_add(float* p, float v) { return atomicAdd(p, v); }
+// *p = max(*p, v) for NON-NEGATIVE floats (their bit patterns order like unsigned integers); no return value needed
+__device__ __forceinline__ void atomic_max_nonneg(float* p, float v) {
+    atomicMax(reinterpret_cast<unsigned*>(p), __float_as_uint(v));
+}
 
 __device__ __forceinline__ void sincos(float x, float* s, float* c) { sincosf(x, s, c); }
 

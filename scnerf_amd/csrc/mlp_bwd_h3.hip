@@ -60,7 +60,7 @@ struct NoRank1 {};
 struct Rank1 {
     const float* alpha;        // the density head's weights, LDS lane-vector table + 4 h
     float dsigma;
-    f32x4 wq;
+    f32x4 wqs[2];              // read from LDS one piece ahead (piece parity), as mlp_fwd_h3.hip's bias
 };
 struct NoGate {};
 struct Gate { u32x4 gate; };   // ReLU bits of the layer below: element 16 t + r <-> word t >> 1, bit 31 - (16 (t & 1) + r)
@@ -79,12 +79,15 @@ struct BwdEpi : std::conditional_t<KIND == 1, Rank1, NoRank1>, std::conditional_
         constexpr int x = PIECE >> 2, q = PIECE & 3, T = 2 * P + x;
         constexpr int sl = 2 * T + (q >> 1), c0 = 2 * (q & 1);
         static_assert(sl < NS, "operand buffer too small for this tile");
+#ifdef SCN_H3_NO_EPI                // (timing experiment)
+        if constexpr (SUB == 10) { oh[sl][c0] += (unsigned)(acc[x][4 * q] > 1e30f); }
+        return;
+#endif
         if constexpr (SUB == 0) {
-            if constexpr (KIND == 1) this->wq = *reinterpret_cast<const f32x4*>(this->alpha + (4 * T + q) * 8);
         } else if constexpr (SUB <= 4) {
             constexpr int e = SUB - 1;
             float d = acc[x][4 * q + e] * os;
-            if constexpr (KIND == 1) d = __builtin_fmaf(this->wq[e], this->dsigma, d);
+            if constexpr (KIND == 1) d = __builtin_fmaf(this->wqs[PIECE & 1][e], this->dsigma, d);
             if constexpr (KIND != 2) {
                 constexpr int bit = 31 - (16 * (T & 1) + 4 * q + e);
                 v[e] = keep_if_bit<bit>(d, this->gate[T >> 1]);
@@ -96,6 +99,10 @@ struct BwdEpi : std::conditional_t<KIND == 1, Rank1, NoRank1>, std::conditional_
             am = max3_abs(am, v[2], v[3]);
         } else if constexpr (SUB == 6) {
             hp = pack_f16_scaled(v[0], v[1], s_next);
+            if constexpr (KIND == 1) {
+                constexpr int NT = PIECE < 7 ? 4 * (2 * P + ((PIECE + 1) >> 2)) + ((PIECE + 1) & 3) : (P < 3 ? 4 * (2 * P + 2) : 0);
+                this->wqs[(PIECE + 1) & 1] = *reinterpret_cast<const f32x4*>(this->alpha + NT * 8);
+            }
         } else if constexpr (SUB == 7) {
             oh[sl][c0] = hp;
             ol[sl][c0] = pack_f16(residual_f16<0>(v[0], s_next, hp), residual_f16<1>(v[1], s_next, hp));
@@ -112,6 +119,10 @@ struct BwdEpi : std::conditional_t<KIND == 1, Rank1, NoRank1>, std::conditional_
     }
 };
 
+// Where the weight-gradient GEMMs' chunk maxima of the dZ operands go (wgrad256_half.h): amax [8][n_chunks], job j =
+// dZ of trunk layer j + 1 (j = 7: d feature); chunk = samples per weight-gradient workgroup.
+struct ChunkMaxima { float* amax; int n_chunks; long chunk; };
+
 template <int PD>
 __host__ __device__ constexpr unsigned bwd_lds_bytes() {
     return (unsigned)(kStreamLds + 256 * 4 + Var<PD>::kES * kThreads * 4);
@@ -121,7 +132,8 @@ template <int PD>
 __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_h3_kernel(
     const float* __restrict__ d_raw, const float* __restrict__ pts, const float* __restrict__ viewdirs, int vd_stride,
     int samples_per_ray, const float* __restrict__ wbk, const short* __restrict__ wh3, const float* __restrict__ sc,
-    const float* __restrict__ save, float* __restrict__ grads, float* __restrict__ d_pts, float* __restrict__ d_views, long P) {
+    const float* __restrict__ save, float* __restrict__ grads, float* __restrict__ d_pts, float* __restrict__ d_views, long P,
+    ChunkMaxima cm) {
     using V = Var<PD>;
     constexpr int ES = V::kES, ET = V::kET;        // encoded-point slots; 32-column tiles of the d-encoding parts
     const int lane = lane_id();
@@ -157,6 +169,12 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_h3_kernel(
     };
     auto scale_of = [&](int layer, int what) { return sc[layer * kScaleStride + what]; };
     auto amax_of = [&](float a) { return fmaxf(a, shfl_xor(a, 32)); };
+    auto note_chunk_max = [&](int job, float v) {
+        if (cm.amax == nullptr) return;
+        v = fmaxf(v, shfl_xor(v, 16)); v = fmaxf(v, shfl_xor(v, 8)); v = fmaxf(v, shfl_xor(v, 4));
+        v = fmaxf(v, shfl_xor(v, 2)); v = fmaxf(v, shfl_xor(v, 1));
+        if (lane_id() == 0) atomic_max_nonneg(cm.amax + (long)job * cm.n_chunks + (wave_tile * kSamplesPerWave) / cm.chunk, v);
+    };
     using GateEpi = BwdEpi<0>;
     auto make_gate = [&](int layer, float s_in, int mask_sect, int out_offset, int out_width) {
         GateEpi e;
@@ -227,7 +245,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_h3_kernel(
 
     // ---- a 256 -> 256 transposed layer: operand buffer X (its tiles 6, 7 still to come from `pend`), result -> X ^ 1;
     // leaves its own last pair pending.  Every such layer starts at stream unit 6 modulo 8.
-    auto trunk_layer = [&](auto x_tag, auto& pend, auto& cur, float bound_a, float bound_extra) {
+    auto trunk_layer = [&](auto x_tag, auto& pend, auto& cur, float bound_a, float bound_extra, int job) {
         constexpr int X = decltype(x_tag)::value;
         auto operand = [&](auto s_tag, u32x4& xh, u32x4& xl) {
             constexpr int s = decltype(s_tag)::value;
@@ -236,7 +254,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_h3_kernel(
         using Pend = std::remove_reference_t<decltype(pend)>;
         using Cur = std::remove_reference_t<decltype(cur)>;
         tile_pair<6, 16>(w, acc[0], operand, [&](auto sg) { epi_slot<Pend, 3, decltype(sg)::value, 9>(pend, acc[1], bh[X], bl[X]); });
-        cur.s_next = scale_for(__builtin_fmaf(bound_a, amax_of(pend.am), bound_extra));
+        const float am_in = amax_of(pend.am);              // the layer's operand (dZ of weight-gradient job `job`) is complete
+        note_chunk_max(job, am_in);
+        cur.s_next = scale_for(__builtin_fmaf(bound_a, am_in, bound_extra));
         tile_pair<22, 16>(w, acc[1], operand, [&](auto sg) { epi_slot<Cur, 0, decltype(sg)::value, 12>(cur, acc[0], bh[X ^ 1], bl[X ^ 1]); });
         tile_pair<38, 16>(w, acc[0], operand, [&](auto sg) { epi_slot<Cur, 1, decltype(sg)::value, 12>(cur, acc[1], bh[X ^ 1], bl[X ^ 1]); });
         tile_pair<54, 16>(w, acc[1], operand, [&](auto sg) { epi_slot<Cur, 2, decltype(sg)::value, 12>(cur, acc[0], bh[X ^ 1], bl[X ^ 1]); });
@@ -251,13 +271,14 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_h3_kernel(
     epi7.gate = load_gate(7);
     epi7.alpha = alpha_tab + 4 * h;
     epi7.dsigma = dsigma;
-    trunk_layer(I<0>{}, epif, epi7, scale_of(kLayerFeat, kBoundAT), scale_of(kLayerAlpha, kBoundAT) * fabsf(dsigma));
+    epi7.wqs[0] = *reinterpret_cast<const f32x4*>(epi7.alpha);
+    trunk_layer(I<0>{}, epif, epi7, scale_of(kLayerFeat, kBoundAT), scale_of(kLayerAlpha, kBoundAT) * fabsf(dsigma), 7);
     // ---- trunk layers 7^T, 6^T: dZ_{l-1} = gate_{l-1}(W_l^T dZ_l) ----
     GateEpi prev = make_gate(7, epi7.s_next, 6, kGradDz + 6 * 256, 256);
-    trunk_layer(I<1>{}, epi7, prev, scale_of(7, kBoundAT), 0.f);
+    trunk_layer(I<1>{}, epi7, prev, scale_of(7, kBoundAT), 0.f, 6);
     {
         GateEpi cur = make_gate(6, prev.s_next, 5, kGradDz + 5 * 256, 256);
-        trunk_layer(I<0>{}, prev, cur, scale_of(6, kBoundAT), 0.f);
+        trunk_layer(I<0>{}, prev, cur, scale_of(6, kBoundAT), 0.f, 5);
         prev = cur;
     }
     // ---- the skip layer: its encoded-point columns first (d encoded point, parked in LDS), then its h columns ----
@@ -284,7 +305,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_h3_kernel(
             park_pair(I<2>{}, acc[1]);
         }
         GateEpi cur = make_gate(5, prev.s_next, 4, kGradDz + 4 * 256, 256);
-        cur.s_next = scale_for(scale_of(5, kBoundAT) * amax_of(prev.am));
+        const float am5 = amax_of(prev.am);
+        note_chunk_max(4, am5);
+        cur.s_next = scale_for(scale_of(5, kBoundAT) * am5);
         constexpr int U0 = 6;          // (the encoded-point part is 16 or 32 units: the phase stays)
         tile_pair<U0, 16>(w, acc[0], operand, NoFill{});
         tile_pair<U0 + 16, 16>(w, acc[1], operand, [&](auto sg) { epi_slot<GateEpi, 0, decltype(sg)::value, 12>(cur, acc[0], bh[0], bl[0]); });
@@ -296,9 +319,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_h3_kernel(
 #pragma unroll 1
     for (int l = 4; l >= 2; l -= 2) {
         GateEpi cur = make_gate(l, prev.s_next, l - 1, kGradDz + (l - 1) * 256, 256);
-        trunk_layer(I<0>{}, prev, cur, scale_of(l, kBoundAT), 0.f);
+        trunk_layer(I<0>{}, prev, cur, scale_of(l, kBoundAT), 0.f, l - 1);
         GateEpi cur2 = make_gate(l - 1, cur.s_next, l - 2, kGradDz + (l - 2) * 256, 256);
-        trunk_layer(I<1>{}, cur, cur2, scale_of(l - 1, kBoundAT), 0.f);
+        trunk_layer(I<1>{}, cur, cur2, scale_of(l - 1, kBoundAT), 0.f, l - 2);
         prev = cur2;
     }
     // ---- layer 0^T: d encoded point += W_0^T dZ_0, then the encoding's own gradient -> d pts ----
@@ -349,27 +372,29 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_h3_kernel(
 template <int PD>
 static int launch_bwd_h3(const float* d_raw, const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
                          const float* wpacked_bwd, const short* stream_bwd, const float* scales, const float* save,
-                         float* grads, float* d_pts, float* d_views, long long n_samples, hipStream_t st) {
+                         float* grads, float* d_pts, float* d_views, long long n_samples, ChunkMaxima cm, hipStream_t st) {
     constexpr unsigned lds = bwd_lds_bytes<PD>();
     SCN_LDS_OPT_IN((mlp_bwd_h3_kernel<PD>), lds);
     hipLaunchKernelGGL((mlp_bwd_h3_kernel<PD>), dim3(scn_ceil_div(n_samples, kSamplesPerBlock)), dim3(kThreads), lds, st,
                        d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, stream_bwd, scales, save, grads, d_pts,
-                       d_views, (long)n_samples);
+                       d_views, (long)n_samples, cm);
     return scn_launch_status();
 }
 
 extern "C" int scnerf_mlp_bwd_h3(int pt_dims, const float* d_raw, const float* pts, const float* viewdirs, int vd_stride,
                                  int samples_per_ray, const float* wpacked_bwd, const short* stream_bwd, const float* scales,
                                  const float* save, float* grads, float* d_pts, float* d_views, long long n_samples,
-                                 void* stream) {
+                                 float* chunk_amax, int n_chunks, long long chunk_samples, void* stream) {
     SCN_RETURN_IF(!d_raw || !pts || !viewdirs || !wpacked_bwd || !stream_bwd || !scales || !save || !grads || !d_pts || !d_views, SCN_EINVAL);
     SCN_RETURN_IF(samples_per_ray < 1 || vd_stride < 3 || n_samples < 0 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
+    SCN_RETURN_IF(chunk_amax && (n_chunks < 1 || chunk_samples < 32 || chunk_samples % 32), SCN_EINVAL);
     if (n_samples == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    const ChunkMaxima cm{chunk_amax, n_chunks, (long)chunk_samples};
 #ifdef SCN_H3_ONLY_PD3_TRAIN        // (quick experimental builds: one instantiation)
-    return launch_bwd_h3<3>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, stream_bwd, scales, save, grads, d_pts, d_views, n_samples, st);
+    return launch_bwd_h3<3>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, stream_bwd, scales, save, grads, d_pts, d_views, n_samples, cm, st);
 #else
-    return pt_dims == 3 ? launch_bwd_h3<3>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, stream_bwd, scales, save, grads, d_pts, d_views, n_samples, st)
-                        : launch_bwd_h3<4>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, stream_bwd, scales, save, grads, d_pts, d_views, n_samples, st);
+    return pt_dims == 3 ? launch_bwd_h3<3>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, stream_bwd, scales, save, grads, d_pts, d_views, n_samples, cm, st)
+                        : launch_bwd_h3<4>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, stream_bwd, scales, save, grads, d_pts, d_views, n_samples, cm, st);
 #endif
 }

@@ -24,6 +24,9 @@ using namespace scn::h3;
 // encodings are saved in torch column order so the wgrad GEMM writes weight columns directly (as mlp_fwd.hip)
 template <int PD, int L, int NS>
 __device__ __forceinline__ void store_pe_rows(const float (&e)[NS], float* __restrict__ base, long p, int ld, int h, bool live) {
+#ifdef SCN_H3_NO_PESTORE            // (timing experiment)
+    return;
+#endif
     if (!live) return;
     float* row = base + p * ld;
 #pragma unroll
@@ -42,7 +45,7 @@ struct NoDensity {};
 struct Density {
     float sg;                  // running dot product of the density head (this lane's half of the features)
     const float* alpha;        // its weights, LDS lane-vector table + 4 h
-    f32x4 wq;
+    f32x4 wqs[2];              // (read a piece ahead, as the bias)
 };
 template <bool ON> struct MaskBits { unsigned bits0, bits1, words[4]; };
 template <> struct MaskBits<false> {};
@@ -53,21 +56,32 @@ struct FwdEpi : std::conditional_t<KIND == 1, Density, NoDensity>, MaskBits<TRAI
     const float* bias;         // LDS lane-vector table of the layer, + 4 h
     global_bytes_rw save;      // this wave tile's block of the layer's section (TRAIN)
     unsigned lane16;
-    f32x4 bq;
+    // The bias piece of (tile, quarter) is read from LDS ONE PIECE AHEAD into the other of two registers (piece
+    // parity): read in the slot in front of its first use it cost an LDS round trip per piece -- ~100 cycles, 32 times
+    // per layer, a quarter of a layer's MFMA time.  prime() reads the first piece of the layer (at construction).
+    f32x4 bqs[2];
     float v[4];
     unsigned hp;
+
+    __device__ __forceinline__ void prime() {
+        bqs[0] = *reinterpret_cast<const f32x4*>(bias);
+        if constexpr (KIND == 1) this->wqs[0] = *reinterpret_cast<const f32x4*>(this->alpha);
+    }
 
     template <int P, int PIECE, int SUB, int NS>
     __device__ __forceinline__ void sub(f32x16 (&acc)[2], u32x4 (&oh)[NS], u32x4 (&ol)[NS]) {
         constexpr int x = PIECE >> 2, q = PIECE & 3, T = 2 * P + x;
         constexpr int sl = 2 * T + (q >> 1), c0 = 2 * (q & 1);
         static_assert(sl < NS, "operand buffer too small for this tile");
+#ifdef SCN_H3_NO_EPI                // (timing experiment: the epilogue's arithmetic gone, the operand planes untouched)
+        if constexpr (SUB == 10) { oh[sl][c0] += (unsigned)(acc[x][4 * q] > 1e30f); }
+        return;
+#endif
         if constexpr (SUB == 0) {
-            bq = *reinterpret_cast<const f32x4*>(bias + (4 * T + q) * 8);
-            if constexpr (KIND == 1) this->wq = *reinterpret_cast<const f32x4*>(this->alpha + (4 * T + q) * 8);
             if constexpr (TRAIN && KIND != 2 && PIECE == 0) { this->bits0 = 0u; this->bits1 = 0u; }
         } else if constexpr (SUB <= 4) {
             constexpr int e = SUB - 1;
+            const f32x4& bq = bqs[PIECE & 1];
             const float z = __builtin_fmaf(acc[x][4 * q + e], os, bq[e]);
             v[e] = KIND == 2 ? z : relu_raw(z);
             if constexpr (TRAIN && KIND != 2) {
@@ -79,6 +93,11 @@ struct FwdEpi : std::conditional_t<KIND == 1, Density, NoDensity>, MaskBits<TRAI
             else { am = max3(am, v[0], v[1]); am = max3(am, v[2], v[3]); }
         } else if constexpr (SUB == 6) {
             hp = pack_f16_scaled(v[0], v[1], s_next);
+            // the next piece's bias (the next pair's first piece after the last: tile 2 P + 2; beyond the layer's last
+            // tile the read is harmless -- the table region is followed by other tables)
+            constexpr int NT = PIECE < 7 ? 4 * (2 * P + ((PIECE + 1) >> 2)) + ((PIECE + 1) & 3) : 4 * (2 * P + 2);
+            bqs[(PIECE + 1) & 1] = *reinterpret_cast<const f32x4*>(bias + NT * 8);
+            if constexpr (KIND == 1) this->wqs[(PIECE + 1) & 1] = *reinterpret_cast<const f32x4*>(this->alpha + NT * 8);
         } else if constexpr (SUB == 7) {
             oh[sl][c0] = hp;
             ol[sl][c0] = pack_f16(residual_f16<0>(v[0], s_next, hp), residual_f16<1>(v[1], s_next, hp));
@@ -98,12 +117,16 @@ struct FwdEpi : std::conditional_t<KIND == 1, Density, NoDensity>, MaskBits<TRAI
         } else {
             if constexpr (KIND == 1) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) this->sg = __builtin_fmaf(this->wq[e], v[e], this->sg);
+                for (int e = 0; e < 4; ++e) this->sg = __builtin_fmaf(this->wqs[PIECE & 1][e], v[e], this->sg);
             }
             if constexpr (TRAIN && KIND != 2 && PIECE == 7) this->words[P] = (this->bits0 << 16) | this->bits1;
         }
     }
 };
+
+// Where the weight-gradient GEMMs' chunk maxima go (wgrad256_half.h): amax [8][n_chunks], job j = the GEMM whose X
+// operand is the input of trunk layer j + 1 (j = 7: feature_linear); chunk = samples per weight-gradient workgroup.
+struct ChunkMaxima { float* amax; int n_chunks; long chunk; };
 
 struct CoarseStage {
     const float* rays; int ray_stride; int n_rays;
@@ -127,7 +150,7 @@ template <int PD, bool TRAIN, bool COARSE>
 __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
     const float* __restrict__ pts, const float* __restrict__ viewdirs, int vd_stride, int samples_per_ray,
     const float* __restrict__ wpk, const short* __restrict__ wh3, const float* __restrict__ sc,
-    float* __restrict__ raw, float* __restrict__ save_arg, long P, CoarseStage cs) {
+    float* __restrict__ raw, float* __restrict__ save_arg, long P, CoarseStage cs, ChunkMaxima cm) {
     using V = Var<PD>;
     constexpr int ES = V::kES, NE = ES / 8;
     float* const save = TRAIN ? save_arg : nullptr;
@@ -189,7 +212,12 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
     u32x4 eh[NE], el[NE];
     {
         float e[ES];
+#ifdef SCN_H3_NO_PE                 // (timing experiment: no sines / cosines)
+#pragma unroll
+        for (int i = 0; i < ES; ++i) e[i] = px * (float)i + py;
+#else
         pe_slots<PD, 10, ES>(px, py, pz, pw, h, e);
+#endif
         if (save) store_pe_rows<PD, 10, ES>(e, save + (long)kSaveEpts * Ppad, pc, V::kEW, h, live);
 #pragma unroll
         for (int g = 0; g < ES / 4; ++g) park[g * kThreads] = f32x4{e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3]};
@@ -212,6 +240,15 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
     };
     auto scale_of = [&](int layer, int what) { return sc[layer * kScaleStride + what]; };
     auto amax_of = [&](float a) { return fmaxf(a, shfl_xor(a, 32)); };
+    // the largest of the wave's 32 samples -> the weight-gradient chunk this wave tile belongs to (one atomic per wave)
+    auto note_chunk_max = [&](int job, float v) {
+        if constexpr (TRAIN) {
+            if (cm.amax == nullptr) return;
+            v = fmaxf(v, shfl_xor(v, 16)); v = fmaxf(v, shfl_xor(v, 8)); v = fmaxf(v, shfl_xor(v, 4));
+            v = fmaxf(v, shfl_xor(v, 2)); v = fmaxf(v, shfl_xor(v, 1));
+            if (lane_id() == 0) atomic_max_nonneg(cm.amax + (long)job * cm.n_chunks + (wave_tile * kSamplesPerWave) / cm.chunk, v);
+        }
+    };
 
     using Relu = FwdEpi<TRAIN, 0>;
     auto make_relu = [&](int l, float s_in) {         // epilogue of trunk layer l whose input was cut at s_in
@@ -222,6 +259,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
         e.bias = tab_h + 256 * l;
         e.save = TRAIN ? section(kSaveAct + 256 * l, 256) : nullptr;
         e.lane16 = w.lane16;
+        e.prime();
         return e;
     };
     auto store_mask = [&](auto& epi, int sect) {
@@ -262,8 +300,11 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
             epi_slot<Pend, 3, decltype(sg_tag)::value, NEF >= 4 ? 12 : 9>(pend, acc[1], bh[X], bl[X]);
         });
         if constexpr (std::is_base_of_v<MaskBits<true>, Pend>) store_mask(pend, pend_mask_sect);
-        // the layer's input is complete: its measured maximum bounds this layer's output
-        const float am = fmaxf(amax_of(pend.am), am_floor);
+        // the layer's input is complete: its measured maximum bounds this layer's output (and scales the X operand of
+        // this layer's weight-gradient GEMM: job layer - 1, feature_linear: 7)
+        const float am_in = amax_of(pend.am);
+        note_chunk_max(layer == kLayerFeat ? 7 : layer - 1, am_in);
+        const float am = fmaxf(am_in, am_floor);
         cur.s_next = scale_for(fmaxf(__builtin_fmaf(scale_of(layer, kBoundA), am, scale_of(layer, kBoundB)), bound_floor));
         tile_pair<U0 + NK, NK>(w, acc[1], operand, [&](auto sg_tag) {
             epi_slot<Cur, 0, decltype(sg_tag)::value, 12>(cur, acc[0], bh[X ^ 1], bl[X ^ 1]);
@@ -315,6 +356,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
         const Relu t = make_relu(7, prev.s_next);
         epi7.os = t.os; epi7.s_next = 1.f; epi7.am = 0.f; epi7.sg = 0.f; epi7.bias = t.bias;
         epi7.alpha = tab_h + kTabAlpha; epi7.save = t.save; epi7.lane16 = t.lane16;
+        epi7.prime();
     }
     trunk_layer(I<0>{}, I<0>{}, I<0>{}, prev, epi7, 6, 7, 0.f, 0.f);
     FwdEpi<TRAIN, 2> epif;
@@ -323,6 +365,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
     epif.bias = tab_h + kTabFeat;
     epif.save = TRAIN ? section(kSaveFeat, 256) : nullptr;
     epif.lane16 = w.lane16;
+    epif.prime();
     // (the feature vector meets the encoded view direction in the views layer: one scale for both)
     trunk_layer(I<1>{}, I<0>{}, I<0>{}, epi7, epif, 7, kLayerFeat, 0.f, m_ev);
 
@@ -344,6 +387,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
     epiv.bias = tab_h + kTabViews;
     epiv.save = TRAIN ? section(kSaveHv, 128) : nullptr;
     epiv.lane16 = w.lane16;
+    epiv.prime();
     if constexpr (TRAIN) { epiv.words[2] = 0u; epiv.words[3] = 0u; }
     {
         auto operand = [&](auto s_tag, u32x4& xh, u32x4& xl) {
@@ -497,30 +541,34 @@ extern "C" int scnerf_h3_pack(const float* flat_params, const int* jobs, const i
 
 template <int PD, bool TRAIN>
 static int launch_fwd_h3(const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray, const float* wpacked,
-                         const short* wh3, const float* scales, float* raw, float* save, long long n_samples, hipStream_t st) {
+                         const short* wh3, const float* scales, float* raw, float* save, long long n_samples, ChunkMaxima cm,
+                         hipStream_t st) {
     constexpr unsigned lds = fwd_lds_bytes<PD>();
     SCN_LDS_OPT_IN((mlp_fwd_h3_kernel<PD, TRAIN, false>), lds);
     hipLaunchKernelGGL((mlp_fwd_h3_kernel<PD, TRAIN, false>), dim3(scn_ceil_div(n_samples, kSamplesPerBlock)), dim3(kThreads),
                        lds, st, pts, viewdirs, vd_stride, samples_per_ray, wpacked, wh3, scales, raw, save, (long)n_samples,
-                       CoarseStage{});
+                       CoarseStage{}, cm);
     return scn_launch_status();
 }
 
 extern "C" int scnerf_mlp_fwd_h3(int pt_dims, const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
                                  const float* wpacked, const short* stream_fwd, const float* scales, float* raw, float* save,
-                                 long long n_samples, void* stream) {
+                                 long long n_samples, float* chunk_amax, int n_chunks, long long chunk_samples, void* stream) {
     SCN_RETURN_IF(!pts || !viewdirs || !wpacked || !stream_fwd || !scales || !raw, SCN_EINVAL);
     SCN_RETURN_IF(samples_per_ray < 1 || vd_stride < 3 || n_samples < 0 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
+    SCN_RETURN_IF(chunk_amax && (n_chunks < 1 || chunk_samples < 32 || chunk_samples % 32), SCN_EINVAL);
     if (n_samples == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    const ChunkMaxima cm{chunk_amax, n_chunks, (long)chunk_samples};
 #ifdef SCN_H3_ONLY_PD3_TRAIN        // (quick experimental builds: one instantiation)
-    return launch_fwd_h3<3, true>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, stream_fwd, scales, raw, save, n_samples, st);
+    SCN_RETURN_IF(!save || pt_dims != 3, SCN_ENOSUP);
+    return launch_fwd_h3<3, true>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, stream_fwd, scales, raw, save, n_samples, cm, st);
 #else
     if (pt_dims == 3)
-        return save ? launch_fwd_h3<3, true>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, stream_fwd, scales, raw, save, n_samples, st)
-                    : launch_fwd_h3<3, false>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, stream_fwd, scales, raw, save, n_samples, st);
-    return save ? launch_fwd_h3<4, true>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, stream_fwd, scales, raw, save, n_samples, st)
-                : launch_fwd_h3<4, false>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, stream_fwd, scales, raw, save, n_samples, st);
+        return save ? launch_fwd_h3<3, true>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, stream_fwd, scales, raw, save, n_samples, cm, st)
+                    : launch_fwd_h3<3, false>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, stream_fwd, scales, raw, save, n_samples, cm, st);
+    return save ? launch_fwd_h3<4, true>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, stream_fwd, scales, raw, save, n_samples, cm, st)
+                : launch_fwd_h3<4, false>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, stream_fwd, scales, raw, save, n_samples, cm, st);
 #endif
 }
 
@@ -528,28 +576,31 @@ extern "C" int scnerf_coarse_stage_fwd_h3(const float* rays, int ray_stride, con
                                           int lindisp, const float* wpacked, const short* stream_fwd, const float* scales,
                                           float* save, const float* noise, int white_bkgd, float* z, float* pts, float* raw,
                                           float* rgb_map, float* disp_map, float* acc_map, float* depth_map, float* weights,
-                                          int n_rays, int n_samples, void* stream) {
+                                          int n_rays, int n_samples, float* chunk_amax, int n_chunks, long long chunk_samples,
+                                          void* stream) {
     SCN_RETURN_IF(!rays || !t_vals || !wpacked || !stream_fwd || !scales || !z || !pts || !raw || !rgb_map || !disp_map || !acc_map, SCN_EINVAL);
     SCN_RETURN_IF(n_rays < 0 || ray_stride < 11, SCN_EINVAL);
     SCN_RETURN_IF(n_samples != kCoarseSamples, SCN_ENOSUP);
+    SCN_RETURN_IF(chunk_amax && (n_chunks < 1 || chunk_samples < 32 || chunk_samples % 32), SCN_EINVAL);
     if (n_rays == 0) return 0;
     const CoarseStage cs{rays, ray_stride, n_rays, t_vals, t_rand, lindisp, z, pts, noise, white_bkgd,
                          rgb_map, disp_map, acc_map, depth_map, weights};
+    const ChunkMaxima cm{chunk_amax, n_chunks, (long)chunk_samples};
     hipStream_t st = (hipStream_t)stream;
     constexpr unsigned lds = fwd_lds_bytes<3>();
     const long P = (long)n_rays * kCoarseSamples;
 #ifdef SCN_H3_ONLY_PD3_TRAIN
-    (void)cs; (void)st; (void)lds; (void)P;
+    (void)cs; (void)st; (void)lds; (void)P; (void)cm;
     return SCN_ENOSUP;
 #else
     if (save) {
         SCN_LDS_OPT_IN((mlp_fwd_h3_kernel<3, true, true>), lds);
         hipLaunchKernelGGL((mlp_fwd_h3_kernel<3, true, true>), dim3(scn_ceil_div(P, kSamplesPerBlock)), dim3(kThreads), lds, st,
-                           (const float*)nullptr, rays + 8, ray_stride, kCoarseSamples, wpacked, stream_fwd, scales, raw, save, P, cs);
+                           (const float*)nullptr, rays + 8, ray_stride, kCoarseSamples, wpacked, stream_fwd, scales, raw, save, P, cs, cm);
     } else {
         SCN_LDS_OPT_IN((mlp_fwd_h3_kernel<3, false, true>), lds);
         hipLaunchKernelGGL((mlp_fwd_h3_kernel<3, false, true>), dim3(scn_ceil_div(P, kSamplesPerBlock)), dim3(kThreads), lds, st,
-                           (const float*)nullptr, rays + 8, ray_stride, kCoarseSamples, wpacked, stream_fwd, scales, raw, save, P, cs);
+                           (const float*)nullptr, rays + 8, ray_stride, kCoarseSamples, wpacked, stream_fwd, scales, raw, save, P, cs, cm);
     }
     return scn_launch_status();
 #endif

@@ -120,7 +120,9 @@ __device__ __forceinline__ void stream_slot(Stream& ws, char* lds, unsigned tid1
     if constexpr (KAPPA < 24 && KAPPA % 3 == 0)
         *reinterpret_cast<f32x4*>(lds + ws.next() + (KAPPA / 3) * 4096 + tid16) = ws.stage[KAPPA / 3];
 #endif
+#ifndef SCN_H3_NO_BARRIER           // (timing experiment: racy)
     if constexpr (KAPPA == 30) block_sync();
+#endif
 #ifndef SCN_H3_NO_STREAM
     if constexpr (KAPPA >= 24 && KAPPA % 3 == 0)
         // (opaque wave-uniform base + the thread's 32-bit offset: `global_load v, v_off, s[base]`; left to itself the

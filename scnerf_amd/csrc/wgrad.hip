@@ -21,6 +21,7 @@
 #include "mlp_common.h"
 #include "scnerf_hip.h"
 #include "wgrad256.h"
+#include "wgrad256_half.h"
 #include "wgrad256_split.h"
 #include "wgrad_tiles.h"
 
@@ -365,14 +366,14 @@ int launch_wgrad(const WgradArgs& a, int G, hipStream_t stream) {
 int& wgrad_arithmetic() {
     static int mode = [] {
         const char* e = getenv("SCNERF_WGRAD_ARITHMETIC");
-        return (e && (e[0] == 'f' || e[0] == '0')) ? 0 : 1;
+        return (e && (e[0] == 'f' || e[0] == '0')) ? 0 : (e && (e[0] == 's' || e[0] == '1')) ? 1 : 2;
     }();
     return mode;
 }
 
 // the 256 x 256 tile-native GEMMs of a pass in one launch, grid (chunks, jobs)
 int launch_wgrad256(const wg256::Args& a, int G, hipStream_t stream) {
-    if (wgrad_arithmetic() == 1) {
+    if (wgrad_arithmetic() >= 1) {
         SCN_LDS_OPT_IN((wg256s::wgrad256_split_kernel<0>), wg256s::kLdsBytes);
         hipLaunchKernelGGL((wg256s::wgrad256_split_kernel<0>), dim3(G, a.n_jobs), dim3(wg256s::kThreads),
                            wg256s::kLdsBytes, stream, a);
@@ -381,6 +382,21 @@ int launch_wgrad256(const wg256::Args& a, int G, hipStream_t stream) {
     constexpr int F = wg256::kSpread;
     SCN_LDS_OPT_IN((wg256::wgrad256_kernel<F>), wg256::kLdsBytes);
     hipLaunchKernelGGL((wg256::wgrad256_kernel<F>), dim3(G, a.n_jobs), dim3(wg256::kThreads), wg256::kLdsBytes, stream, a);
+    return scn_launch_status();
+}
+
+// the same GEMMs on three fp16 products (wgrad256_half.h): needs the chunk maxima of both operands, [job][chunk]
+int launch_wgrad256_half(const wg256::Args& a, int G, const float* amax_a, const float* amax_b, hipStream_t stream) {
+    wg256h::Args h;
+    for (int j = 0; j < a.n_jobs; ++j) h.job[j] = a.job[j];
+    h.n_jobs = a.n_jobs;
+    h.Ppad = a.Ppad;
+    h.chunk = a.chunk;
+    h.amax_a = amax_a;
+    h.amax_b = amax_b;
+    SCN_LDS_OPT_IN((wg256h::wgrad256_half_kernel<0>), wg256h::kLdsBytes);
+    hipLaunchKernelGGL((wg256h::wgrad256_half_kernel<0>), dim3(G, a.n_jobs), dim3(wg256h::kThreads), wg256h::kLdsBytes,
+                       stream, h);
     return scn_launch_status();
 }
 
@@ -514,9 +530,13 @@ hipEvent_t g_profile_events[2] = {nullptr, nullptr};
 // the GEMM slabs behind the vecmat partials stay 16-byte aligned (the persistent kernel stores them as float4)
 long long vecmat_ws_floats(long long n_chunks) { return (257 * n_chunks + 3) / 4 * 4; }
 
+// amax_x / amax_z (or nullptr): [8][n_chunks] chunk maxima of the X / dZ operands of the eight 256 x 256 GEMMs in the
+// order they are queued below (layers 1 .. 7, feature_linear), left by the resident kernels: with them the eight run
+// on three fp16 products (wgrad256_half.h) unless the arithmetic is switched to fp32 / split
 template <int PD>
 int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long long P, int n_chunks,
-               float* workspace, float* g, int accumulate, void* stream) {
+               float* workspace, float* g, int accumulate, void* stream, const float* amax_x = nullptr,
+               const float* amax_z = nullptr) {
     using namespace scn::mlp;
     using V = Var<PD>;
     const long long Ppad = scn::mlp::padded_samples(P);
@@ -564,7 +584,8 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
 #undef SCN_WG
     if (big.n_jobs > 0) {
         if (g_profile_events[0]) SCN_HIP(hipEventRecord(g_profile_events[0], st));
-        rc = launch_wgrad256(big, n_chunks, st);
+        rc = (amax_x && amax_z && wgrad_arithmetic() == 2) ? launch_wgrad256_half(big, n_chunks, amax_z, amax_x, st)
+                                                            : launch_wgrad256(big, n_chunks, st);
         if (rc != 0) return rc;
         if (g_profile_events[1]) SCN_HIP(hipEventRecord(g_profile_events[1], st));
         g_profile_events[0] = g_profile_events[1] = nullptr;
@@ -597,8 +618,46 @@ extern "C" int scnerf_wgrad_profile_events(void* before, void* after) {
 }
 
 extern "C" int scnerf_wgrad_arithmetic(int mode) {
-    if (mode == 0 || mode == 1) wgrad_arithmetic() = mode;
+    if (mode == 0 || mode == 1 || mode == 2) wgrad_arithmetic() = mode;
     return wgrad_arithmetic();
+}
+
+extern "C" long long scnerf_wgrad_chunk_samples(long long n_samples, int n_chunks) {
+    if (n_samples < 0 || n_chunks < 1) return -1;
+    const long long Ppad = scn::mlp::padded_samples(n_samples);
+    long long chunk = (Ppad + n_chunks - 1) / n_chunks;
+    chunk = (chunk + kMS - 1) / kMS * kMS;
+    return chunk == 0 ? kMS : chunk;
+}
+
+extern "C" int scnerf_nerf_wgrad_h3(int pt_dims, const float* save, const float* grads, const float* d_raw,
+                                    long long n_samples, int n_chunks, float* workspace, float* flat_grad,
+                                    int accumulate, const float* amax_x, const float* amax_z, void* stream) {
+    SCN_RETURN_IF(!save || !grads || !d_raw || !workspace || !flat_grad || n_samples < 1 || n_chunks < 1, SCN_EINVAL);
+    SCN_RETURN_IF(pt_dims != 3 && pt_dims != 4, SCN_EINVAL);
+    if (pt_dims == 3) return nerf_wgrad<3>(save, grads, d_raw, n_samples, n_chunks, workspace, flat_grad, accumulate, stream, amax_x, amax_z);
+    return nerf_wgrad<4>(save, grads, d_raw, n_samples, n_chunks, workspace, flat_grad, accumulate, stream, amax_x, amax_z);
+}
+
+// one 256 x 256 GEMM on three fp16 products with the chunk maxima given (tests: accuracy against fp64)
+extern "C" int scnerf_wgrad256_half(const float* dz_tiled, const float* x_tiled, long long n_samples, int n_chunks,
+                                    float* workspace, float* dW, float* db, const float* amax_dz, const float* amax_x,
+                                    void* stream) {
+    SCN_RETURN_IF(!dz_tiled || !x_tiled || !workspace || !dW || !amax_dz || !amax_x || n_samples < 1 || n_chunks < 1, SCN_EINVAL);
+    hipStream_t st = (hipStream_t)stream;
+    wg256::Args one;
+    one.n_jobs = 1;
+    one.Ppad = scn::mlp::padded_samples(n_samples);
+    one.chunk = scnerf_wgrad_chunk_samples(n_samples, n_chunks);
+    float* part_w = workspace;
+    float* part_b = workspace + (long)n_chunks * 256 * 256;
+    one.job[0] = wg256::Job{dz_tiled, x_tiled, part_w, db ? part_b : nullptr};
+    int rc = launch_wgrad256_half(one, n_chunks, amax_dz, amax_x, st);
+    SCN_RETURN_IF(rc != 0, rc);
+    const long total = 256L * 256 + (db ? 256 : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(scn_ceil_div(total, 256)), dim3(256), 0, st, part_w, db ? part_b : nullptr,
+                       n_chunks, 256, 256, 256, 256, dW, 256, 0, db);
+    return scn_launch_status();
 }
 
 long long scnerf_nerf_wgrad_workspace_floats(int n_chunks) {

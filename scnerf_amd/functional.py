@@ -74,20 +74,23 @@ class RenderRaysFunction(torch.autograd.Function):
         # what the arithmetic in force (ops.mlp_arithmetic) needs besides the packed fp32 buffer: nothing (the fused fp32
         # kernels), the planes of the 256-wide layers (split-arithmetic GEMMs), or the resident kernels' streams
         pl_c = ops.pack_for_arithmetic(flat_c, train) if n > 0 else None
+        resident = isinstance(pl_c, ops.ResidentWeights)
+        # (resident kernels, training: they leave the chunk maxima the fp16 weight-gradient GEMMs scale by)
+        mx_c = ops.ChunkMaxima(n * sc, dev) if (train and resident) else None
         if sc == ops.COARSE_STAGE_SAMPLES and n > 0:
             # the whole coarse stage -- stratified depths, network, compositing -- is one launch
             z_c, pts_c, raw_c, rgb_c, disp_c, acc_c, w_c, depth_c = ops.coarse_stage_fwd(
                 rays, host_linspace(sc, dev), _c(t_rand), cfg.lindisp, wf_c, save_c, _c(noise_c), cfg.white_bkgd,
-                planes=pl_c)
+                planes=pl_c, maxima=mx_c)
         else:
             z_c, pts_c = ops.coarse_sample(rays, host_linspace(sc, dev), _c(t_rand), cfg.lindisp)
-            raw_c = ops.mlp_fwd(pts_c, viewdirs, sc, wf_c, save_c, planes=pl_c).view(n, sc, 4)
+            raw_c = ops.mlp_fwd(pts_c, viewdirs, sc, wf_c, save_c, planes=pl_c, maxima=mx_c).view(n, sc, 4)
             rgb_c, disp_c, acc_c, w_c, depth_c = ops.composite_fwd(raw_c, z_c, rays, _c(noise_c), cfg.white_bkgd)
 
         ctx.cfg, ctx.train, ctx.n = cfg, train, n
         ctx.net_c, ctx.net_f = net_c, net_f
         ctx.n_params_c = len(net_c.ordered_parameters())
-        ctx.coarse = (z_c, pts_c, raw_c, _c(noise_c), save_c)
+        ctx.coarse = (z_c, pts_c, raw_c, _c(noise_c), save_c, mx_c)
         ctx.pl_c = pl_c
         ctx.rays = rays
         ctx.wb_c = ops.pack_weights(flat_c, "bwd") if train else None
@@ -106,10 +109,11 @@ class RenderRaysFunction(torch.autograd.Function):
         wf_f = wf_c if fine_net is net_c else ops.pack_weights(flat_f, "fwd")
         save_f = ops.save_workspace(n * tot, dev) if train else None
         pl_f = pl_c if fine_net is net_c else (ops.pack_for_arithmetic(flat_f, train) if n > 0 else None)
-        raw_f = ops.mlp_fwd(pts_f, viewdirs, tot, wf_f, save_f, planes=pl_f).view(n, tot, 4)
+        mx_f = ops.ChunkMaxima(n * tot, dev) if (train and resident) else None
+        raw_f = ops.mlp_fwd(pts_f, viewdirs, tot, wf_f, save_f, planes=pl_f, maxima=mx_f).view(n, tot, 4)
         rgb_f, disp_f, acc_f, _, depth_f = ops.composite_fwd(raw_f, z_f, rays, _c(noise_f), cfg.white_bkgd,
                                                              want_weights=False)
-        ctx.fine = (z_f, pts_f, raw_f, _c(noise_f), save_f)
+        ctx.fine = (z_f, pts_f, raw_f, _c(noise_f), save_f, mx_f)
         ctx.pl_f = pl_f
         ctx.wb_f = (ctx.wb_c if fine_net is net_c else ops.pack_weights(flat_f, "bwd")) if train else None
         ctx.mark_non_differentiable(z_std, z_f, z_s)
@@ -119,22 +123,22 @@ class RenderRaysFunction(torch.autograd.Function):
     def _stage_dgrad(stage, rays, spr, wbk, white_bkgd, g_rgb, g_disp, g_acc, g_depth, g_raw, d_rays, accumulate,
                      planes=None):
         """Data gradients of one stage (compositing, network, rays); -> what its weight gradients need."""
-        z, pts, raw, noise, save = stage
+        z, pts, raw, noise, save, maxima = stage
         d_raw, d_rd = ops.composite_bwd(raw, z, rays, noise, white_bkgd, _c(g_rgb), _c(g_disp), _c(g_acc),
                                         _c(g_depth), _c(g_raw))
-        grads, d_pts, d_views = ops.mlp_bwd(d_raw, pts, rays[:, 8:11], spr, wbk, save, planes=planes)
+        grads, d_pts, d_views = ops.mlp_bwd(d_raw, pts, rays[:, 8:11], spr, wbk, save, planes=planes, maxima=maxima)
         ops.ray_reduce(d_pts, d_views, z, d_rd, d_rays, accumulate)
-        return save, grads, d_raw, z.shape[0] * spr
+        return save, grads, d_raw, z.shape[0] * spr, maxima
 
     @staticmethod
     def _stage_wgrad(pending, into=None):
         """`into`: the network's attached flat .grad buffer -- the weight gradients are ADDED to it and
         None is returned (nothing for autograd to accumulate); otherwise a fresh flat gradient."""
-        save, grads, d_raw, P = pending
+        save, grads, d_raw, P, maxima = pending
         if into is not None:
-            ops.nerf_wgrad(save, grads, d_raw, P, flat_grad=into, accumulate=True)
+            ops.nerf_wgrad(save, grads, d_raw, P, flat_grad=into, accumulate=True, maxima=maxima)
             return None
-        return ops.nerf_wgrad(save, grads, d_raw, P)
+        return ops.nerf_wgrad(save, grads, d_raw, P, maxima=maxima)
 
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, g_depth, g_raw, g_rgb0, g_disp0, g_acc0, g_depth0, *_unused):

@@ -67,10 +67,13 @@ class _NerfNetFunction(torch.autograd.Function):
         # training: the 256-wide layers as split-arithmetic GEMMs (ops.mlp_arithmetic), as in the SCNeRF step
         pl_f = ops.pack_for_arithmetic(flat_f, train, 3, remap=fg_net.pack_remap()) if n > 0 else None
         pl_b = ops.pack_for_arithmetic(flat_b, train, 4, remap=bg_net.pack_remap()) if n > 0 else None
+        resident = train and isinstance(pl_f, ops.ResidentWeights)
+        mx_f = ops.ChunkMaxima(n * sf, dev) if resident else None        # (for the fp16 weight-gradient GEMMs)
+        mx_b = ops.ChunkMaxima(n * sb, dev) if resident else None
         raw_f = ops.mlp_fwd(fg_pts, views, sf, ops.pack_weights(flat_f, "fwd", pd=3, remap=fg_net.pack_remap()),
-                            save_f, pd=3, planes=pl_f)
+                            save_f, pd=3, planes=pl_f, maxima=mx_f)
         raw_b = ops.mlp_fwd(bg_pts, views, sb, ops.pack_weights(flat_b, "fwd", pd=4, remap=bg_net.pack_remap()),
-                            save_b, pd=4, planes=pl_b)
+                            save_b, pd=4, planes=pl_b, maxima=mx_b)
         out = {"rgb": (n, 3), "fg_weights": (n, sf), "bg_weights": (n, sb), "fg_rgb": (n, 3), "fg_depth": (n,),
                "bg_rgb": (n, 3), "bg_depth": (n,), "bg_lambda": (n,)}
         t = {k: torch.empty(sh, dtype=torch.float32, device=dev) for k, sh in out.items()}
@@ -83,7 +86,7 @@ class _NerfNetFunction(torch.autograd.Function):
         if train:
             ctx.state = (o, d, zmax, zf, zb, fg_pts, bg_pts, views, raw_f, raw_b, save_f, save_b,
                          ops.pack_weights(flat_f, "bwd", pd=3, remap=fg_net.pack_remap()),
-                         ops.pack_weights(flat_b, "bwd", pd=4, remap=bg_net.pack_remap()), pl_f, pl_b)
+                         ops.pack_weights(flat_b, "bwd", pd=4, remap=bg_net.pack_remap()), pl_f, pl_b, mx_f, mx_b)
         tails = {"rgb": (3,), "fg_weights": (sf,), "bg_weights": (sb,), "fg_rgb": (3,), "bg_rgb": (3,)}
         return tuple(t[k].view(*dots, *tails.get(k, ())) for k in _OUT_KEYS)
 
@@ -93,7 +96,7 @@ class _NerfNetFunction(torch.autograd.Function):
             raise RuntimeError("NerfNet.forward was evaluated without gradient tracking")
         n, sf, sb, o_shape, zmax_shape, fgz_shape = ctx.dims
         fg_net, bg_net = ctx.nets
-        (o, d, zmax, zf, zb, fg_pts, bg_pts, views, raw_f, raw_b, save_f, save_b, wb_f, wb_b, pl_f, pl_b) = ctx.state
+        (o, d, zmax, zf, zb, fg_pts, bg_pts, views, raw_f, raw_b, save_f, save_b, wb_f, wb_b, pl_f, pl_b, mx_f, mx_b) = ctx.state
         dev = o.device
         lib = _capi.load()
         gs = [None if x is None else x.reshape(n, -1).contiguous().float() for x in g]
@@ -107,10 +110,10 @@ class _NerfNetFunction(torch.autograd.Function):
                                                  _p(d_norm), n, sf, sb, _stream()), "scnerf_npp_composite_bwd")
         # both networks' data gradients first, then both weight-gradient passes (one clock recovery after the bf16
         # weight-gradient GEMMs instead of two: functional.py)
-        grads_f, d_pts_f, d_views_f = ops.mlp_bwd(d_raw_f, fg_pts, views, sf, wb_f, save_f, pd=3, planes=pl_f)
-        grads_b, d_pts_b, d_views_b = ops.mlp_bwd(d_raw_b, bg_pts, views, sb, wb_b, save_b, pd=4, planes=pl_b)
-        flat_gf = ops.nerf_wgrad(save_f, grads_f, d_raw_f, n * sf, pd=3)
-        flat_gb = ops.nerf_wgrad(save_b, grads_b, d_raw_b, n * sb, pd=4)
+        grads_f, d_pts_f, d_views_f = ops.mlp_bwd(d_raw_f, fg_pts, views, sf, wb_f, save_f, pd=3, planes=pl_f, maxima=mx_f)
+        grads_b, d_pts_b, d_views_b = ops.mlp_bwd(d_raw_b, bg_pts, views, sb, wb_b, save_b, pd=4, planes=pl_b, maxima=mx_b)
+        flat_gf = ops.nerf_wgrad(save_f, grads_f, d_raw_f, n * sf, pd=3, maxima=mx_f)
+        flat_gb = ops.nerf_wgrad(save_b, grads_b, d_raw_b, n * sb, pd=4, maxima=mx_b)
         g_o, g_d = torch.empty_like(o), torch.empty_like(d)
         g_z = torch.empty((n, sf), dtype=torch.float32, device=dev)
         _capi.check(lib.scnerf_npp_points_bwd(_p(o), _p(d), _p(zf), _p(zb), _p(d_pts_f), _p(d_pts_b), _p(d_views_f),

@@ -286,6 +286,19 @@ class ResidentWeights:
         self.fwd, self.bwd, self.scales, self.pd = fwd, bwd, scales, pd
 
 
+class ChunkMaxima:
+    """Per weight-gradient workgroup chunk, the largest |value| of the operands of the eight 256 x 256 GEMMs of one
+    network pass: `x` [8, chunks] left by the resident forward, `z` [8, chunks] by the resident data-gradient chain
+    (one atomic max per wave and layer); with them the GEMMs run on three fp16 products (csrc/wgrad256_half.h)."""
+    __slots__ = ("x", "z", "chunks", "chunk_samples")
+
+    def __init__(self, P: int, device):
+        self.chunks = wgrad_chunks(P)
+        self.chunk_samples = int(_capi.load().scnerf_wgrad_chunk_samples(int(P), self.chunks))
+        both = torch.zeros((2, 8, self.chunks), dtype=torch.float32, device=device)
+        self.x, self.z = both[0], both[1]
+
+
 _h3_tables = {}
 
 
@@ -372,7 +385,8 @@ def _fwd_split_piecewise(pd, P, tag, wpacked, planes, save, stage_call):
 
 
 def mlp_fwd(pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked: Tensor,
-            save: Optional[Tensor] = None, pd: int = 3, planes: Optional[Tensor] = None) -> Tensor:
+            save: Optional[Tensor] = None, pd: int = 3, planes: Optional[Tensor] = None,
+            maxima: Optional["ChunkMaxima"] = None) -> Tensor:
     """pts [P, pd] (pd = 3: x y z; pd = 4: x y z 1/r) -> raw [P, 4] (rgb logits, sigma pre-activation).
     `planes` (pack_planes; training only): the 256-wide layers run as split-arithmetic GEMMs."""
     _f(pts, "pts"), _f(wpacked, "wpacked")
@@ -388,7 +402,7 @@ def mlp_fwd(pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked: Tensor
     if isinstance(planes, ResidentWeights):
         if planes.pd != pd:
             raise ValueError("resident weights of another network variant")
-        return mlp_fwd_resident(pts, viewdirs, samples_per_ray, wpacked, planes, save)
+        return mlp_fwd_resident(pts, viewdirs, samples_per_ray, wpacked, planes, save, maxima)
     raw = torch.empty((P, 4), dtype=torch.float32, device=pts.device)
     tag = "" if pd == 3 else "/pd4"
     if planes is not None:
@@ -416,7 +430,7 @@ def mlp_fwd(pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked: Tensor
 
 
 def mlp_fwd_resident(pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked: Tensor, rw: ResidentWeights,
-                     save: Optional[Tensor] = None) -> Tensor:
+                     save: Optional[Tensor] = None, maxima: Optional[ChunkMaxima] = None) -> Tensor:
     """mlp_fwd in the resident arithmetic: one launch, three fp16 products per product, activations register-resident
     (csrc/mlp_fwd_h3.hip); save (training) receives the same workspace as mlp_fwd's."""
     _f(pts, "pts"), _f(wpacked, "wpacked")
@@ -433,8 +447,10 @@ def mlp_fwd_resident(pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacke
     raw = torch.empty((P, 4), dtype=torch.float32, device=pts.device)
     with PROFILE.region("mlp_fwd_h3_kernel%s/P=%d/%s" % ("" if pd == 3 else "/pd4", P, "train" if save is not None else "infer"),
                         2 * _MAC_PER_SAMPLE[pd] * P):
+        mx = maxima if save is not None else None
         st = _capi.load().scnerf_mlp_fwd_h3(pd, _p(pts), vptr, vstride, int(samples_per_ray), _p(wpacked), _p(rw.fwd),
-                                            _p(rw.scales), _p(raw), _p(save), P, _stream())
+                                            _p(rw.scales), _p(raw), _p(save), P, _p(mx.x) if mx else None,
+                                            mx.chunks if mx else 0, mx.chunk_samples if mx else 0, _stream())
     _capi.check(st, "scnerf_mlp_fwd_h3")
     return raw
 
@@ -443,7 +459,8 @@ COARSE_STAGE_SAMPLES = 64        # the fused coarse stage exists for two wave ti
 
 
 def coarse_stage_fwd(rays: Tensor, t_vals: Tensor, t_rand: Optional[Tensor], lindisp: bool, wpacked: Tensor,
-                     save: Optional[Tensor], noise: Optional[Tensor], white_bkgd: bool, planes: Optional[Tensor] = None):
+                     save: Optional[Tensor], noise: Optional[Tensor], white_bkgd: bool, planes: Optional[Tensor] = None,
+                     maxima: Optional["ChunkMaxima"] = None):
     """coarse_sample + mlp_fwd + composite_fwd of the coarse stage as one launch (64 samples per ray):
     -> (z [n,64], pts [n,64,3], raw [n,64,4], rgb [n,3], disp [n], acc [n], weights [n,64], depth [n])."""
     _f(rays, "rays"), _f(t_vals, "t_vals"), _f(wpacked, "wpacked")
@@ -476,7 +493,8 @@ def coarse_stage_fwd(rays: Tensor, t_vals: Tensor, t_rand: Optional[Tensor], lin
             st = _capi.load().scnerf_coarse_stage_fwd_h3(
                 _p(rays), rays.shape[1], _p(t_vals), _p(t_rand), int(bool(lindisp)), _p(wpacked), _p(planes.fwd),
                 _p(planes.scales), _p(save), _p(noise), int(bool(white_bkgd)), _p(z), _p(pts), _p(raw), _p(rgb), _p(disp),
-                _p(acc), _p(depth), _p(w), n, s, _stream())
+                _p(acc), _p(depth), _p(w), n, s, _p(maxima.x) if (maxima and save is not None) else None,
+                maxima.chunks if maxima else 0, maxima.chunk_samples if maxima else 0, _stream())
         _capi.check(st, "scnerf_coarse_stage_fwd_h3")
         return z, pts, raw, rgb, disp, acc, w, depth
     if planes is not None:
@@ -523,13 +541,13 @@ def _bwd_split_piecewise(pd, P, tag, wpacked_bwd, planes, save, grads, d_raw, st
 
 
 def mlp_bwd(d_raw: Tensor, pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked_bwd: Tensor,
-            save: Tensor, pd: int = 3, planes: Optional[Tensor] = None):
+            save: Tensor, pd: int = 3, planes: Optional[Tensor] = None, maxima: Optional["ChunkMaxima"] = None):
     """-> (grads workspace, d_pts [P,pd], d_views [P,3]).  `planes` (pack_planes): the 256-wide transposed layers
     run as split-arithmetic GEMMs."""
     if isinstance(planes, ResidentWeights):
         if planes.pd != pd:
             raise ValueError("resident weights of another network variant")
-        return mlp_bwd_resident(d_raw, pts, viewdirs, samples_per_ray, wpacked_bwd, planes, save)
+        return mlp_bwd_resident(d_raw, pts, viewdirs, samples_per_ray, wpacked_bwd, planes, save, maxima)
     _f(d_raw, "d_raw"), _f(pts, "pts"), _f(wpacked_bwd, "wpacked_bwd"), _f(save, "save")
     vptr, vstride = _vd(viewdirs)
     lay = ML.layout(pd)
@@ -563,7 +581,7 @@ def mlp_bwd(d_raw: Tensor, pts: Tensor, viewdirs: Tensor, samples_per_ray: int, 
 
 
 def mlp_bwd_resident(d_raw: Tensor, pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked_bwd: Tensor,
-                     rw: ResidentWeights, save: Tensor):
+                     rw: ResidentWeights, save: Tensor, maxima: Optional[ChunkMaxima] = None):
     """mlp_bwd in the resident arithmetic (csrc/mlp_bwd_h3.hip): one launch -> (grads workspace, d_pts, d_views)."""
     _f(d_raw, "d_raw"), _f(pts, "pts"), _f(wpacked_bwd, "wpacked_bwd"), _f(save, "save")
     vptr, vstride = _vd(viewdirs)
@@ -578,7 +596,9 @@ def mlp_bwd_resident(d_raw: Tensor, pts: Tensor, viewdirs: Tensor, samples_per_r
     d_views = torch.empty((P, 3), dtype=torch.float32, device=dev)
     with PROFILE.region("mlp_bwd_h3_kernel%s/P=%d" % ("" if pd == 3 else "/pd4", P), 2 * _MAC_PER_SAMPLE[pd] * P):
         st = _capi.load().scnerf_mlp_bwd_h3(pd, _p(d_raw), _p(pts), vptr, vstride, int(samples_per_ray), _p(wpacked_bwd),
-                                            _p(rw.bwd), _p(rw.scales), _p(save), _p(grads), _p(d_pts), _p(d_views), P, _stream())
+                                            _p(rw.bwd), _p(rw.scales), _p(save), _p(grads), _p(d_pts), _p(d_views), P,
+                                            _p(maxima.z) if maxima else None, maxima.chunks if maxima else 0,
+                                            maxima.chunk_samples if maxima else 0, _stream())
     _capi.check(st, "scnerf_mlp_bwd_h3")
     return grads, d_pts, d_views
 
@@ -592,14 +612,16 @@ _wgrad_ws = {}
 
 
 def wgrad_arithmetic(mode: Optional[str] = None) -> str:
-    """"split" (default): the 256 x 256 weight-gradient GEMMs run on the bf16 matrix pipe with exactly cut fp32
-    operands (csrc/wgrad256_split.h); "fp32": on the exact-fp32 MFMA.  Without an argument: the mode in force."""
-    code = {None: -1, "fp32": 0, "split": 1}[mode]
-    return ("fp32", "split")[_capi.load().scnerf_wgrad_arithmetic(code)]
+    """The 256 x 256 weight-gradient GEMMs: "half" (default) -- three fp16 products per product with one power-of-two
+    scale per operand and workgroup chunk, where the resident kernels left the chunk maxima (csrc/wgrad256_half.h;
+    otherwise as "split"); "split" -- the bf16 matrix pipe with exactly cut fp32 operands, six products
+    (csrc/wgrad256_split.h); "fp32": the exact-fp32 MFMA.  Without an argument: the mode in force."""
+    code = {None: -1, "fp32": 0, "split": 1, "half": 2}[mode]
+    return ("fp32", "split", "half")[_capi.load().scnerf_wgrad_arithmetic(code)]
 
 
 def nerf_wgrad(save: Tensor, grads: Tensor, d_raw: Tensor, P: int, flat_grad: Optional[Tensor] = None,
-               pd: int = 3, accumulate: bool = False) -> Tensor:
+               pd: int = 3, accumulate: bool = False, maxima: Optional[ChunkMaxima] = None) -> Tensor:
     """All parameter gradients of one network -> flat buffer (mlp_layout.Layout parameter order);
     `accumulate`: add to `flat_grad` instead of overwriting it."""
     lib = _capi.load()
@@ -617,10 +639,16 @@ def nerf_wgrad(save: Tensor, grads: Tensor, d_raw: Tensor, P: int, flat_grad: Op
         inner = None
         if PROFILE.enabled:
             # the dominant launch inside this C call -- the eight 256 x 256 GEMMs -- between two events of its own
-            inner = PROFILE.raw_pair("wgrad256_kernel<8 GEMMs, %s>%s/P=%d" % (wgrad_arithmetic(), tag, P), 8 * 2 * 256 * 256 * P)
+            mode = wgrad_arithmetic()
+            if mode == "half" and maxima is None:
+                mode = "split"
+            inner = PROFILE.raw_pair("wgrad256_kernel<8 GEMMs, %s>%s/P=%d" % (mode, tag, P), 8 * 2 * 256 * 256 * P)
             lib.scnerf_wgrad_profile_events(inner[0].cuda_event, inner[1].cuda_event)
-        st = lib.scnerf_nerf_wgrad(pd, _p(save), _p(grads), _p(d_raw), P, chunks, _p(_wgrad_ws[key]),
-                                   _p(flat_grad), int(bool(accumulate)), _stream())
+        if maxima is not None and maxima.chunks != chunks:
+            raise ValueError("chunk maxima of another chunking")
+        st = lib.scnerf_nerf_wgrad_h3(pd, _p(save), _p(grads), _p(d_raw), P, chunks, _p(_wgrad_ws[key]),
+                                      _p(flat_grad), int(bool(accumulate)), _p(maxima.x) if maxima else None,
+                                      _p(maxima.z) if maxima else None, _stream())
     _capi.check(st, "scnerf_nerf_wgrad")
     return flat_grad
 

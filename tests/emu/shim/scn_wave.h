@@ -218,6 +218,14 @@ inline float atomic_add(float* p, float v) {
     }
 }
 
+inline void atomic_max_nonneg(float* p, float v) {
+    uint32_t* u = reinterpret_cast<uint32_t*>(p);
+    uint32_t nv;
+    std::memcpy(&nv, &v, 4);
+    uint32_t old = __atomic_load_n(u, __ATOMIC_RELAXED);
+    while (old < nv && !__atomic_compare_exchange_n(u, &old, nv, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+
 inline void sincos(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
 
 }  // namespace scn

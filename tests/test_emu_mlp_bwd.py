@@ -90,7 +90,7 @@ def test_full_network_weight_gradients_match_autograd(pd, arith):
     try:
         _full_network_weight_gradients(pd)
     finally:
-        H.lib().scnerf_wgrad_arithmetic(1)
+        H.lib().scnerf_wgrad_arithmetic(2)
 
 
 def _full_network_weight_gradients(pd):

@@ -76,7 +76,7 @@ def test_resident_forward_matches_oracle(n_rays, spr, save, pd):
     vd = vd / vd.norm(dim=-1, keepdim=True)
     raw = np.full((P, 4), np.nan, np.float32)
     sv = np.full(lay.save_floats(P), np.nan, np.float32) if save else None
-    H.call("scnerf_mlp_fwd_h3", pd, pts.numpy(), vd.numpy(), 3, spr, wpk, fwd, sc, raw, sv, P, None)
+    H.call("scnerf_mlp_fwd_h3", pd, pts.numpy(), vd.numpy(), 3, spr, wpk, fwd, sc, raw, sv, P, None, 0, 0, None)
     ref = O.query_network(p, pts.reshape(n_rays, spr, pd), vd).reshape(P, 4)
     np.testing.assert_allclose(raw, ref.numpy(), rtol=2e-5, atol=2e-5)
     if save:
@@ -122,11 +122,11 @@ def test_resident_dgrad_matches_autograd(n_rays, spr, pd):
     d_raw[3] = 0.0
     raw = np.zeros((P, 4), np.float32)
     save = np.full(lay.save_floats(P), np.nan, np.float32)
-    H.call("scnerf_mlp_fwd_h3", pd, pts.numpy(), vd.numpy(), 3, spr, wpk, fwd, sc, raw, save, P, None)
+    H.call("scnerf_mlp_fwd_h3", pd, pts.numpy(), vd.numpy(), 3, spr, wpk, fwd, sc, raw, save, P, None, 0, 0, None)
     grads = np.full(ML.grad_floats(P), np.nan, np.float32)
     d_pts = np.full((P, pd), np.nan, np.float32)
     d_views = np.full((P, 3), np.nan, np.float32)
-    H.call("scnerf_mlp_bwd_h3", pd, d_raw.numpy(), pts.numpy(), vd.numpy(), 3, spr, wbk, bwd, sc, save, grads, d_pts, d_views, P, None)
+    H.call("scnerf_mlp_bwd_h3", pd, d_raw.numpy(), pts.numpy(), vd.numpy(), 3, spr, wbk, bwd, sc, save, grads, d_pts, d_views, P, None, 0, 0, None)
     ref = oracle_backward(p, pts, vd, spr, d_raw)
     gv = grad_views(grads, P)
 
@@ -148,3 +148,41 @@ def test_resident_dgrad_matches_autograd(n_rays, spr, pd):
     got_vd = d_views.reshape(n_rays, spr, 3).sum(1)
     sv = float(np.abs(ref["d_vd"].numpy()).max())
     assert float(np.abs(got_vd - ref["d_vd"].numpy()).max()) <= 3e-5 * sv
+
+
+def _tiled(m):
+    """[P, 256] -> tile-native section (P a multiple of 32)"""
+    P = m.shape[0]
+    return np.ascontiguousarray(m.reshape(P // 32, 32, 8, 4, 2, 4).transpose(0, 2, 3, 4, 1, 5)).reshape(-1)
+
+
+def test_half_weight_gradient_gemm_is_fp32_grade_on_the_interpreter():
+    """The 256 x 256 weight-gradient GEMM on three fp16 products with one scale per operand and workgroup chunk
+    (csrc/wgrad256_half.h) against fp64: per-sample gradient magnitudes spread over 2^40, half of X zero (post-ReLU), an
+    all-zero chunk.  With magnitudes this far apart a handful of samples carries each sum, so the bound is that of a
+    SINGLE product of two cut operands -- 3 x 2^-22 of |dz x| (two cuts and the dropped low x low term) -- not the
+    averaged-out error of a long sum, which the GPU test measures against the fp32 kernel on 65 536 samples.  Bias sums
+    exact to fp32 summation."""
+    rng = np.random.default_rng(5)
+    P, chunks = 512, 4                       # 128 samples per chunk = 8 slabs
+    dz = rng.standard_normal((P, 256)).astype(np.float32) * (2.0 ** rng.integers(-30, 10, (P, 1))).astype(np.float32)
+    x = rng.standard_normal((P, 256)).astype(np.float32) * (2.0 ** rng.integers(-3, 3, (P, 256))).astype(np.float32)
+    x *= rng.random((P, 256)) < 0.5
+    dz[128:256] = 0.0                        # a chunk whose gradient vanishes
+    chunk = H.lib().scnerf_wgrad_chunk_samples(P, chunks)
+    assert chunk == 128
+    amax_dz = np.abs(dz).reshape(chunks, -1).max(1).astype(np.float32)
+    amax_x = np.abs(x).reshape(chunks, -1).max(1).astype(np.float32)
+    ws = np.full(chunks * (65536 + 256), np.nan, np.float32)
+    dW = np.full((256, 256), np.nan, np.float32)
+    db = np.full(256, np.nan, np.float32)
+    H.call("scnerf_wgrad256_half", _tiled(dz), _tiled(x), P, chunks, ws, dW, db, amax_dz, amax_x, None)
+    ref = dz.astype(np.float64).T @ x.astype(np.float64)
+    scale = np.abs(dz).astype(np.float64).T @ np.abs(x).astype(np.float64)
+    err = np.abs(dW - ref) / scale
+    assert err.max() < 3 * 2.0 ** -22 and np.sqrt((err * err).mean()) < 1e-7, (err.max(), np.sqrt((err * err).mean()))
+    np.testing.assert_allclose(db, dz.astype(np.float64).sum(0), rtol=2e-5, atol=1e-30)
+    # maxima given too LARGE (a chunk mate outside this GEMM's view) only cost low-order bits of the small values
+    dW2 = np.full((256, 256), np.nan, np.float32)
+    H.call("scnerf_wgrad256_half", _tiled(dz), _tiled(x), P, chunks, ws, dW2, db, amax_dz * 64, amax_x * 64, None)
+    assert (np.abs(dW2 - ref) / scale).max() < 3 * 2.0 ** -22

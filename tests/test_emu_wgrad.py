@@ -41,7 +41,7 @@ def test_wgrad(arith, P, lda, n_load, n_out, a_tiled, ldb, k_load, k_out, b_tile
     try:
         _wgrad_case(P, lda, n_load, n_out, a_tiled, ldb, k_load, k_out, b_tiled, chunks, ldo, col0)
     finally:
-        assert H.lib().scnerf_wgrad_arithmetic(1) == 1
+        assert H.lib().scnerf_wgrad_arithmetic(2) == 2
 
 
 def _wgrad_case(P, lda, n_load, n_out, a_tiled, ldb, k_load, k_out, b_tiled, chunks, ldo, col0):
@@ -101,5 +101,5 @@ def test_split_products_are_fp32_grade():
                db, None)
         errs[arith] = float((np.abs(dW - ref) / scale).max())
         np.testing.assert_allclose(db, A.astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
-    assert H.lib().scnerf_wgrad_arithmetic(-1) == 1                      # query leaves the mode alone
+    assert H.lib().scnerf_wgrad_arithmetic(-1) == 2                      # query leaves the mode alone
     assert errs[1] <= 2.0 * errs[0] + 1e-9 and errs[1] < 1e-6, errs

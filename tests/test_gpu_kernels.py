@@ -210,13 +210,33 @@ def test_split_weight_gradient_gemm_is_fp32_grade(ops):
             out[mode] = dW
             np.testing.assert_allclose(db.cpu().numpy(), A.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
     finally:
-        ops.wgrad_arithmetic("split")
-    assert ops.wgrad_arithmetic() == "split"
+        ops.wgrad_arithmetic("half")
+    assert ops.wgrad_arithmetic() == "half"
+    # three fp16 products with one scale per operand and workgroup chunk (csrc/wgrad256_half.h), maxima as the
+    # resident kernels leave them; also with every sample's gradient scaled by its own power of two over 2^40
+    chunk = lib.scnerf_wgrad_chunk_samples(P, chunks)
+    ws2 = torch.empty(chunks * (65536 + 256), device="cuda")
+    for tag, Az in (("half", A), ("half_wide_range", A * torch.exp2(torch.randint(-30, 10, (P, 1), device="cuda", generator=g).float()))):
+        ref_z = Az.double().T @ B.double()
+        scale_z = Az.double().abs().T @ B.double().abs()
+        amax_a = Az.abs().view(chunks, -1).max(1)[0].contiguous()
+        amax_b = B.abs().view(chunks, -1).max(1)[0].contiguous()
+        assert chunk * chunks == P
+        dW = torch.full((256, 256), float("nan"), device="cuda")
+        db = torch.full((256,), float("nan"), device="cuda")
+        _capi.check(lib.scnerf_wgrad256_half(ops._p(tiled(Az)), ops._p(Bt), P, chunks, ops._p(ws2), ops._p(dW), ops._p(db),
+                                             ops._p(amax_a), ops._p(amax_b), ops._stream()), "scnerf_wgrad256_half")
+        e = (dW.double() - ref_z).abs() / scale_z
+        err[tag] = {"max": float(e.max()), "rms": float((e * e).mean().sqrt())}
+        np.testing.assert_allclose(db.cpu().numpy(), Az.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
     PA.REPORT["wgrad256_arithmetic_65536_samples"] = {
         "error_over_sum_abs_products_vs_fp64": err,
         "max_difference_between_the_two_over_sum_abs_products": float(((out["split"] - out["fp32"]).double().abs() / scale).max())}
     assert err["split"]["max"] <= 1.5 * err["fp32"]["max"] + 1e-9 and err["split"]["max"] < 2e-7, err
     assert err["split"]["rms"] <= 2.0 * err["fp32"]["rms"], err
+    assert err["half"]["max"] <= 2.0 * err["fp32"]["max"] + 1e-9 and err["half"]["rms"] <= 2.0 * err["fp32"]["rms"], err
+    # (a few samples carry each sum when magnitudes differ by 2^40: bounded by one cut product, 3 x 2^-22)
+    assert err["half_wide_range"]["max"] <= 3 * 2.0 ** -22 and err["half_wide_range"]["rms"] <= 1e-7, err
 
 
 @pytest.fixture(params=["split", "half"])

@@ -74,7 +74,7 @@ def arithmetic(request):
     from scnerf_amd import ops
     saved = (ops.mlp_arithmetic(), ops.wgrad_arithmetic())
     ops.mlp_arithmetic(request.param)
-    ops.wgrad_arithmetic("fp32" if request.param == "fp32" else "split")
+    ops.wgrad_arithmetic("fp32" if request.param == "fp32" else "half")
     yield request.param
     ops.mlp_arithmetic(saved[0])
     ops.wgrad_arithmetic(saved[1])

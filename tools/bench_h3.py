@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--spr", type=int, default=192)
     ap.add_argument("--out", default=None)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--only-resident-train", action="store_true", help="time the two resident training kernels only (ablation builds)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     pd = 3
@@ -58,6 +59,12 @@ def main():
         res[name] = {"ms": ms, "tflops_fp32_equiv": out["flop_per_pass"] / ms / 1e9}
         print("%-34s %8.3f ms  %7.1f TFLOP/s (algorithmic fp32)" % (name, ms, res[name]["tflops_fp32_equiv"]), flush=True)
 
+    if a.only_resident_train:
+        d_raw = torch.randn(P, 4, generator=g).to(dev) * 1e-3
+        run("resident train", lambda: ops.mlp_fwd_resident(pts, vd, a.spr, wpk, rw, save_b))
+        run("resident dgrad", lambda: ops.mlp_bwd_resident(d_raw, pts, vd, a.spr, wbk, rw, save_b))
+        print(json.dumps({k: round(v["ms"], 3) for k, v in res.items()}))
+        return
     run("fused fp32 train", lambda: ops.mlp_fwd(pts, vd, a.spr, wpk, save_a))
     run("fused fp32 infer", lambda: ops.mlp_fwd(pts, vd, a.spr, wpk, None))
     ops.mlp_arithmetic("half")

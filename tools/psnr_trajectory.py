@@ -93,7 +93,7 @@ def run_gpu(steps, every, arithmetic, perturb=0.0, perturb_seed=0, wgrad=None):
     from scnerf_amd.render import render_rays
     from scnerf_amd.run_nerf_helpers import NeRF, get_embedder
     ops.mlp_arithmetic(arithmetic)
-    ops.wgrad_arithmetic(wgrad or ("fp32" if arithmetic == "fp32" else "split"))
+    ops.wgrad_arithmetic(wgrad or ("fp32" if arithmetic == "fp32" else "half"))
     dev = torch.device("cuda")
     rays, target, train, held = scene()
     rays_d, target_d = rays.to(dev), target.to(dev)
