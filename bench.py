@@ -341,7 +341,11 @@ def extras_single_gpu(w, dev, sync):
                         "both sides; PSNR of the fine render on 2048 held-out rays (tools/psnr_trajectory.py)"
                         % (gold["steps"], gold["n_rand"], gold["samples"][0], gold["samples"][1], gold["lr"]),
             "arithmetic": saved[0], "final_psnr_gpu": curve[-1]["psnr"], "final_psnr_cpu_oracle": gold["final_psnr"],
+            "final_psnr_cpu_oracle_ensemble_mean_std": [gold["mean"][-1], gold["std"][-1]],
             "max_abs_psnr_difference_along_the_curve": max(abs(c["psnr"] - want[c["step"]]) for c in curve if c["step"] in want),
+            "note": "single trajectories of a chaotic training run differ by 0.05-0.2 dB where the curve is steep (the oracle's "
+                    "own 1e-7-perturbed ensemble: tests/golden/psnr_oracle.json); ensemble means agree within 0.1 dB "
+                    "(tests/test_gpu_psnr.py, profiles/psnr_r03.json)",
             "seconds_gpu": time.perf_counter() - t0, "seconds_cpu_oracle": gold["seconds"]}
     except Exception as e:                       # (reported, never fatal to the headline line)
         out["psnr_vs_reference"] = {"error": repr(e)}

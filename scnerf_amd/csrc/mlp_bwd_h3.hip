@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_h3_kernel(
     };
     auto scale_of = [&](int layer, int what) { return sc[layer * kScaleStride + what]; };
     auto amax_of = [&](float a) { return fmaxf(a, shfl_xor(a, 32)); };
-    auto note_chunk_max = [&](int job, float v) {
+    auto note_chunk_max = [&](int job, float v) __attribute__((always_inline)) {
         if (cm.amax == nullptr) return;
         v = fmaxf(v, shfl_xor(v, 16)); v = fmaxf(v, shfl_xor(v, 8)); v = fmaxf(v, shfl_xor(v, 4));
         v = fmaxf(v, shfl_xor(v, 2)); v = fmaxf(v, shfl_xor(v, 1));
@@ -245,7 +245,8 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_h3_kernel(
 
     // ---- a 256 -> 256 transposed layer: operand buffer X (its tiles 6, 7 still to come from `pend`), result -> X ^ 1;
     // leaves its own last pair pending.  Every such layer starts at stream unit 6 modulo 8.
-    auto trunk_layer = [&](auto x_tag, auto& pend, auto& cur, float bound_a, float bound_extra, int job) {
+    auto trunk_layer = [&](auto x_tag, auto& pend, auto& cur, float bound_a, float bound_extra, int job)
+                           __attribute__((always_inline)) {        // (not inlined, the operand arrays go to scratch)
         constexpr int X = decltype(x_tag)::value;
         auto operand = [&](auto s_tag, u32x4& xh, u32x4& xl) {
             constexpr int s = decltype(s_tag)::value;

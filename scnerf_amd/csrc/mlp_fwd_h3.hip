@@ -241,7 +241,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
     auto scale_of = [&](int layer, int what) { return sc[layer * kScaleStride + what]; };
     auto amax_of = [&](float a) { return fmaxf(a, shfl_xor(a, 32)); };
     // the largest of the wave's 32 samples -> the weight-gradient chunk this wave tile belongs to (one atomic per wave)
-    auto note_chunk_max = [&](int job, float v) {
+    auto note_chunk_max = [&](int job, float v) __attribute__((always_inline)) {
         if constexpr (TRAIN) {
             if (cm.amax == nullptr) return;
             v = fmaxf(v, shfl_xor(v, 16)); v = fmaxf(v, shfl_xor(v, 8)); v = fmaxf(v, shfl_xor(v, 4));
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
     // output buffer X ^ 1; NEF encoded-point slabs in front (the skip layer).  Leaves its own last pair pending.
     // U0: the layer's first stream unit modulo 8 (compile time).
     auto trunk_layer = [&](auto x_tag, auto nef_tag, auto u0_tag, auto& pend, auto& cur, int pend_mask_sect, int layer,
-                           float am_floor, float bound_floor) {
+                           float am_floor, float bound_floor) __attribute__((always_inline)) {
         constexpr int X = decltype(x_tag)::value, NEF = decltype(nef_tag)::value, U0 = decltype(u0_tag)::value;
         constexpr int NK = NEF + 16;
         auto operand = [&](auto s_tag, u32x4& xh, u32x4& xl) {

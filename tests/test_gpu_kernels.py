@@ -228,7 +228,8 @@ def test_split_weight_gradient_gemm_is_fp32_grade(ops):
                                              ops._p(amax_a), ops._p(amax_b), ops._stream()), "scnerf_wgrad256_half")
         e = (dW.double() - ref_z).abs() / scale_z
         err[tag] = {"max": float(e.max()), "rms": float((e * e).mean().sqrt())}
-        np.testing.assert_allclose(db.cpu().numpy(), Az.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+        eb = (db.double() - Az.double().sum(0)).abs() / Az.double().abs().sum(0)           # fp32 sums of 65 536 terms
+        assert float(eb.max()) <= 2e-6, (tag, float(eb.max()))
     PA.REPORT["wgrad256_arithmetic_65536_samples"] = {
         "error_over_sum_abs_products_vs_fp64": err,
         "max_difference_between_the_two_over_sum_abs_products": float(((out["split"] - out["fp32"]).double().abs() / scale).max())}

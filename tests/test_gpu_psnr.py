@@ -27,20 +27,30 @@ def test_scene_is_reproducible():
 @pytest.mark.gpu
 @pytest.mark.parametrize("arithmetic", ["resident", "half", "split", "fp32"])
 def test_psnr_trajectory_tracks_the_oracle(arithmetic):
+    """Training is chaotic: two runs of the SAME fp32 algorithm whose initial weights differ by a relative 1e-7 are
+    0.05-0.2 dB apart while the curve is steep (the CPU oracle's own ensemble in the fixture shows it, and so do eight
+    GPU runs per arithmetic: profiles/psnr_r03.json), so single trajectories are compared loosely and the ENSEMBLE MEAN
+    -- four runs with the fixture's four perturbations -- tightly: within 0.1 dB of the oracle ensemble's mean at every
+    checkpoint."""
     import sys
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import psnr_trajectory as T
     from scnerf_amd import ops
     from tests import parity_attribution as PA
-    want = {c["step"]: c["psnr"] for c in json.load(open(GOLDEN))["curve"]}
+    gold = json.load(open(GOLDEN))
+    n_ck = 5                                                    # checkpoints 0, 25, 50, 75, 100
+    want = np.array([e["psnr"][:n_ck] for e in gold["ensemble"]])
     saved = (ops.mlp_arithmetic(), ops.wgrad_arithmetic())
     try:
-        curve = T.run_gpu(100, 25, arithmetic)
+        got = np.array([[c["psnr"] for c in T.run_gpu(100, 25, arithmetic, e["perturb"], e["perturb_seed"])]
+                        for e in gold["ensemble"]])
     finally:
         ops.mlp_arithmetic(saved[0])
         ops.wgrad_arithmetic(saved[1])
-    got = {c["step"]: c["psnr"] for c in curve}
-    PA.REPORT["psnr_100_steps/" + arithmetic] = {"gpu": got, "oracle": {k: want[k] for k in got}}
-    assert got[100] > got[0] + 3.0                                   # it learns
-    for step in (25, 50, 75, 100):
-        assert abs(got[step] - want[step]) <= 0.1, (arithmetic, step, got[step], want[step])
+    PA.REPORT["psnr_100_steps/" + arithmetic] = {"checkpoints": gold["checkpoints"][:n_ck], "gpu_runs": got.tolist(),
+                                                 "gpu_mean": got.mean(0).tolist(), "oracle_mean": want.mean(0).tolist(),
+                                                 "oracle_std": want.std(0).tolist()}
+    assert (got[:, -1] > got[:, 0] + 3.0).all()                                    # it learns
+    assert np.abs(got.mean(0) - want.mean(0)).max() <= 0.1, (arithmetic, got.mean(0), want.mean(0))
+    assert np.abs(got - want.mean(0)).max() <= 0.4, (arithmetic, got, want.mean(0))
