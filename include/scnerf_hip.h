@@ -306,11 +306,14 @@ int scnerf_layer_split(int pt_dims, int layer, const short* planes, const float*
 int scnerf_wgrad_arithmetic(int mode);
 long long scnerf_nerf_wgrad_workspace_floats(int n_chunks);
 /* scnerf_nerf_wgrad with the eight 256 x 256 GEMMs on THREE fp16 products (csrc/wgrad256_half.h) when the chunk maxima
- * of their operands are given -- amax_x / amax_z [8][n_chunks], left by scnerf_mlp_fwd_h3 / scnerf_coarse_stage_fwd_h3
- * and scnerf_mlp_bwd_h3 for the same n_chunks -- and the arithmetic in force is 2 (the default); otherwise as
+ * of their operands are given -- amax_x / amax_z [8][scnerf_wgrad256_chunks(n_chunks)], left by scnerf_mlp_fwd_h3 /
+ * scnerf_coarse_stage_fwd_h3 and scnerf_mlp_bwd_h3 for that chunk count -- and the arithmetic in force is 2 (the default); otherwise as
  * scnerf_nerf_wgrad.  scnerf_wgrad_chunk_samples: the samples per workgroup chunk both sides use.
  * scnerf_wgrad256_half: one such GEMM with given maxima [n_chunks] (accuracy tests); workspace n_chunks * (65536 + 256). */
 long long scnerf_wgrad_chunk_samples(long long n_samples, int n_chunks);
+/* chunks the eight 256 x 256 GEMMs of scnerf_nerf_wgrad[_h3] split the samples into when the call is given n_chunks (an
+ * eighth: 32 x 8 jobs = one workgroup per CU): the chunk count of amax_x / amax_z. */
+int scnerf_wgrad256_chunks(int n_chunks);
 int scnerf_nerf_wgrad_h3(int pt_dims, const float* save, const float* grads, const float* d_raw,
                          long long n_samples, int n_chunks, float* workspace, float* flat_grad,
                          int accumulate, const float* amax_x, const float* amax_z, void* stream);

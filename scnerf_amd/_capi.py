@@ -68,6 +68,7 @@ PROTOTYPES = {
     "scnerf_wgrad": [P, I, I, I, I, P, I, I, I, I, LL, I, P, P, I, I, P, P],
     "scnerf_vecmat": [P, P, I, LL, I, P, P, P, P],
     "scnerf_wgrad_arithmetic": [I],
+    "scnerf_wgrad256_chunks": [I],
     "scnerf_wgrad_profile_events": [P, P],
     "scnerf_pack_split_planes": [I, P, P, P],
     "scnerf_mlp_fwd_split": [I, P, P, I, I, P, P, P, P, P, LL, P],

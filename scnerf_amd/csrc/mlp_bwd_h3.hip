@@ -79,8 +79,11 @@ struct BwdEpi : std::conditional_t<KIND == 1, Rank1, NoRank1>, std::conditional_
         constexpr int x = PIECE >> 2, q = PIECE & 3, T = 2 * P + x;
         constexpr int sl = 2 * T + (q >> 1), c0 = 2 * (q & 1);
         static_assert(sl < NS, "operand buffer too small for this tile");
-#ifdef SCN_H3_NO_EPI                // (timing experiment)
-        if constexpr (SUB == 10) { oh[sl][c0] += (unsigned)(acc[x][4 * q] > 1e30f); }
+#ifdef SCN_H3_NO_EPI                // (timing experiment: the epilogue reduced to moving the accumulators into the planes)
+        if constexpr (SUB == 1) {
+            oh[sl][c0] = __float_as_uint(acc[x][4 * q]) & 0x3bff3bffu; oh[sl][c0 + 1] = __float_as_uint(acc[x][4 * q + 1]) & 0x3bff3bffu;
+            ol[sl][c0] = __float_as_uint(acc[x][4 * q + 2]) & 0x3bff3bffu; ol[sl][c0 + 1] = __float_as_uint(acc[x][4 * q + 3]) & 0x3bff3bffu;
+        }
         return;
 #endif
         if constexpr (SUB == 0) {

@@ -45,7 +45,7 @@ struct NoDensity {};
 struct Density {
     float sg;                  // running dot product of the density head (this lane's half of the features)
     const float* alpha;        // its weights, LDS lane-vector table + 4 h
-    f32x4 wqs[2];              // (read a piece ahead, as the bias)
+    f32x4 wq;
 };
 template <bool ON> struct MaskBits { unsigned bits0, bits1, words[4]; };
 template <> struct MaskBits<false> {};
@@ -56,32 +56,31 @@ struct FwdEpi : std::conditional_t<KIND == 1, Density, NoDensity>, MaskBits<TRAI
     const float* bias;         // LDS lane-vector table of the layer, + 4 h
     global_bytes_rw save;      // this wave tile's block of the layer's section (TRAIN)
     unsigned lane16;
-    // The bias piece of (tile, quarter) is read from LDS ONE PIECE AHEAD into the other of two registers (piece
-    // parity): read in the slot in front of its first use it cost an LDS round trip per piece -- ~100 cycles, 32 times
-    // per layer, a quarter of a layer's MFMA time.  prime() reads the first piece of the layer (at construction).
-    f32x4 bqs[2];
+    // (reading the bias piece one piece ahead into a second register was tried: no difference, four registers more)
+    f32x4 bq;
     float v[4];
     unsigned hp;
 
-    __device__ __forceinline__ void prime() {
-        bqs[0] = *reinterpret_cast<const f32x4*>(bias);
-        if constexpr (KIND == 1) this->wqs[0] = *reinterpret_cast<const f32x4*>(this->alpha);
-    }
+    __device__ __forceinline__ void prime() {}
 
     template <int P, int PIECE, int SUB, int NS>
     __device__ __forceinline__ void sub(f32x16 (&acc)[2], u32x4 (&oh)[NS], u32x4 (&ol)[NS]) {
         constexpr int x = PIECE >> 2, q = PIECE & 3, T = 2 * P + x;
         constexpr int sl = 2 * T + (q >> 1), c0 = 2 * (q & 1);
         static_assert(sl < NS, "operand buffer too small for this tile");
-#ifdef SCN_H3_NO_EPI                // (timing experiment: the epilogue's arithmetic gone, the operand planes untouched)
-        if constexpr (SUB == 10) { oh[sl][c0] += (unsigned)(acc[x][4 * q] > 1e30f); }
+#ifdef SCN_H3_NO_EPI                // (timing experiment: the epilogue reduced to moving the accumulators into the planes)
+        if constexpr (SUB == 1) {
+            oh[sl][c0] = __float_as_uint(acc[x][4 * q]) & 0x3bff3bffu; oh[sl][c0 + 1] = __float_as_uint(acc[x][4 * q + 1]) & 0x3bff3bffu;
+            ol[sl][c0] = __float_as_uint(acc[x][4 * q + 2]) & 0x3bff3bffu; ol[sl][c0 + 1] = __float_as_uint(acc[x][4 * q + 3]) & 0x3bff3bffu;
+        }
         return;
 #endif
         if constexpr (SUB == 0) {
+            bq = *reinterpret_cast<const f32x4*>(bias + (4 * T + q) * 8);
+            if constexpr (KIND == 1) this->wq = *reinterpret_cast<const f32x4*>(this->alpha + (4 * T + q) * 8);
             if constexpr (TRAIN && KIND != 2 && PIECE == 0) { this->bits0 = 0u; this->bits1 = 0u; }
         } else if constexpr (SUB <= 4) {
             constexpr int e = SUB - 1;
-            const f32x4& bq = bqs[PIECE & 1];
             const float z = __builtin_fmaf(acc[x][4 * q + e], os, bq[e]);
             v[e] = KIND == 2 ? z : relu_raw(z);
             if constexpr (TRAIN && KIND != 2) {
@@ -93,11 +92,6 @@ struct FwdEpi : std::conditional_t<KIND == 1, Density, NoDensity>, MaskBits<TRAI
             else { am = max3(am, v[0], v[1]); am = max3(am, v[2], v[3]); }
         } else if constexpr (SUB == 6) {
             hp = pack_f16_scaled(v[0], v[1], s_next);
-            // the next piece's bias (the next pair's first piece after the last: tile 2 P + 2; beyond the layer's last
-            // tile the read is harmless -- the table region is followed by other tables)
-            constexpr int NT = PIECE < 7 ? 4 * (2 * P + ((PIECE + 1) >> 2)) + ((PIECE + 1) & 3) : 4 * (2 * P + 2);
-            bqs[(PIECE + 1) & 1] = *reinterpret_cast<const f32x4*>(bias + NT * 8);
-            if constexpr (KIND == 1) this->wqs[(PIECE + 1) & 1] = *reinterpret_cast<const f32x4*>(this->alpha + NT * 8);
         } else if constexpr (SUB == 7) {
             oh[sl][c0] = hp;
             ol[sl][c0] = pack_f16(residual_f16<0>(v[0], s_next, hp), residual_f16<1>(v[1], s_next, hp));
@@ -117,7 +111,7 @@ struct FwdEpi : std::conditional_t<KIND == 1, Density, NoDensity>, MaskBits<TRAI
         } else {
             if constexpr (KIND == 1) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) this->sg = __builtin_fmaf(this->wqs[PIECE & 1][e], v[e], this->sg);
+                for (int e = 0; e < 4; ++e) this->sg = __builtin_fmaf(this->wq[e], v[e], this->sg);
             }
             if constexpr (TRAIN && KIND != 2 && PIECE == 7) this->words[P] = (this->bits0 << 16) | this->bits1;
         }

@@ -113,7 +113,11 @@ __device__ __forceinline__ void stream_prime(Stream& ws, const void* stream, cha
     ws.cur = 0u;
 }
 
-// what the stream does in slot KAPPA (0 .. 47) of a chunk
+// what the stream does in slot KAPPA (0 .. 47) of a chunk: piece i of the NEXT chunk goes from its staging register to
+// LDS in slot 3 i, and the register is refilled right away (slot 3 i + 1) with piece i of the chunk after that -- a load
+// is waited for 47 slots (~1.6 us) after it was issued.  vmcnt counts loads AND stores in issue order: the wait also
+// covers every activation store issued before the load, and those take an HBM write's time to retire (with the loads
+// issued 24 slots ahead the waits cost ~0.4 ms of a 3 ms launch: SCN_H3_LATE_LOADS is that schedule).
 template <int KAPPA>
 __device__ __forceinline__ void stream_slot(Stream& ws, char* lds, unsigned tid16) {
 #ifndef SCN_H3_NO_STREAM            // (timing experiment)
@@ -124,10 +128,15 @@ __device__ __forceinline__ void stream_slot(Stream& ws, char* lds, unsigned tid1
     if constexpr (KAPPA == 30) block_sync();
 #endif
 #ifndef SCN_H3_NO_STREAM
-    if constexpr (KAPPA >= 24 && KAPPA % 3 == 0)
+#ifdef SCN_H3_LATE_LOADS
+    constexpr int LOAD_PIECE = (KAPPA >= 24 && KAPPA % 3 == 0) ? (KAPPA - 24) / 3 : -1;
+#else
+    constexpr int LOAD_PIECE = (KAPPA < 24 && KAPPA % 3 == 1) ? KAPPA / 3 : -1;
+#endif
+    if constexpr (LOAD_PIECE >= 0)
         // (opaque wave-uniform base + the thread's 32-bit offset: `global_load v, v_off, s[base]`; left to itself the
         //  compiler keeps a 64-bit per-lane pointer across the layer loop and spills it)
-        ws.stage[(KAPPA - 24) / 3] = load_f32x4(uniform_global(ws.g + ((KAPPA - 24) / 3) * 4096), pinned_here(tid16));
+        ws.stage[LOAD_PIECE] = load_f32x4(uniform_global(ws.g + LOAD_PIECE * 4096), pinned_here(tid16));
 #endif
     if constexpr (KAPPA == 47) {
         ws.cur = ws.next();
@@ -168,8 +177,10 @@ __device__ __forceinline__ void unit(Wave& w, u32x4 xhA, u32x4 xlA, u32x4 xhB, u
     constexpr int PH = U & 7, RP = U & 1;
     static_for<6>([&](auto j_tag) {
         constexpr int j = decltype(j_tag)::value;
-        fill(j_tag);
+        // (the stream first: its barrier drains the LDS queue -- `s_waitcnt lgkmcnt(0)` -- so it sits in front of the
+        //  reads this slot issues, not behind them)
         stream_slot<PH * 6 + j>(w.ws, w.lds, w.tid16);
+        fill(j_tag);
         if constexpr (j < 4) {
             // (the next unit may sit in the next chunk: its buffer is complete behind this chunk's barrier at slot 30.
             //  At j = 5 of unit 7 stream_slot has already switched buffers, hence the reads stay in slots 0 .. 3.)

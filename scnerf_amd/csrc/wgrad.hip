@@ -533,6 +533,11 @@ long long vecmat_ws_floats(long long n_chunks) { return (257 * n_chunks + 3) / 4
 // amax_x / amax_z (or nullptr): [8][n_chunks] chunk maxima of the X / dZ operands of the eight 256 x 256 GEMMs in the
 // order they are queued below (layers 1 .. 7, feature_linear), left by the resident kernels: with them the eight run
 // on three fp16 products (wgrad256_half.h) unless the arithmetic is switched to fp32 / split
+// The eight 256 x 256 GEMMs of a pass are ONE launch of (chunks, 8) workgroups, one per CU at a time: with an eighth of
+// the chunks the narrow GEMMs use, 256 chunks become 32 x 8 = 256 workgroups -- one wave over the chip, every workgroup
+// eight times as many samples -- and the partial slabs (256 KB each) shrink from 0.5 GB to 67 MB written and re-read.
+int big_chunks(int n_chunks) { return (n_chunks >= 8 && n_chunks % 8 == 0) ? n_chunks / 8 : n_chunks; }
+
 template <int PD>
 int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long long P, int n_chunks,
                float* workspace, float* g, int accumulate, void* stream, const float* amax_x = nullptr,
@@ -552,6 +557,7 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
     wg256::Args big;                 // the eight 256 x 256 GEMMs go out as one launch
     big.n_jobs = 0;
     float* ws = workspace + vecmat_ws_floats(n_chunks);   // [0, 257 G) rounded up: the vecmat partials
+    const int nb = big_chunks(n_chunks);                  // chunks of the eight 256 x 256 GEMMs
     hipStream_t st = (hipStream_t)stream;
 #define SCN_WG(...)                                                                            \
     {                                                                                          \
@@ -567,13 +573,13 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
     for (int l = 1; l <= 7; ++l) {
         if (l == 5) {
             SCN_WG(dz(5), 256, 256, 256, 1, S(kSaveEpts), EW, EW, IN, 0, P, n_chunks, ws, g + V::trunk_w(5), SK, 0, nullptr)
-            SCN_WG(dz(5), 256, 256, 256, 1, act(4), 256, 256, 256, 1, P, n_chunks, ws, g + V::trunk_w(5), SK, IN, g + V::trunk_b(5))
+            SCN_WG(dz(5), 256, 256, 256, 1, act(4), 256, 256, 256, 1, P, nb, ws, g + V::trunk_w(5), SK, IN, g + V::trunk_b(5))
         } else {
-            SCN_WG(dz(l), 256, 256, 256, 1, act(l - 1), 256, 256, 256, 1, P, n_chunks, ws, g + V::trunk_w(l), 256, 0, g + V::trunk_b(l))
+            SCN_WG(dz(l), 256, 256, 256, 1, act(l - 1), 256, 256, 256, 1, P, nb, ws, g + V::trunk_w(l), 256, 0, g + V::trunk_b(l))
         }
     }
     // feature_linear; alpha_linear (one output row) = d sigma^T . act7 with d sigma = d_raw[:, 3]
-    SCN_WG(G(kGradDfeat), 256, 256, 256, 1, act(7), 256, 256, 256, 1, P, n_chunks, ws, g + V::kWF, 256, 0, g + V::kBF)
+    SCN_WG(G(kGradDfeat), 256, 256, 256, 1, act(7), 256, 256, 256, 1, P, nb, ws, g + V::kWF, 256, 0, g + V::kBF)
     rc = vecmat_impl(act(7), d_raw + 3, 4, P, n_chunks, workspace, g + V::kWA, g + V::kBA, accumulate, stream);
     if (rc != 0) return rc;
     // views layer: [feature | encoded direction]
@@ -584,8 +590,8 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
 #undef SCN_WG
     if (big.n_jobs > 0) {
         if (g_profile_events[0]) SCN_HIP(hipEventRecord(g_profile_events[0], st));
-        rc = (amax_x && amax_z && wgrad_arithmetic() == 2) ? launch_wgrad256_half(big, n_chunks, amax_z, amax_x, st)
-                                                            : launch_wgrad256(big, n_chunks, st);
+        rc = (amax_x && amax_z && wgrad_arithmetic() == 2) ? launch_wgrad256_half(big, nb, amax_z, amax_x, st)
+                                                            : launch_wgrad256(big, nb, st);
         if (rc != 0) return rc;
         if (g_profile_events[1]) SCN_HIP(hipEventRecord(g_profile_events[1], st));
         g_profile_events[0] = g_profile_events[1] = nullptr;
@@ -621,6 +627,8 @@ extern "C" int scnerf_wgrad_arithmetic(int mode) {
     if (mode == 0 || mode == 1 || mode == 2) wgrad_arithmetic() = mode;
     return wgrad_arithmetic();
 }
+
+extern "C" int scnerf_wgrad256_chunks(int n_chunks) { return n_chunks < 1 ? -1 : big_chunks(n_chunks); }
 
 extern "C" long long scnerf_wgrad_chunk_samples(long long n_samples, int n_chunks) {
     if (n_samples < 0 || n_chunks < 1) return -1;

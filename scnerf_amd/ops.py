@@ -293,7 +293,7 @@ class ChunkMaxima:
     __slots__ = ("x", "z", "chunks", "chunk_samples")
 
     def __init__(self, P: int, device):
-        self.chunks = wgrad_chunks(P)
+        self.chunks = int(_capi.load().scnerf_wgrad256_chunks(wgrad_chunks(P)))
         self.chunk_samples = int(_capi.load().scnerf_wgrad_chunk_samples(int(P), self.chunks))
         both = torch.zeros((2, 8, self.chunks), dtype=torch.float32, device=device)
         self.x, self.z = both[0], both[1]
@@ -644,7 +644,7 @@ def nerf_wgrad(save: Tensor, grads: Tensor, d_raw: Tensor, P: int, flat_grad: Op
                 mode = "split"
             inner = PROFILE.raw_pair("wgrad256_kernel<8 GEMMs, %s>%s/P=%d" % (mode, tag, P), 8 * 2 * 256 * 256 * P)
             lib.scnerf_wgrad_profile_events(inner[0].cuda_event, inner[1].cuda_event)
-        if maxima is not None and maxima.chunks != chunks:
+        if maxima is not None and maxima.chunks != lib.scnerf_wgrad256_chunks(chunks):
             raise ValueError("chunk maxima of another chunking")
         st = lib.scnerf_nerf_wgrad_h3(pd, _p(save), _p(grads), _p(d_raw), P, chunks, _p(_wgrad_ws[key]),
                                       _p(flat_grad), int(bool(accumulate)), _p(maxima.x) if maxima else None,

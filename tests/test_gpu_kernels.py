@@ -175,6 +175,106 @@ def test_mlp_backward_and_weight_gradients_match_autograd(ops, pd, resident):
         grad_close(fg[o:o + int(np.prod(shape))].reshape(shape), p[name].grad.numpy(), name, q=0.99, tol_q=2e-3)
 
 
+def _gates_from_masks(mask_sec, P, ntile):
+    """lane-native ReLU bit words [tiles, 64 lanes, 4 words] -> bool [P, 32 ntile] (element 16 t + r of lane (m, h) =
+    feature feat_of(t, r, h): word i >> 5, bit 31 - (i & 31))"""
+    m = np.asarray(mask_sec, dtype=np.uint32)
+    out = np.zeros((m.shape[0] * 32, 32 * ntile), bool)
+    for t_ in range(ntile):
+        for r in range(16):
+            i = 16 * t_ + r
+            bit = (m[:, :, i >> 5] >> np.uint32(31 - (i & 31))) & np.uint32(1)           # [tiles, 64]
+            for hh in range(2):
+                out[:, ML.feat_of(t_, r, hh)] = bit[:, 32 * hh: 32 * hh + 32].reshape(-1).astype(bool)
+    return out[:P]
+
+
+@pytest.mark.parametrize("resident", [False, True], ids=["fused_fp32", "resident"])
+def test_relu_gate_flips_are_attributed(ops, resident):
+    """Gradient differences against autograd on the CPU, attributed like the sampler's (tests/parity_attribution.py):
+    the only discontinuity of the network is the ReLU gate, and a pre-activation within rounding of zero may land on
+    either side in two fp32 evaluations.  (1) every (sample, unit) whose gate differs between the kernel's saved bit
+    masks and the CPU run has a CPU pre-activation within a few roundings of zero -- relative to sum |w x| + |b|;
+    (2) with the KERNEL's gates imposed on the CPU run, everything agrees tightly: raw to 2e-5, every row of d pts to
+    2e-5 of the largest entry, every parameter gradient to 2e-5 (q0.999) / 1e-4 (max) of its largest entry (measured:
+    1e-6 and 5e-6, profiles/parity_r03.json) -- a hundred to five hundred times tighter than the unattributed bounds of
+    test_mlp_backward_and_weight_gradients_match_autograd, which have to absorb the flipped samples."""
+    import torch.nn.functional as F
+    from tests import parity_attribution as PA
+    from tests.emu_mlp_util import network_params, save_views
+    pd = 3
+    lay = ML.layout(pd)
+    p = {k: v.clone().requires_grad_(True) for k, v in network_params(4, pd).items()}
+    flat = dev(_flat({k: v.detach() for k, v in p.items()}, pd))
+    n_rays, spr = 64, 192
+    P = n_rays * spr
+    g = torch.Generator().manual_seed(21)
+    pts = (torch.rand(P, pd, generator=g) * 2.4 - 1.2).requires_grad_(True)
+    vd = torch.randn(n_rays, 3, generator=g)
+    vd = (vd / vd.norm(dim=-1, keepdim=True))
+    d_raw = torch.randn(P, 4, generator=g)
+    save = ops.save_workspace(P, "cuda", pd)
+    planes = ops.pack_resident(flat, pd) if resident else None
+    raw = ops.mlp_fwd(dev(pts.detach()), dev(vd), spr, ops.pack_weights(flat, "fwd", pd=pd), save, pd=pd, planes=planes)
+    grads, d_pts, d_views = ops.mlp_bwd(dev(d_raw), dev(pts.detach()), dev(vd), spr, ops.pack_weights(flat, "bwd", pd=pd), save,
+                                        pd=pd, planes=planes)
+    fg = ops.nerf_wgrad(save, grads, dev(d_raw), P, pd=pd).cpu().numpy()
+    sv = save_views(save.cpu().numpy(), P, pd)
+    gates = [torch.from_numpy(_gates_from_masks(sv["mask"][l], P, 8)) for l in range(8)]
+    gate_v = torch.from_numpy(_gates_from_masks(sv["mask"][8], P, 4))
+
+    vps = vd[:, None, :].expand(n_rays, spr, 3).reshape(P, 3)
+
+    def forward(impose):
+        e = O.positional_encoding(pts, 10)
+        ev = O.positional_encoding(vps, 4)
+        h, zs = e, []
+        for i in range(8):
+            z = F.linear(h, p["pts_linears.%d.weight" % i], p["pts_linears.%d.bias" % i])
+            zs.append((z, h))
+            h = z * gates[i] if impose else F.relu(z)
+            if i == 4:
+                h = torch.cat([e, h], -1)
+        sigma = F.linear(h, p["alpha_linear.weight"], p["alpha_linear.bias"])
+        feat = F.linear(h, p["feature_linear.weight"], p["feature_linear.bias"])
+        xin = torch.cat([feat, ev], -1)
+        zv = F.linear(xin, p["views_linears.0.weight"], p["views_linears.0.bias"])
+        zs.append((zv, xin))
+        hv = zv * gate_v if impose else F.relu(zv)
+        rgb = F.linear(hv, p["rgb_linear.weight"], p["rgb_linear.bias"])
+        return torch.cat([rgb, sigma], -1), zs
+
+    # (1) where the gates differ, the CPU pre-activation is within rounding of zero
+    with torch.no_grad():
+        _, zs = forward(False)
+    names = ["pts_linears.%d" % i for i in range(8)] + ["views_linears.0"]
+    n_flips, worst = 0, 0.0
+    for (z, x), gate, name in zip(zs, gates + [gate_v], names):
+        flip = (z > 0) != gate
+        n_flips += int(flip.sum())
+        if flip.any():
+            size = x.abs() @ p[name + ".weight"].detach().abs().T + p[name + ".bias"].detach().abs()
+            worst = max(worst, float((z.abs() / size)[flip].max()))
+    assert worst <= 4e-6, worst                   # a few fp32 roundings of the accumulated sum
+    # (2) the kernel's gates imposed on the CPU run
+    out, _ = forward(True)
+    np.testing.assert_allclose(raw.cpu().numpy(), out.detach().numpy(), rtol=2e-5, atol=2e-5)
+    (out * d_raw).sum().backward()
+    ref_pts = pts.grad.numpy()
+    row_err = np.abs(d_pts.cpu().numpy() - ref_pts).max(1) / np.abs(ref_pts).max()
+    assert row_err.max() <= 2e-5, row_err.max()
+    report = {"gate_flips": n_flips, "gates": int(sum(g_.numel() for g_ in gates) + gate_v.numel()),
+              "largest_flipped_preactivation_over_sum_abs": worst, "d_pts_worst_row": float(row_err.max()), "parameters": {}}
+    for name, shape in lay.param_shapes:
+        o = lay.param_offsets[name]
+        a, b = fg[o:o + int(np.prod(shape))].reshape(-1), p[name].grad.numpy().reshape(-1)
+        scale = float(np.abs(b).max()) + 1e-30
+        err = np.abs(a - b) / scale
+        report["parameters"][name] = {"q0.999": float(np.quantile(err, 0.999)), "max": float(err.max())}
+        assert np.quantile(err, 0.999) <= 2e-5 and err.max() <= 1e-4, (name, report["parameters"][name])
+    PA.REPORT["relu_gate_attribution/" + ("resident" if resident else "fused_fp32")] = report
+
+
 def test_split_weight_gradient_gemm_is_fp32_grade(ops):
     """The 256 x 256 weight-gradient GEMM on the bf16 matrix pipe (operands cut exactly into three bf16 numbers, six
     partial products; csrc/wgrad256_split.h) against fp64, beside the exact-fp32 MFMA kernel on the same
