@@ -463,11 +463,12 @@ def main():
     ops.PROFILE.enabled = False
     per_rank_ms, allreduce_info = None, None
     if world > 1:
-        mine = torch.tensor([dt / a.steps * 1e3], device=dev, dtype=torch.float64)
+        small = dev if a.backend == "nccl" else torch.device("cpu")      # (gloo gathers host tensors)
+        mine = torch.tensor([dt / a.steps * 1e3], device=small, dtype=torch.float64)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         per_rank_ms = [float(x.item()) for x in every]
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=small, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         allreduce_info = rccl_allreduce_probe(dev, int(reducer.flat.numel()))       # the step's collective on its own

@@ -181,7 +181,7 @@ def test_half_weight_gradient_gemm_is_fp32_grade_on_the_interpreter():
     scale = np.abs(dz).astype(np.float64).T @ np.abs(x).astype(np.float64)
     err = np.abs(dW - ref) / scale
     assert err.max() < 3 * 2.0 ** -22 and np.sqrt((err * err).mean()) < 1e-7, (err.max(), np.sqrt((err * err).mean()))
-    np.testing.assert_allclose(db, dz.astype(np.float64).sum(0), rtol=2e-5, atol=1e-30)
+    assert (np.abs(db - dz.astype(np.float64).sum(0)) / np.abs(dz).astype(np.float64).sum(0)).max() < 1e-6     # fp32 sums
     # maxima given too LARGE (a chunk mate outside this GEMM's view) only cost low-order bits of the small values
     dW2 = np.full((256, 256), np.nan, np.float32)
     H.call("scnerf_wgrad256_half", _tiled(dz), _tiled(x), P, chunks, ws, dW2, db, amax_dz * 64, amax_x * 64, None)

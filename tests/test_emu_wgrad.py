@@ -101,5 +101,6 @@ def test_split_products_are_fp32_grade():
                db, None)
         errs[arith] = float((np.abs(dW - ref) / scale).max())
         np.testing.assert_allclose(db, A.astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
-    assert H.lib().scnerf_wgrad_arithmetic(-1) == 2                      # query leaves the mode alone
+    assert H.lib().scnerf_wgrad_arithmetic(-1) == 1                      # query leaves the mode alone
+    assert H.lib().scnerf_wgrad_arithmetic(2) == 2                       # (the default again)
     assert errs[1] <= 2.0 * errs[0] + 1e-9 and errs[1] < 1e-6, errs
