@@ -337,7 +337,8 @@ int scnerf_nerf_wgrad(int pt_dims, const float* save, const float* grads, const 
  *
  * scnerf_h3_pack: flat parameters (reference registration order) -> the two fragment streams (fp16 planes of
  * weight x the layer's power-of-two scale, in the order a wave consumes them) and the scale table [12][8] floats
- * (per layer: Sw, 1 / Sw, largest row 1-norm A, largest |bias| B, largest column 1-norm A'); once per optimizer
+ * (per layer: Sw, 1 / Sw, largest row 1-norm A, largest |bias| B, largest column 1-norm A'; scnerf_h3_scale_floats()
+ * floats: the table followed by the scale pass's scratch); once per optimizer
  * step.  jobs [12][4] ints (weight offset, rows, columns, bias offset), idx_* [frags * 512] ints (flat parameter
  * index or -1), meta_* [frags] bytes (plane | layer << 1): the tables of scnerf_amd/mlp_layout.py (h3_plan,
  * h3_scale_jobs), device pointers.  A direction with frags == 0 is skipped. */

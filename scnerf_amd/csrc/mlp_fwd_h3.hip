@@ -21,58 +21,86 @@ using namespace scn;
 using namespace scn::h3;
 
 // ---- packing: flat parameters -> fp16 planes in fragment order, and the per-layer scales --------------------------------
-// jobs [12][4]: (weight offset, rows, columns, bias offset); table [12][8]: Sw, 1 / Sw, A, B, A'
-__global__ __launch_bounds__(256) void h3_scale_kernel(const float* __restrict__ params, const int* __restrict__ jobs,
-                                                       float* __restrict__ table) {
-    float* red = dynamic_lds<float>();                      // 256 floats
-    const int l = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+// jobs [12][4]: (weight offset, rows, columns, bias offset); table [12][8]: Sw, 1 / Sw, A, B, A'.  Two launches, every sum
+// in a fixed order (the scales must not change from run to run):
+//   h3_scale_partial_kernel  grid (12 layers, 16 row blocks): a block's 16 rows (a wave per row, coalesced along it) ->
+//                            the block's largest |w|, largest row 1-norm, largest |b| and its partial column sums
+//   h3_scale_finish_kernel   grid (12): column sums = the 16 partials added in order; the layer's five numbers
+constexpr int kScaleBlocks = 16, kScaleCols = 512;
+constexpr int kScalePartial = 4 + kScaleCols;      // floats per (layer, row block)
+
+__global__ __launch_bounds__(256) void h3_scale_partial_kernel(const float* __restrict__ params, const int* __restrict__ jobs,
+                                                               float* __restrict__ partial) {
+    float* red = dynamic_lds<float>();              // [4 waves][3] + [4 waves][512] column partials
+    float* cols_w = red + 16;
+    const int l = blockIdx.x, blk = blockIdx.y, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const float* wt = params + jobs[4 * l];
     const int rows = jobs[4 * l + 1], cols = jobs[4 * l + 2];
     const float* bs = params + jobs[4 * l + 3];
-    auto reduce_max = [&](float v) {
-        red[tid] = v;
-        block_sync();
-        for (int s = 128; s > 0; s >>= 1) {
-            if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
-            block_sync();
-        }
-        const float r = red[0];
-        block_sync();
-        return r;
-    };
-    // a wave per row (coalesced along the row), the row's 1-norm by a fixed-order wave reduction; a thread per column
-    // (coalesced across the threads): everything in a fixed order -- the scales must not change from run to run
+    const int per = (rows + kScaleBlocks - 1) / kScaleBlocks;
+    const int r0 = blk * per, r1 = min(rows, r0 + per);
     float mx = 0.f, rowsum = 0.f, bmax = 0.f;
-    for (int r = wave; r < rows; r += 4) {
+    float colp[kScaleCols / 64];
+#pragma unroll
+    for (int k = 0; k < kScaleCols / 64; ++k) colp[k] = 0.f;
+    for (int r = r0 + wave; r < r1; r += 4) {
         float s = 0.f;
-        for (int c = lane; c < cols; c += 64) {
-            const float a = fabsf(wt[(long)r * cols + c]);
+#pragma unroll
+        for (int k = 0; k < kScaleCols / 64; ++k) {
+            const int c = lane + 64 * k;
+            const float a = c < cols ? fabsf(wt[(long)r * cols + c]) : 0.f;
             s += a;
             mx = fmaxf(mx, a);
+            colp[k] += a;
         }
         for (int o = 32; o > 0; o >>= 1) s += shfl_xor(s, o);
         rowsum = fmaxf(rowsum, s);
         bmax = fmaxf(bmax, fabsf(bs[r]));
     }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, shfl_xor(mx, o));
+#pragma unroll
+    for (int k = 0; k < kScaleCols / 64; ++k) cols_w[wave * kScaleCols + lane + 64 * k] = colp[k];
+    if (lane == 0) { red[wave * 3] = mx; red[wave * 3 + 1] = rowsum; red[wave * 3 + 2] = bmax; }
+    block_sync();
+    float* out = partial + ((long)l * kScaleBlocks + blk) * kScalePartial;
+    if (tid < 3) out[tid] = fmaxf(fmaxf(red[tid], red[3 + tid]), fmaxf(red[6 + tid], red[9 + tid]));
+    for (int c = tid; c < kScaleCols; c += 256)
+        out[4 + c] = ((cols_w[c] + cols_w[kScaleCols + c]) + cols_w[2 * kScaleCols + c]) + cols_w[3 * kScaleCols + c];
+}
+
+__global__ __launch_bounds__(256) void h3_scale_finish_kernel(const float* __restrict__ partial, const int* __restrict__ jobs,
+                                                              float* __restrict__ table) {
+    float* red = dynamic_lds<float>();              // 256 floats
+    const int l = blockIdx.x, tid = threadIdx.x;
+    const int cols = jobs[4 * l + 2];
+    const float* p = partial + (long)l * kScaleBlocks * kScalePartial;
     float colsum = 0.f;
     for (int c = tid; c < cols; c += 256) {
         float s = 0.f;
-        for (int r = 0; r < rows; ++r) s += fabsf(wt[(long)r * cols + c]);
+        for (int b = 0; b < kScaleBlocks; ++b) s += p[b * kScalePartial + 4 + c];
         colsum = fmaxf(colsum, s);
     }
-    mx = reduce_max(mx);
-    rowsum = reduce_max(rowsum);
-    colsum = reduce_max(colsum);
-    bmax = reduce_max(bmax);
+    red[tid] = colsum;
+    block_sync();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+        block_sync();
+    }
     if (tid == 0) {
+        float mx = 0.f, rowsum = 0.f, bmax = 0.f;
+        for (int b = 0; b < kScaleBlocks; ++b) {
+            mx = fmaxf(mx, p[b * kScalePartial]);
+            rowsum = fmaxf(rowsum, p[b * kScalePartial + 1]);
+            bmax = fmaxf(bmax, p[b * kScalePartial + 2]);
+        }
         const float sw = scn::h3::scale_for(mx);
         float* t = table + l * kScaleStride;
         t[kSw] = sw;
         t[kSwInv] = scn::h3::inv_pow2(sw);
-        // (sums of up to 339 fp32 terms in any order: a relative 1e-4 covers their rounding)
+        // (sums of up to 339 fp32 terms: a relative 1e-4 covers their rounding)
         t[kBoundA] = rowsum * 1.0001f;
         t[kBoundB] = bmax;
-        t[kBoundAT] = colsum * 1.0001f;
+        t[kBoundAT] = red[0] * 1.0001f;
         t[5] = mx; t[6] = 0.f; t[7] = 0.f;
     }
 }
@@ -92,7 +120,10 @@ __global__ __launch_bounds__(256) void h3_pack_kernel(const float* __restrict__ 
 
 }  // namespace
 
-extern "C" long long scnerf_h3_scale_floats(void) { return (long long)kScaleLayers * kScaleStride; }
+// the scale table, followed by the scale pass's own scratch (per layer and row block: three maxima + column partials)
+extern "C" long long scnerf_h3_scale_floats(void) {
+    return (long long)kScaleLayers * kScaleStride + (long long)kScaleLayers * kScaleBlocks * kScalePartial;
+}
 
 extern "C" int scnerf_h3_pack(const float* flat_params, const int* jobs, const int* idx_fwd, const unsigned char* meta_fwd,
                               long long frags_fwd, const int* idx_bwd, const unsigned char* meta_bwd, long long frags_bwd,
@@ -101,7 +132,10 @@ extern "C" int scnerf_h3_pack(const float* flat_params, const int* jobs, const i
     SCN_RETURN_IF((frags_fwd > 0 && (!idx_fwd || !meta_fwd || !stream_fwd)) || (frags_bwd > 0 && (!idx_bwd || !meta_bwd || !stream_bwd)), SCN_EINVAL);
     SCN_RETURN_IF(frags_fwd < 0 || frags_bwd < 0, SCN_EINVAL);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(h3_scale_kernel, dim3(kScaleLayers), dim3(256), 1024, st, flat_params, jobs, scales);
+    float* partial = scales + kScaleLayers * kScaleStride;
+    hipLaunchKernelGGL(h3_scale_partial_kernel, dim3(kScaleLayers, kScaleBlocks), dim3(256), (16 + 4 * kScaleCols) * 4, st,
+                       flat_params, jobs, partial);
+    hipLaunchKernelGGL(h3_scale_finish_kernel, dim3(kScaleLayers), dim3(256), 1024, st, partial, jobs, scales);
     if (frags_fwd > 0)
         hipLaunchKernelGGL(h3_pack_kernel, dim3(scn_ceil_div(frags_fwd * 512, 256)), dim3(256), 0, st, flat_params, idx_fwd,
                            meta_fwd, scales, stream_fwd, (long)(frags_fwd * 512));

@@ -1,0 +1,10 @@
+#!/bin/bash
+# final evidence collection of the round (run on the GPU box)
+set -u
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r03
+(timeout 900 python -m pytest tests -m gpu -q > gpurun_out/r03/gpu_tests.txt 2>&1; echo rc=$? >> gpurun_out/r03/gpu_tests.txt)
+timeout 900 python bench.py > gpurun_out/r03/bench_n1.json 2> gpurun_out/r03/bench_n1.err
+timeout 600 bash tools/collect_profiles.sh r03 > gpurun_out/r03/collect.log 2>&1
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --one-device --no-cpu > gpurun_out/r03/bench_n2_gloo_one_device.json 2> gpurun_out/r03/bench_n2.err
+tail -3 gpurun_out/r03/gpu_tests.txt

@@ -10,13 +10,15 @@ import os
 import sys
 
 KEEP = ("mlp_fwd_kernel", "mlp_bwd_kernel", "mlp_fwd_h3_kernel", "mlp_bwd_h3_kernel", "wgrad256_kernel", "wgrad256_split_kernel",
+        "wgrad256_half_kernel", "copyBuffer",
         "layer_split_kernel", "wgrad_tiles_kernel", "wgrad_reduce_multi_kernel", "wgrad_kernel", "vecmat_kernel", "elementwise_kernel")
 
 # bench.py's region names of the kernels whose HBM traffic goes into profiles/pmc_traffic_r03.json (P = 786432)
 REGIONS = {"mlp_fwd_h3_kernel<3, true, false>": "mlp_fwd_h3_kernel/P=786432/train",
            "mlp_fwd_h3_kernel<3, false, false>": "mlp_fwd_h3_kernel/P=786432/infer",
            "mlp_bwd_h3_kernel<3>": "mlp_bwd_h3_kernel/P=786432",
-           "wgrad256_split_kernel<0>": "wgrad256_kernel<8 GEMMs, split>/P=786432"}
+           "wgrad256_split_kernel<0>": "wgrad256_kernel<8 GEMMs, split>/P=786432",
+           "wgrad256_half_kernel<0>": "wgrad256_kernel<8 GEMMs, half>/P=786432"}
 
 
 def traffic_json(agg, out_path, source):
@@ -36,15 +38,17 @@ def traffic_json(agg, out_path, source):
         f, w = mean(k, "FETCH_SIZE"), mean(k, "WRITE_SIZE")
         if f is None or w is None:
             continue
-        short = k.replace("void ", "").replace("scn::wg256s::", "")
+        short = k.replace("void ", "").replace("scn::wg256s::", "").replace("scn::wg256h::", "")
         per[short] = {"fetch_kb_raw": f, "write_kb": w, "bytes": int(w * 1024 + 2 * f * 1024)}
         for pat, region in REGIONS.items():
             if pat in short:
                 by_region[region] = per[short]["bytes"]
-    cal = [v for k, v in per.items() if "elementwise_kernel" in k]
+    # the calibration copy: the LARGEST dispatch of the runtime's blit kernel (small copies share its name)
+    cal = [{"fetch_kb_raw": max(agg[k]["FETCH_SIZE"]), "write_kb": max(agg[k]["WRITE_SIZE"])} for k in agg
+           if "copyBuffer" in k and agg[k].get("FETCH_SIZE") and agg[k].get("WRITE_SIZE")]
     rec = {"_csrc_sha16": bench.csrc_sha16(), "_source": source, "bytes_per_launch": by_region, "per_kernel": per}
     if cal:
-        c = max(cal, key=lambda v: v["bytes"])
+        c = max(cal, key=lambda v: v["write_kb"])
         rec["calibration_copy_1GiB_read_1GiB_written"] = {
             "fetch_kb_raw": c["fetch_kb_raw"], "write_kb": c["write_kb"],
             "read_bytes_counted_x2_over_known": 2 * c["fetch_kb_raw"] * 1024 / float(1 << 30),

@@ -26,15 +26,16 @@ def main():
     a = torch.rand(CALIBRATION_FLOATS, device="cuda")
     b = torch.empty_like(a)
     for _ in range(reps):
-        torch.add(a, 1.0, out=b)            # (an elementwise kernel; a plain copy_ goes through the runtime's blit)
+        b.copy_(a)                          # (the runtime's blit kernel, __amd_rocclr_copyBuffer: wide loads and stores)
     for _ in range(reps):
         ops.mlp_fwd(pts, vd, 192, wf, None, planes=rw)
+    mx = ops.ChunkMaxima(P, "cuda")
     for _ in range(reps):
-        ops.mlp_fwd(pts, vd, 192, wf, save, planes=rw)
+        ops.mlp_fwd(pts, vd, 192, wf, save, planes=rw, maxima=mx)
     for _ in range(reps):
-        grads, d_pts, d_views = ops.mlp_bwd(d_raw, pts, vd, 192, wb, save, planes=rw)
+        grads, d_pts, d_views = ops.mlp_bwd(d_raw, pts, vd, 192, wb, save, planes=rw, maxima=mx)
     for _ in range(reps):
-        ops.nerf_wgrad(save, grads, d_raw, P)
+        ops.nerf_wgrad(save, grads, d_raw, P, maxima=mx)
     if os.environ.get("WITH_FP32"):
         for _ in range(reps):
             ops.mlp_fwd(pts, vd, 192, wf, save)
