@@ -308,7 +308,11 @@ long long scnerf_nerf_wgrad_workspace_floats(int n_chunks);
 /* scnerf_nerf_wgrad with the eight 256 x 256 GEMMs on THREE fp16 products (csrc/wgrad256_half.h) when the chunk maxima
  * of their operands are given -- amax_x / amax_z [8][scnerf_wgrad256_chunks(n_chunks)], left by scnerf_mlp_fwd_h3 /
  * scnerf_coarse_stage_fwd_h3 and scnerf_mlp_bwd_h3 for that chunk count -- and the arithmetic in force is 2 (the default); otherwise as
- * scnerf_nerf_wgrad.  scnerf_wgrad_chunk_samples: the samples per workgroup chunk both sides use.
+ * scnerf_nerf_wgrad.  With `scales` (the table of scnerf_h3_pack) as well, the narrow GEMMs with a tile-native dZ
+ * (256 x 64 / 128 of the encoded-point layers, 128 x 256 of the views layer) run on three fp16 products too
+ * (csrc/wgrad_half_narrow.h): amax_z then has 11 rows -- 8: dZ of the views layer, 9: dZ of layer 0, 10: max(1, |point|),
+ * all left by scnerf_mlp_bwd_h3 -- and the feature is bounded through amax_x row 7 and the table.
+ * scnerf_wgrad_chunk_samples: the samples per workgroup chunk both sides use.
  * scnerf_wgrad256_half: one such GEMM with given maxima [n_chunks] (accuracy tests); workspace n_chunks * (65536 + 256). */
 long long scnerf_wgrad_chunk_samples(long long n_samples, int n_chunks);
 /* chunks the eight 256 x 256 GEMMs of scnerf_nerf_wgrad[_h3] split the samples into when the call is given n_chunks (an
@@ -316,10 +320,18 @@ long long scnerf_wgrad_chunk_samples(long long n_samples, int n_chunks);
 int scnerf_wgrad256_chunks(int n_chunks);
 int scnerf_nerf_wgrad_h3(int pt_dims, const float* save, const float* grads, const float* d_raw,
                          long long n_samples, int n_chunks, float* workspace, float* flat_grad,
-                         int accumulate, const float* amax_x, const float* amax_z, void* stream);
+                         int accumulate, const float* amax_x, const float* amax_z, const float* scales, void* stream);
 int scnerf_wgrad256_half(const float* dz_tiled, const float* x_tiled, long long n_samples, int n_chunks,
                          float* workspace, float* dW, float* db, const float* amax_dz, const float* amax_x,
                          void* stream);
+/* One of the narrow weight-gradient GEMMs on three fp16 products (csrc/wgrad_half_narrow.h; accuracy tests): dZ tile-native
+ * of width n_load (256 / 128), X row-major [n_samples][k_load] (k_load 64 / 128, x_tiled 0) or tile-native (k_load 256,
+ * x_tiled 1); amax_dz / amax_x [n_coarse]: the operands' maxima per chunk of coarse_chunk samples; workspace
+ * scnerf_wgrad_workspace_floats(n_load, k_load, n_chunks); dW [n_load][k_out], db [n_load] or NULL. */
+int scnerf_wgrad_half_narrow(const float* dz_tiled, int n_load, const float* x, int k_load, int k_out, int x_tiled,
+                             long long n_samples, int n_chunks, float* workspace, float* dW, float* db,
+                             const float* amax_dz, const float* amax_x, int n_coarse, long long coarse_chunk,
+                             void* stream);
 /* Measurement hook (bench.py): two hipEvent_t (created by the caller) that the NEXT scnerf_nerf_wgrad records on its
  * stream right before and after its one launch of the eight 256 x 256 GEMMs; cleared after use.  NULLs switch it off. */
 int scnerf_wgrad_profile_events(void* before, void* after);
@@ -348,7 +360,7 @@ int scnerf_h3_pack(const float* flat_params, const int* jobs, const int* idx_fwd
                    short* stream_fwd, short* stream_bwd, float* scales, void* stream);
 /* wpacked: the packed fp32 buffer of scnerf_gather_f32 (its lane-vector tables: biases, density head); save == NULL:
  * inference.  Arguments otherwise as scnerf_mlp_fwd / scnerf_coarse_stage_fwd. */
-/* chunk_amax (or NULL; training): [8][n_chunks] floats, zeroed by the caller -- the kernel leaves there, per
+/* chunk_amax (or NULL; training): [8][n_chunks] floats (scnerf_mlp_bwd_h3: [11][n_chunks]), zeroed by the caller -- the kernel leaves there, per
  * weight-gradient workgroup chunk of chunk_samples samples (scnerf_wgrad_chunk_samples), the largest |value| of the X
  * operand of each of the eight 256 x 256 weight-gradient GEMMs (scnerf_nerf_wgrad_h3). */
 int scnerf_mlp_fwd_h3(int pt_dims, const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,

@@ -202,6 +202,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_h3_kernel(
         epi_all<GateEpi, 1>(epiv, acc[1], bh[1], bl[1]);
     }
     const float am_v = amax_of(epiv.am);
+    note_chunk_max(8, am_v);            // dZ of the views layer: the A operand of its weight-gradient GEMMs
 
     // ---- views layer^T, encoded-direction rows first: d ev = (W_v^T)[256 ..] dZ_v -> d viewdirs ----
     auto hv_operand = [&](auto s_tag, u32x4& xh, u32x4& xl) {
@@ -329,6 +330,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_h3_kernel(
         float de[ES];
         tile_pair<6, 16>(w, acc[0], operand, [&](auto sg) { epi_slot<GateEpi, 3, decltype(sg)::value, 9>(prev, acc[1], bh[0], bl[0]); });
         const float os0 = inv_pow2(prev.s_next) * scale_of(0, kSwInv);
+        note_chunk_max(9, amax_of(prev.am));        // dZ of layer 0
         auto add_pair = [&](auto t0_tag, f32x16 (&a)[2]) {
             constexpr int T0 = decltype(t0_tag)::value;
 #pragma unroll
@@ -348,6 +350,12 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_h3_kernel(
             add_pair(I<2>{}, acc[1]);
         }
         float ga, gb;
+        {
+            // max(1, |point|) bounds every column of the encoded point (the point itself, sines and cosines)
+            float am_e = fmaxf(fmaxf(1.f, fabsf(pts[pc * PD + 0])), fmaxf(fabsf(pts[pc * PD + 1]), fabsf(pts[pc * PD + 2])));
+            if constexpr (PD == 4) am_e = fmaxf(am_e, fabsf(pts[pc * PD + 3]));
+            note_chunk_max(10, am_e);
+        }
         pe_backward<PD, 10, ES>(pts[pc * PD + 0], pts[pc * PD + 1], pts[pc * PD + 2], PD == 4 ? pts[pc * PD + (PD - 1)] : 0.f, h, de, &ga, &gb);
         const float oa = shfl_xor(ga, 32), ob = shfl_xor(gb, 32);
         if (live && h == 0) {

@@ -19,9 +19,11 @@
 
 #include "launch.h"
 #include "mlp_common.h"
+#include "mlp_h3.h"
 #include "scnerf_hip.h"
 #include "wgrad256.h"
 #include "wgrad256_half.h"
+#include "wgrad_half_narrow.h"
 #include "wgrad256_split.h"
 #include "wgrad_tiles.h"
 
@@ -409,6 +411,21 @@ int launch_wgrad_tiles(const wgt::Args& a, int G, hipStream_t stream) {
     return scn_launch_status();
 }
 
+// the same shapes on three fp16 products (wgrad_half_narrow.h)
+template <int NA, int NB, bool B_ROWMAJOR>
+int launch_wgrad_half_narrow(const wgnh::Args& a, int G, hipStream_t stream) {
+    SCN_LDS_OPT_IN((wgnh::wgrad_half_narrow_kernel<NA, NB, B_ROWMAJOR>), wgnh::kLdsBytes);
+    hipLaunchKernelGGL((wgnh::wgrad_half_narrow_kernel<NA, NB, B_ROWMAJOR>), dim3(G), dim3(wgnh::kThreads), wgnh::kLdsBytes, stream, a);
+    return scn_launch_status();
+}
+
+// where a narrow GEMM finds its operands' maxima (nullptr rows: stay on the fp32 MFMA)
+struct NarrowScales {
+    wgnh::Bound a, b;
+    int n_coarse;
+    long coarse_chunk;
+};
+
 struct Shape { int BN, BK; };
 
 bool pick_shape(int n_load, int k_load, Shape* s) {
@@ -432,7 +449,8 @@ namespace {
 // GEMM into partials at `workspace`; fills `job` (the reduction that finishes it) and returns the floats used
 int wgrad_gemm(const float* dz, int lda, int n_load, int n_out, int dz_tiled, const float* x, int ldb, int k_load,
                int k_out, int x_tiled, long long n_samples, int n_chunks, float* workspace, float* dW, int ldo,
-               int col0, float* db, hipStream_t st, ReduceJob* job, long long* used, wg256::Args* batch = nullptr) {
+               int col0, float* db, hipStream_t st, ReduceJob* job, long long* used, wg256::Args* batch = nullptr,
+               const NarrowScales* narrow = nullptr) {
     SCN_RETURN_IF(!dz || !x || !workspace || !dW || n_samples < 0 || n_chunks < 1, SCN_EINVAL);
     SCN_RETURN_IF(lda % 4 || ldb % 4 || n_load % 4 || k_load % 4 || n_out > n_load || k_out > k_load, SCN_EINVAL);
     SCN_RETURN_IF(((uintptr_t)dz | (uintptr_t)x | (uintptr_t)workspace) & 15, SCN_EINVAL);
@@ -466,10 +484,18 @@ int wgrad_gemm(const float* dz, int lda, int n_load, int n_out, int dz_tiled, co
         rc = batch ? 0 : launch_wgrad256(one, G, st);
     } else if (dz_tiled && n_load == lda && k_load == ldb && n_out <= n_load &&
                ((n_load == 256 && !x_tiled && (k_load == 64 || k_load == 128)) || (n_load == 128 && x_tiled && k_load == 256))) {
-        wgt::Args t{dz, x, a.part_w, db ? a.part_b : nullptr, a.P, a.Ppad, a.chunk};
-        if (n_load == 128) rc = launch_wgrad_tiles<128, 256, false>(t, G, st);
-        else if (k_load == 64) rc = launch_wgrad_tiles<256, 64, true>(t, G, st);
-        else rc = launch_wgrad_tiles<256, 128, true>(t, G, st);
+        if (narrow && narrow->a.amax && narrow->b.amax) {
+            wgnh::Args t{dz, x, a.part_w, db ? a.part_b : nullptr, a.P, a.Ppad, a.chunk, narrow->a, narrow->b,
+                         narrow->n_coarse, narrow->coarse_chunk};
+            if (n_load == 128) rc = launch_wgrad_half_narrow<128, 256, false>(t, G, st);
+            else if (k_load == 64) rc = launch_wgrad_half_narrow<256, 64, true>(t, G, st);
+            else rc = launch_wgrad_half_narrow<256, 128, true>(t, G, st);
+        } else {
+            wgt::Args t{dz, x, a.part_w, db ? a.part_b : nullptr, a.P, a.Ppad, a.chunk};
+            if (n_load == 128) rc = launch_wgrad_tiles<128, 256, false>(t, G, st);
+            else if (k_load == 64) rc = launch_wgrad_tiles<256, 64, true>(t, G, st);
+            else rc = launch_wgrad_tiles<256, 128, true>(t, G, st);
+        }
     } else if (s.BN == 256 && s.BK == 256) rc = launch_wgrad<4, 4>(a, G, st);
     else if (s.BN == 256 && s.BK == 128) rc = launch_wgrad<4, 2>(a, G, st);
     else if (s.BN == 256 && s.BK == 64) rc = launch_wgrad<4, 1>(a, G, st);
@@ -541,7 +567,7 @@ int big_chunks(int n_chunks) { return (n_chunks >= 8 && n_chunks % 8 == 0) ? n_c
 template <int PD>
 int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long long P, int n_chunks,
                float* workspace, float* g, int accumulate, void* stream, const float* amax_x = nullptr,
-               const float* amax_z = nullptr) {
+               const float* amax_z = nullptr, const float* scales = nullptr) {
     using namespace scn::mlp;
     using V = Var<PD>;
     const long long Ppad = scn::mlp::padded_samples(P);
@@ -559,20 +585,37 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
     float* ws = workspace + vecmat_ws_floats(n_chunks);   // [0, 257 G) rounded up: the vecmat partials
     const int nb = big_chunks(n_chunks);                  // chunks of the eight 256 x 256 GEMMs
     hipStream_t st = (hipStream_t)stream;
+    // the narrow GEMMs on three fp16 products: rows 8 .. 10 of the dZ maxima are dZ of the views layer, dZ of layer 0
+    // and max(1, |point|) >= the encoded point (mlp_bwd_h3_kernel.h); the feature is bounded through its layer
+    const bool half_narrow = amax_x && amax_z && scales && wgrad_arithmetic() == 2;
+    const long coarse_chunk = (long)scnerf_wgrad_chunk_samples(P, nb);
+    auto zrow = [&](int r) { return wgnh::Bound{amax_z + (long)r * nb, nullptr, nullptr}; };
+    const NarrowScales ns_l0{zrow(9), zrow(10), nb, coarse_chunk};
+    const NarrowScales ns_l5{zrow(4), zrow(10), nb, coarse_chunk};
+    const NarrowScales ns_views{zrow(8),
+                                wgnh::Bound{amax_x ? amax_x + 7L * nb : nullptr,
+                                            scales ? scales + scn::h3::kLayerFeat * scn::h3::kScaleStride + scn::h3::kBoundA : nullptr,
+                                            scales ? scales + scn::h3::kLayerFeat * scn::h3::kScaleStride + scn::h3::kBoundB : nullptr},
+                                nb, coarse_chunk};
+    const NarrowScales* narrow = nullptr;
 #define SCN_WG(...)                                                                            \
     {                                                                                          \
         long long used__ = 0;                                                                  \
-        rc = wgrad_gemm(__VA_ARGS__, st, &jobs.j[jobs.n], &used__, &big);                      \
+        rc = wgrad_gemm(__VA_ARGS__, st, &jobs.j[jobs.n], &used__, &big, narrow);              \
         if (rc != 0) return rc;                                                                \
         ws += used__;                                                                          \
         ++jobs.n;                                                                              \
     }
     // (dz, lda, n_load, n_out, tiled,  x, ldb, k_load, k_out, tiled,  P, chunks, ws, dW, ldo, col0, db)
     // layer 0: X = encoded points (row-major, IN valid of EW columns)
+    narrow = half_narrow ? &ns_l0 : nullptr;
     SCN_WG(dz(0), 256, 256, 256, 1, S(kSaveEpts), EW, EW, IN, 0, P, n_chunks, ws, g + V::kW0, IN, 0, g + V::kB0)
+    narrow = nullptr;
     for (int l = 1; l <= 7; ++l) {
         if (l == 5) {
+            narrow = half_narrow ? &ns_l5 : nullptr;
             SCN_WG(dz(5), 256, 256, 256, 1, S(kSaveEpts), EW, EW, IN, 0, P, n_chunks, ws, g + V::trunk_w(5), SK, 0, nullptr)
+            narrow = nullptr;
             SCN_WG(dz(5), 256, 256, 256, 1, act(4), 256, 256, 256, 1, P, nb, ws, g + V::trunk_w(5), SK, IN, g + V::trunk_b(5))
         } else {
             SCN_WG(dz(l), 256, 256, 256, 1, act(l - 1), 256, 256, 256, 1, P, nb, ws, g + V::trunk_w(l), 256, 0, g + V::trunk_b(l))
@@ -583,7 +626,9 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
     rc = vecmat_impl(act(7), d_raw + 3, 4, P, n_chunks, workspace, g + V::kWA, g + V::kBA, accumulate, stream);
     if (rc != 0) return rc;
     // views layer: [feature | encoded direction]
+    narrow = half_narrow ? &ns_views : nullptr;
     SCN_WG(G(kGradDzv), 128, 128, 128, 1, S(kSaveFeat), 256, 256, 256, 1, P, n_chunks, ws, g + V::kWV, 283, 0, g + V::kBV)
+    narrow = nullptr;
     SCN_WG(G(kGradDzv), 128, 128, 128, 1, S(kSaveEviews), 32, 32, 27, 0, P, n_chunks, ws, g + V::kWV, 283, 256, nullptr)
     // rgb_linear: dZ = d_raw[:, 0:3] (row-major), X = hidden of the views layer
     SCN_WG(d_raw, 4, 4, 3, 0, S(kSaveHv), 128, 128, 128, 1, P, n_chunks, ws, g + V::kWRGB, 128, 0, g + V::kBRGB)
@@ -640,11 +685,33 @@ extern "C" long long scnerf_wgrad_chunk_samples(long long n_samples, int n_chunk
 
 extern "C" int scnerf_nerf_wgrad_h3(int pt_dims, const float* save, const float* grads, const float* d_raw,
                                     long long n_samples, int n_chunks, float* workspace, float* flat_grad,
-                                    int accumulate, const float* amax_x, const float* amax_z, void* stream) {
+                                    int accumulate, const float* amax_x, const float* amax_z, const float* scales,
+                                    void* stream) {
     SCN_RETURN_IF(!save || !grads || !d_raw || !workspace || !flat_grad || n_samples < 1 || n_chunks < 1, SCN_EINVAL);
     SCN_RETURN_IF(pt_dims != 3 && pt_dims != 4, SCN_EINVAL);
-    if (pt_dims == 3) return nerf_wgrad<3>(save, grads, d_raw, n_samples, n_chunks, workspace, flat_grad, accumulate, stream, amax_x, amax_z);
-    return nerf_wgrad<4>(save, grads, d_raw, n_samples, n_chunks, workspace, flat_grad, accumulate, stream, amax_x, amax_z);
+    if (pt_dims == 3) return nerf_wgrad<3>(save, grads, d_raw, n_samples, n_chunks, workspace, flat_grad, accumulate, stream, amax_x, amax_z, scales);
+    return nerf_wgrad<4>(save, grads, d_raw, n_samples, n_chunks, workspace, flat_grad, accumulate, stream, amax_x, amax_z, scales);
+}
+
+// one narrow GEMM (256 x 64 / 256 x 128 with a row-major X, 128 x 256 with a tile-native X) on three fp16 products with
+// the maxima given per coarse chunk of coarse_chunk samples (tests: accuracy against fp64); workspace as scnerf_wgrad
+extern "C" int scnerf_wgrad_half_narrow(const float* dz_tiled, int n_load, const float* x, int k_load, int k_out,
+                                        int x_tiled, long long n_samples, int n_chunks, float* workspace, float* dW,
+                                        float* db, const float* amax_dz, const float* amax_x, int n_coarse,
+                                        long long coarse_chunk, void* stream) {
+    SCN_RETURN_IF(!amax_dz || !amax_x || n_coarse < 1 || coarse_chunk < 32, SCN_EINVAL);
+    SCN_RETURN_IF(!((n_load == 256 && !x_tiled && (k_load == 64 || k_load == 128)) || (n_load == 128 && x_tiled && k_load == 256)), SCN_ENOSUP);
+    ReduceJob j;
+    long long used;
+    hipStream_t st = (hipStream_t)stream;
+    const NarrowScales ns{wgnh::Bound{amax_dz, nullptr, nullptr}, wgnh::Bound{amax_x, nullptr, nullptr}, n_coarse, (long)coarse_chunk};
+    const int rc = wgrad_gemm(dz_tiled, n_load, n_load, n_load, 1, x, k_load, k_load, k_out, x_tiled, n_samples, n_chunks,
+                              workspace, dW, k_out, 0, db, st, &j, &used, nullptr, &ns);
+    SCN_RETURN_IF(rc != 0, rc);
+    const long total = (long)n_load * k_out + (db ? n_load : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(scn_ceil_div(total, 256)), dim3(256), 0, st, j.part_w, j.part_b,
+                       j.G, j.BN, j.BK, n_load, k_out, dW, k_out, 0, db);
+    return scn_launch_status();
 }
 
 // one 256 x 256 GEMM on three fp16 products with the chunk maxima given (tests: accuracy against fp64)

@@ -290,13 +290,16 @@ class ChunkMaxima:
     """Per weight-gradient workgroup chunk, the largest |value| of the operands of the eight 256 x 256 GEMMs of one
     network pass: `x` [8, chunks] left by the resident forward, `z` [8, chunks] by the resident data-gradient chain
     (one atomic max per wave and layer); with them the GEMMs run on three fp16 products (csrc/wgrad256_half.h)."""
-    __slots__ = ("x", "z", "chunks", "chunk_samples")
+    __slots__ = ("x", "z", "chunks", "chunk_samples", "scales")
 
     def __init__(self, P: int, device):
         self.chunks = int(_capi.load().scnerf_wgrad256_chunks(wgrad_chunks(P)))
         self.chunk_samples = int(_capi.load().scnerf_wgrad_chunk_samples(int(P), self.chunks))
-        both = torch.zeros((2, 8, self.chunks), dtype=torch.float32, device=device)
+        # rows 0 .. 7: the eight 256 x 256 GEMMs; rows 8 .. 10 of z: dZ of the views layer, dZ of layer 0, max(1, |point|)
+        # (left by the resident data-gradient kernel for the narrow GEMMs, csrc/wgrad_half_narrow.h)
+        both = torch.zeros((2, 11, self.chunks), dtype=torch.float32, device=device)
         self.x, self.z = both[0], both[1]
+        self.scales = None        # the scale table of the weights the data-gradient kernel ran with (mlp_bwd_resident)
 
 
 _h3_tables = {}
@@ -595,6 +598,8 @@ def mlp_bwd_resident(d_raw: Tensor, pts: Tensor, viewdirs: Tensor, samples_per_r
     d_pts = torch.empty((P, pd), dtype=torch.float32, device=dev)
     d_views = torch.empty((P, 3), dtype=torch.float32, device=dev)
     with PROFILE.region("mlp_bwd_h3_kernel%s/P=%d" % ("" if pd == 3 else "/pd4", P), 2 * _MAC_PER_SAMPLE[pd] * P):
+        if maxima is not None:
+            maxima.scales = rw.scales
         st = _capi.load().scnerf_mlp_bwd_h3(pd, _p(d_raw), _p(pts), vptr, vstride, int(samples_per_ray), _p(wpacked_bwd),
                                             _p(rw.bwd), _p(rw.scales), _p(save), _p(grads), _p(d_pts), _p(d_views), P,
                                             _p(maxima.z) if maxima else None, maxima.chunks if maxima else 0,
@@ -648,7 +653,8 @@ def nerf_wgrad(save: Tensor, grads: Tensor, d_raw: Tensor, P: int, flat_grad: Op
             raise ValueError("chunk maxima of another chunking")
         st = lib.scnerf_nerf_wgrad_h3(pd, _p(save), _p(grads), _p(d_raw), P, chunks, _p(_wgrad_ws[key]),
                                       _p(flat_grad), int(bool(accumulate)), _p(maxima.x) if maxima else None,
-                                      _p(maxima.z) if maxima else None, _stream())
+                                      _p(maxima.z) if maxima else None,
+                                      _p(maxima.scales) if maxima is not None and maxima.scales is not None else None, _stream())
     _capi.check(st, "scnerf_nerf_wgrad")
     return flat_grad
 

@@ -186,3 +186,46 @@ def test_half_weight_gradient_gemm_is_fp32_grade_on_the_interpreter():
     dW2 = np.full((256, 256), np.nan, np.float32)
     H.call("scnerf_wgrad256_half", _tiled(dz), _tiled(x), P, chunks, ws, dW2, db, amax_dz * 64, amax_x * 64, None)
     assert (np.abs(dW2 - ref) / scale).max() < 3 * 2.0 ** -22
+
+
+def _tiled_w(m):
+    """[P, W] -> tile-native section of width W (P a multiple of 32, W of 32)"""
+    P, W = m.shape
+    return np.ascontiguousarray(m.reshape(P // 32, 32, W // 32, 4, 2, 4).transpose(0, 2, 3, 4, 1, 5)).reshape(-1)
+
+
+@pytest.mark.parametrize("shape", ["256x64", "256x128", "128x256"])
+def test_narrow_half_weight_gradient_gemms_on_the_interpreter(shape):
+    """The narrow weight-gradient GEMMs on three fp16 products (csrc/wgrad_half_narrow.h) against fp64: a row-major X
+    with garbage in the rows beyond the valid samples (staged as zeros), valid columns fewer than loaded ones, more
+    workgroups than coarse chunks of the maxima (a workgroup takes the largest maximum its range touches), a workgroup
+    range straddling two coarse chunks, an all-zero stretch; bias sums exact to fp32 summation."""
+    rng = np.random.default_rng(11)
+    wa, wb = (int(v) for v in shape.split("x"))
+    tiled_x = wb == 256
+    k_out = wb if tiled_x else wb - 1
+    P, Ppad, chunks = 500, 512, 8                      # 64 samples per workgroup = 4 slabs
+    n_coarse, coarse = 3, 192                          # 192, 192, 128 samples: workgroup 2 and 5 straddle
+    dz = np.zeros((Ppad, wa), np.float32)
+    dz[:P] = rng.standard_normal((P, wa)).astype(np.float32) * (2.0 ** rng.integers(-20, 6, (P, 1))).astype(np.float32)
+    dz[256:320] = 0.0
+    x = rng.standard_normal((Ppad, wb)).astype(np.float32) * (2.0 ** rng.integers(-3, 3, (Ppad, wb))).astype(np.float32)
+    if tiled_x:
+        x[P:] = 0.0                                    # a tile-native X is zero beyond the valid samples (the forward writes it)
+        xin = _tiled_w(x)
+    else:
+        x[P:] = np.nan                                 # a row-major X may hold anything there
+        xin = x.reshape(-1).copy()
+    xv = np.where(np.arange(Ppad)[:, None] < P, x, 0.0)
+    amax_dz = np.array([np.abs(dz[c * coarse:(c + 1) * coarse]).max() for c in range(n_coarse)], np.float32)
+    amax_x = np.array([np.abs(xv[c * coarse:(c + 1) * coarse]).max() for c in range(n_coarse)], np.float32)
+    ws = np.full(H.lib().scnerf_wgrad_workspace_floats(wa, wb, chunks), np.nan, np.float32)
+    dW = np.full((wa, k_out), np.nan, np.float32)
+    db = np.full(wa, np.nan, np.float32)
+    H.call("scnerf_wgrad_half_narrow", _tiled_w(dz), wa, xin, wb, k_out, int(tiled_x), P, chunks, ws, dW, db, amax_dz, amax_x,
+           n_coarse, coarse, None)
+    ref = dz.astype(np.float64).T @ xv.astype(np.float64)[:, :k_out]
+    scale = np.abs(dz).astype(np.float64).T @ np.abs(xv).astype(np.float64)[:, :k_out]
+    err = np.abs(dW - ref) / scale
+    assert err.max() < 3 * 2.0 ** -22 and np.sqrt((err * err).mean()) < 1e-7, (err.max(), np.sqrt((err * err).mean()))
+    assert (np.abs(db - dz.astype(np.float64).sum(0)) / np.abs(dz).astype(np.float64).sum(0)).max() < 1e-6
