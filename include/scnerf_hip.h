@@ -310,8 +310,9 @@ long long scnerf_nerf_wgrad_workspace_floats(int n_chunks);
  * scnerf_coarse_stage_fwd_h3 and scnerf_mlp_bwd_h3 for that chunk count -- and the arithmetic in force is 2 (the default); otherwise as
  * scnerf_nerf_wgrad.  With `scales` (the table of scnerf_h3_pack) as well, the narrow GEMMs with a tile-native dZ
  * (256 x 64 / 128 of the encoded-point layers, 128 x 256 of the views layer) run on three fp16 products too
- * (csrc/wgrad_half_narrow.h): amax_z then has 11 rows -- 8: dZ of the views layer, 9: dZ of layer 0, 10: max(1, |point|),
- * all left by scnerf_mlp_bwd_h3 -- and the feature is bounded through amax_x row 7 and the table.
+ * (csrc/wgrad_half_narrow.h): amax_z then has 12 rows -- 8: dZ of the views layer, 9: dZ of layer 0, 10: max(1, |point|),
+ * 11: max(1, |direction|), all left by scnerf_mlp_bwd_h3 -- and the feature is bounded through amax_x row 7 and the
+ * table.
  * scnerf_wgrad_chunk_samples: the samples per workgroup chunk both sides use.
  * scnerf_wgrad256_half: one such GEMM with given maxima [n_chunks] (accuracy tests); workspace n_chunks * (65536 + 256). */
 long long scnerf_wgrad_chunk_samples(long long n_samples, int n_chunks);
@@ -360,7 +361,7 @@ int scnerf_h3_pack(const float* flat_params, const int* jobs, const int* idx_fwd
                    short* stream_fwd, short* stream_bwd, float* scales, void* stream);
 /* wpacked: the packed fp32 buffer of scnerf_gather_f32 (its lane-vector tables: biases, density head); save == NULL:
  * inference.  Arguments otherwise as scnerf_mlp_fwd / scnerf_coarse_stage_fwd. */
-/* chunk_amax (or NULL; training): [8][n_chunks] floats (scnerf_mlp_bwd_h3: [11][n_chunks]), zeroed by the caller -- the kernel leaves there, per
+/* chunk_amax (or NULL; training): [8][n_chunks] floats (scnerf_mlp_bwd_h3: [12][n_chunks]), zeroed by the caller -- the kernel leaves there, per
  * weight-gradient workgroup chunk of chunk_samples samples (scnerf_wgrad_chunk_samples), the largest |value| of the X
  * operand of each of the eight 256 x 256 weight-gradient GEMMs (scnerf_nerf_wgrad_h3). */
 int scnerf_mlp_fwd_h3(int pt_dims, const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,

@@ -217,6 +217,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_h3_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) dev[r] = (acce[0][r] + acce[1][r]) * os;
         const long ray = pc / samples_per_ray;
+        // max(1, |direction|) bounds every column of the encoded direction
+        note_chunk_max(11, fmaxf(fmaxf(1.f, fabsf(viewdirs[ray * vd_stride + 0])),
+                                 fmaxf(fabsf(viewdirs[ray * vd_stride + 1]), fabsf(viewdirs[ray * vd_stride + 2]))));
         float gxy, gz;
         pe_backward<3, 4, 16>(viewdirs[ray * vd_stride + 0], viewdirs[ray * vd_stride + 1], viewdirs[ray * vd_stride + 2], 0.f, h, dev, &gxy, &gz);
         const float oxy = shfl_xor(gxy, 32), oz = shfl_xor(gz, 32);

@@ -267,6 +267,74 @@ __global__ __launch_bounds__(kThreads) void vecmat_kernel(const float* __restric
     }
 }
 
+// dW[c][k] = sum_p V[p][c] * X[p][k], db[c] = sum_p V[p][c] for c < 4: V row-major [P][4], X tile-native of width 128
+// (rgb_linear's weight gradient: V = d_raw, whose fourth column -- d sigma -- is summed along and not reduced; X = the
+// hidden layer of the views branch).  As vecmat_kernel: HBM-bound, X is read once, a thread owns the same 4 features of
+// the same in-tile sample in every tile it visits; two tiles per iteration keep eight 16-byte loads in flight per thread.
+// Partials [G][4][128] and [G][4] in ReduceJob's layout.
+__global__ __launch_bounds__(kThreads) void rows4_kernel(const float* __restrict__ X, const float* __restrict__ V, long P,
+                                                         long n_tiles, float* __restrict__ part_w, float* __restrict__ part_b) {
+    const int tid = threadIdx.x, lane = lane_id();
+    const int m = lane & 31;
+    f32x4 acc[4][4];       // [piece][row]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 vs = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long tile = blockIdx.x; tile < n_tiles; tile += 2L * gridDim.x) {
+        const long tile2 = tile + gridDim.x;
+        const bool two = tile2 < n_tiles;
+        const long p0 = tile * 32 + m, p1 = tile2 * 32 + m;
+        const f32x4 v0 = p0 < P ? *reinterpret_cast<const f32x4*>(V + p0 * 4) : zero;
+        const f32x4 v1 = (two && p1 < P) ? *reinterpret_cast<const f32x4*>(V + p1 * 4) : zero;
+        if (tid < 32) vs += v0 + v1;
+        const f32x4* blk0 = reinterpret_cast<const f32x4*>(X + tile * (32L * 128));
+        const f32x4* blk1 = reinterpret_cast<const f32x4*>(X + (two ? tile2 : tile) * (32L * 128));
+        f32x4 x0[4], x1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x0[i] = blk0[tid + kThreads * i]; x1[i] = blk1[tid + kThreads * i]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][c][j] = fmaf(v1[c], x1[i][j], fmaf(v0[c], x0[i][j], acc[i][c][j]));
+    }
+    // fold the 32 samples (lanes with equal lane >> 5); piece tid + 256 i = (t * 4 + q) * 64 + lane
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = acc[i][c][j];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) x += shfl_xor(x, o);
+                acc[i][c][j] = x;
+            }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float x = vs[c];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) x += shfl_xor(x, o);
+        vs[c] = x;
+    }
+    float* ow = part_w + (long)blockIdx.x * (4 * 128);
+    if (m == 0) {
+        const int h = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tq = (tid + kThreads * i) >> 6;          // t * 4 + q
+            const int col = (tq >> 2) * 32 + (tq & 3) * 8 + 4 * h;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(ow + c * 128 + col) = acc[i][c];
+        }
+        if (tid == 0) *reinterpret_cast<f32x4*>(part_b + (long)blockIdx.x * 4) = vs;
+    }
+}
+
 // fixed-order sum over the G partials with four independent accumulators (four loads in flight per
 // thread: the single-accumulator loop was latency-bound at ~1 TB/s)
 __device__ __forceinline__ float sum_partials(const float* __restrict__ p, long stride, int G) {
@@ -486,7 +554,7 @@ int wgrad_gemm(const float* dz, int lda, int n_load, int n_out, int dz_tiled, co
                ((n_load == 256 && !x_tiled && (k_load == 64 || k_load == 128)) || (n_load == 128 && x_tiled && k_load == 256))) {
         if (narrow && narrow->a.amax && narrow->b.amax) {
             wgnh::Args t{dz, x, a.part_w, db ? a.part_b : nullptr, a.P, a.Ppad, a.chunk, narrow->a, narrow->b,
-                         narrow->n_coarse, narrow->coarse_chunk};
+                         narrow->n_coarse, narrow->coarse_chunk, nullptr, nullptr, wgnh::Bound{nullptr, nullptr, nullptr}};
             if (n_load == 128) rc = launch_wgrad_half_narrow<128, 256, false>(t, G, st);
             else if (k_load == 64) rc = launch_wgrad_half_narrow<256, 64, true>(t, G, st);
             else rc = launch_wgrad_half_narrow<256, 128, true>(t, G, st);
@@ -626,12 +694,45 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
     rc = vecmat_impl(act(7), d_raw + 3, 4, P, n_chunks, workspace, g + V::kWA, g + V::kBA, accumulate, stream);
     if (rc != 0) return rc;
     // views layer: [feature | encoded direction]
-    narrow = half_narrow ? &ns_views : nullptr;
-    SCN_WG(G(kGradDzv), 128, 128, 128, 1, S(kSaveFeat), 256, 256, 256, 1, P, n_chunks, ws, g + V::kWV, 283, 0, g + V::kBV)
-    narrow = nullptr;
-    SCN_WG(G(kGradDzv), 128, 128, 128, 1, S(kSaveEviews), 32, 32, 27, 0, P, n_chunks, ws, g + V::kWV, 283, 256, nullptr)
+    if (half_narrow) {
+        // one launch for both X operands of the views layer: dZ is read (and cut) once (wgrad_half_narrow.h, WB2 = 32)
+        const int Gv = n_chunks;
+        long chunk = (Ppad + Gv - 1) / Gv;
+        chunk = (chunk + kMS - 1) / kMS * kMS;
+        float* part_w = ws;
+        float* part_b = part_w + (long)Gv * 128 * 256;
+        float* part_w2 = part_b + (long)Gv * 128;
+        wgnh::Args t{G(kGradDzv), S(kSaveFeat), part_w, part_b, (long)P, (long)Ppad, chunk, ns_views.a, ns_views.b, nb, coarse_chunk,
+                     S(kSaveEviews), part_w2, zrow(11)};
+        SCN_LDS_OPT_IN((wgnh::wgrad_half_narrow_kernel<128, 256, false, 32>), wgnh::kLdsBytes);
+        hipLaunchKernelGGL((wgnh::wgrad_half_narrow_kernel<128, 256, false, 32>), dim3(Gv), dim3(wgnh::kThreads), wgnh::kLdsBytes, st, t);
+        rc = scn_launch_status();
+        if (rc != 0) return rc;
+        ReduceJob& J1 = jobs.j[jobs.n++];
+        J1.part_w = part_w; J1.part_b = part_b; J1.dW = g + V::kWV; J1.db = g + V::kBV;
+        J1.G = Gv; J1.BN = 128; J1.BK = 256; J1.n_out = 128; J1.k_out = 256; J1.ldo = 283; J1.col0 = 0; J1.block0 = 0;
+        ReduceJob& J2 = jobs.j[jobs.n++];
+        J2.part_w = part_w2; J2.part_b = nullptr; J2.dW = g + V::kWV; J2.db = nullptr;
+        J2.G = Gv; J2.BN = 128; J2.BK = 32; J2.n_out = 128; J2.k_out = 27; J2.ldo = 283; J2.col0 = 256; J2.block0 = 0;
+        ws += (long)Gv * (128 * 256 + 128 + 128 * 32);
+    } else {
+        SCN_WG(G(kGradDzv), 128, 128, 128, 1, S(kSaveFeat), 256, 256, 256, 1, P, n_chunks, ws, g + V::kWV, 283, 0, g + V::kBV)
+        SCN_WG(G(kGradDzv), 128, 128, 128, 1, S(kSaveEviews), 32, 32, 27, 0, P, n_chunks, ws, g + V::kWV, 283, 256, nullptr)
+    }
     // rgb_linear: dZ = d_raw[:, 0:3] (row-major), X = hidden of the views layer
-    SCN_WG(d_raw, 4, 4, 3, 0, S(kSaveHv), 128, 128, 128, 1, P, n_chunks, ws, g + V::kWRGB, 128, 0, g + V::kBRGB)
+    {
+        // (rows4_kernel: the hidden layer is read once at the HBM rate; the general kernel pads three rows to a 64-row tile)
+        const int Gr = n_chunks;
+        float* part_w = ws;
+        float* part_b = ws + (long)Gr * 4 * 128;
+        hipLaunchKernelGGL(rows4_kernel, dim3(Gr), dim3(kThreads), 0, st, S(kSaveHv), d_raw, (long)P, (long)(Ppad / 32), part_w, part_b);
+        rc = scn_launch_status();
+        if (rc != 0) return rc;
+        ReduceJob& J = jobs.j[jobs.n++];
+        J.part_w = part_w; J.part_b = part_b; J.dW = g + V::kWRGB; J.db = g + V::kBRGB;
+        J.G = Gr; J.BN = 4; J.BK = 128; J.n_out = 3; J.k_out = 128; J.ldo = 128; J.col0 = 0; J.block0 = 0;
+        ws += (long)Gr * (4 * 128 + 4);
+    }
 #undef SCN_WG
     if (big.n_jobs > 0) {
         if (g_profile_events[0]) SCN_HIP(hipEventRecord(g_profile_events[0], st));

@@ -23,6 +23,11 @@
 // too LARGE only costs low-order bits of the small values (wgrad256_half.h).
 //
 // A row-major B operand may hold anything in rows >= P: those rows are staged as zeros (as wgrad_tiles.h).
+//
+// Second X operand (WB2 = 32; the views layer: X = [feature | encoded direction]).  The 128 x 32 product against the
+// encoded direction shares dZ with the 128 x 256 one, so it rides along instead of reading dZ again: its 32 columns
+// (row-major [P][32]) take the unused half of the LDS row's A region (WA = 128 fills tiles 0 .. 3; tile 4 holds them),
+// waves 0 and 1 stage them, and the waves with wk = 0 multiply them with their A tiles into TA more accumulators.
 #pragma once
 #include <type_traits>
 
@@ -60,6 +65,10 @@ struct Args {
     Bound a, b;
     int n_coarse;          // chunks of the maxima
     long coarse_chunk;     // samples per chunk of the maxima
+    // second X operand (WB2 > 0): row-major [P][WB2], partials [G][WA][WB2]
+    const float* B2;
+    float* part_w2;
+    Bound b2;
 };
 
 // where the 4-feature group fg of an operand sits in its 256-position region of an LDS row (wgrad256_half.h's image)
@@ -67,11 +76,13 @@ __device__ __forceinline__ int region_pos(int fg) {
     return 128 * (fg >> 5) + 16 * ((fg >> 3) & 3) + 64 * ((fg & 7) >> 2) + 4 * (fg & 3);
 }
 
-template <int WA, int WB, bool B_ROWMAJOR>
+template <int WA, int WB, bool B_ROWMAJOR, int WB2 = 0>
 __global__ __launch_bounds__(kThreads, 1) void wgrad_half_narrow_kernel(Args a) {
     constexpr int TA = WA / 64, TB = WB / 64;             // accumulator tiles per wave
     constexpr int PA = WA / 64, PB = WB / 64;             // 16-byte pieces per thread and slab
+    constexpr int P2 = WB2 ? 1 : 0;                       // the second X operand's piece (waves 0 and 1 only)
     static_assert((TA == 2 || TA == 4) && (TB == 1 || TB == 2 || TB == 4), "wave tile shapes");
+    static_assert(WB2 == 0 || (WB2 == 32 && WA == 128), "the second X operand sits in the unused half of the A region");
     short* lds = dynamic_lds<short>();
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const int wn = wave >> 1, wk = wave & 1;
@@ -81,9 +92,14 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_half_narrow_kernel(Args a) 
     float* const pw_block = a.part_w + (long)blockIdx.x * WA * WB;
     float* const pb_block = a.part_b ? a.part_b + (long)blockIdx.x * WA : nullptr;
 
+    float* const pw2_block = WB2 ? a.part_w2 + (long)blockIdx.x * WA * (WB2 ? WB2 : 1) : nullptr;
+
     if (n_slab == 0) {
         for (int e = tid * 4; e < WA * WB; e += kThreads * 4)
             *reinterpret_cast<f32x4*>(pw_block + e) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (WB2 > 0)
+            for (int e = tid * 4; e < WA * WB2; e += kThreads * 4)
+                *reinterpret_cast<f32x4*>(pw2_block + e) = f32x4{0.f, 0.f, 0.f, 0.f};
         if (pb_block && tid < WA) pb_block[tid] = 0.f;
         return;
     }
@@ -98,8 +114,17 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_half_narrow_kernel(Args a) 
     };
     const float sa = wg256h::scale_for(bound_of(a.a));
     const float sb = wg256h::scale_for(bound_of(a.b));
+    float sb2 = 1.f;
+    if constexpr (WB2 > 0) sb2 = wg256h::scale_for(bound_of(a.b2));
 
     f32x16 acc[TA][TB];
+    f32x16 acc2[WB2 ? TA : 1];
+    if constexpr (WB2 > 0) {
+#pragma unroll
+        for (int i = 0; i < TA; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[i][r] = 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TA; ++i)
 #pragma unroll
@@ -133,7 +158,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_half_narrow_kernel(Args a) 
     const int rd_a = rd_row * kRowEl + rd_col;
     const int rd_b = rd_row * kRowEl + 2 * kPlane + rd_col;
 
-    f32x4 raw[kSets][PA + PB];
+    f32x4 raw[kSets][PA + PB + P2];
     auto load_slab = [&](auto set_tag, int s) {
         constexpr int SET = decltype(set_tag)::value;
         s = min(s, n_slab - 1);
@@ -154,6 +179,23 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_half_narrow_kernel(Args a) 
                 raw[SET][PA + q] = load_stream(reinterpret_cast<const f32x4*>(a.B + p0 * WB + ((fg >> 1) * 64 + 32 * (fg & 1) + m) * 4));
             }
         }
+        if constexpr (WB2 > 0) {
+            // waves 0, 1: 4-column group c of in-slab sample ml + 8 wave
+            if (wave < 2) {
+                const long p = p0 + m0 + ml + 8 * wave;
+                raw[SET][PA + PB] = p < a.P ? load_stream(reinterpret_cast<const f32x4*>(a.B2 + p * WB2 + 4 * c)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto cut_piece = [&](const f32x4& x4, float s, short* d) {
+        u32x2 ph, pl;
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2) {
+            ph[w2] = pack_f16_scaled(x4[2 * w2], x4[2 * w2 + 1], s);
+            pl[w2] = pack_f16(residual_f16<0>(x4[2 * w2], s, ph[w2]), residual_f16<1>(x4[2 * w2 + 1], s, ph[w2]));
+        }
+        *reinterpret_cast<u32x2*>(d) = ph;
+        *reinterpret_cast<u32x2*>(d + kPlane) = pl;
     };
     auto cut_slab = [&](auto set_tag, int buf) {
         constexpr int SET = decltype(set_tag)::value;
@@ -170,15 +212,13 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_half_narrow_kernel(Args a) 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bsum[PA == 4 ? (q >> 1) : 0][e] = add_raw(bsum[PA == 4 ? (q >> 1) : 0][e], x4[e]);
             }
-            u32x2 ph, pl;
-#pragma unroll
-            for (int w2 = 0; w2 < 2; ++w2) {
-                ph[w2] = pack_f16_scaled(x4[2 * w2], x4[2 * w2 + 1], s);
-                pl[w2] = pack_f16(residual_f16<0>(x4[2 * w2], s, ph[w2]), residual_f16<1>(x4[2 * w2 + 1], s, ph[w2]));
+            cut_piece(x4, s, img + m * kRowEl + ((m & 7) >> 2) * 8 + region_pos(fg) + (is_b ? 2 * kPlane : 0));
+        }
+        if constexpr (WB2 > 0) {
+            if (wave < 2) {
+                const int m = ml + 8 * wave;
+                cut_piece(raw[SET][PA + PB], sb2, img + m * kRowEl + ((m & 7) >> 2) * 8 + region_pos(32 + c));
             }
-            short* d = img + m * kRowEl + ((m & 7) >> 2) * 8 + region_pos(fg) + (is_b ? 2 * kPlane : 0);
-            *reinterpret_cast<u32x2*>(d) = ph;
-            *reinterpret_cast<u32x2*>(d + kPlane) = pl;
         }
     };
     // one plane of one 32-feature tile -> the MFMA operand (8 samples of the lane's k-group)
@@ -202,6 +242,17 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_half_narrow_kernel(Args a) 
                 acc[i][j] = mfma_32x32x16_f16(Al[i], Bh[j], acc[i][j]);
                 acc[i][j] = mfma_32x32x16_f16(Ah[i], Bl[j], acc[i][j]);
             }
+        if constexpr (WB2 > 0) {
+            if (wk == 0) {
+                const s16x8 Ch = read_tile(buf, rd_a, 0, 4), Cl = read_tile(buf, rd_a, 1, 4);
+#pragma unroll
+                for (int i = 0; i < TA; ++i) {
+                    acc2[i] = mfma_32x32x16_f16(Ah[i], Ch, acc2[i]);
+                    acc2[i] = mfma_32x32x16_f16(Al[i], Ch, acc2[i]);
+                    acc2[i] = mfma_32x32x16_f16(Ah[i], Cl, acc2[i]);
+                }
+            }
+        }
     };
 
     using S0 = std::integral_constant<int, 0>;
@@ -249,6 +300,18 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_half_narrow_kernel(Args a) 
                     const int n = 32 * (wn * TA + i) + (r & 3) + 8 * (r >> 2) + 4 * mh2;
                     pw_block[n * WB + 32 * (wk * TB + j) + li] = (acc[i][j][r] * una) * unb;
                 }
+        if constexpr (WB2 > 0) {
+            if (wk == 0) {
+                const float unb2 = __uint_as_float(0x7f000000u - __float_as_uint(sb2));
+#pragma unroll
+                for (int i = 0; i < TA; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int n = 32 * (wn * TA + i) + (r & 3) + 8 * (r >> 2) + 4 * mh2;
+                        pw2_block[n * WB2 + li] = (acc2[i][r] * una) * unb2;
+                    }
+            }
+        }
     }
     // bias sums: a thread's pieces of one feature group over its 2 in-slab samples and all slabs; 8 sample lanes to fold
 #pragma unroll

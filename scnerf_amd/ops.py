@@ -295,9 +295,9 @@ class ChunkMaxima:
     def __init__(self, P: int, device):
         self.chunks = int(_capi.load().scnerf_wgrad256_chunks(wgrad_chunks(P)))
         self.chunk_samples = int(_capi.load().scnerf_wgrad_chunk_samples(int(P), self.chunks))
-        # rows 0 .. 7: the eight 256 x 256 GEMMs; rows 8 .. 10 of z: dZ of the views layer, dZ of layer 0, max(1, |point|)
-        # (left by the resident data-gradient kernel for the narrow GEMMs, csrc/wgrad_half_narrow.h)
-        both = torch.zeros((2, 11, self.chunks), dtype=torch.float32, device=device)
+        # rows 0 .. 7: the eight 256 x 256 GEMMs; rows 8 .. 11 of z: dZ of the views layer, dZ of layer 0, max(1, |point|),
+        # max(1, |direction|) (left by the resident data-gradient kernel for the narrow GEMMs, csrc/wgrad_half_narrow.h)
+        both = torch.zeros((2, 12, self.chunks), dtype=torch.float32, device=device)
         self.x, self.z = both[0], both[1]
         self.scales = None        # the scale table of the weights the data-gradient kernel ran with (mlp_bwd_resident)
 

@@ -11,7 +11,7 @@ import pytest
 from scnerf_amd import _capi
 
 LLVM = "/opt/rocm/lib/llvm/bin"
-HOT = ("mlp_fwd_h3_kernel", "mlp_bwd_h3_kernel", "wgrad256_half_kernel", "wgrad256_split_kernel", "wgrad256_kernel", "wgrad_tiles_kernel")
+HOT = ("mlp_fwd_h3_kernel", "mlp_bwd_h3_kernel", "wgrad256_half_kernel", "wgrad_half_narrow_kernel", "wgrad256_split_kernel", "wgrad256_kernel", "wgrad_tiles_kernel")
 
 
 def _code_objects(tmp_path):
