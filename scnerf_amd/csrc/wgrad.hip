@@ -456,13 +456,8 @@ int launch_wgrad256(const wg256::Args& a, int G, hipStream_t stream) {
 }
 
 // the same GEMMs on three fp16 products (wgrad256_half.h): needs the chunk maxima of both operands, [job][chunk]
-int launch_wgrad256_half(const wg256::Args& a, int G, const float* amax_a, const float* amax_b, hipStream_t stream,
-                         const float* vec = nullptr, long vec_P = 0, int vec_job = -1, float* part_v = nullptr) {
+int launch_wgrad256_half(const wg256::Args& a, int G, const float* amax_a, const float* amax_b, hipStream_t stream) {
     wg256h::Args h;
-    h.vec = vec ? vec : a.job[0].A;          // (readable in any case: wgrad256_half.h)
-    h.vec_P = vec ? vec_P : 1;
-    h.vec_job = vec ? vec_job : -1;
-    h.part_v = part_v;
     for (int j = 0; j < a.n_jobs; ++j) h.job[j] = a.job[j];
     h.n_jobs = a.n_jobs;
     h.Ppad = a.Ppad;
@@ -696,13 +691,8 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
     }
     // feature_linear; alpha_linear (one output row) = d sigma^T . act7 with d sigma = d_raw[:, 3]
     SCN_WG(G(kGradDfeat), 256, 256, 256, 1, act(7), 256, 256, 256, 1, P, nb, ws, g + V::kWF, 256, 0, g + V::kBF)
-    const int feature_job = big.n_jobs - 1;
-    // on three fp16 products the vector-matrix product rides on feature_linear's GEMM (same X); otherwise its own pass
-    const bool vec_rides = amax_x && amax_z && wgrad_arithmetic() == 2;
-    if (!vec_rides) {
-        rc = vecmat_impl(act(7), d_raw + 3, 4, P, n_chunks, workspace, g + V::kWA, g + V::kBA, accumulate, stream);
-        if (rc != 0) return rc;
-    }
+    rc = vecmat_impl(act(7), d_raw + 3, 4, P, n_chunks, workspace, g + V::kWA, g + V::kBA, accumulate, stream);
+    if (rc != 0) return rc;
     // views layer: [feature | encoded direction]
     if (half_narrow) {
         // one launch for both X operands of the views layer: dZ is read (and cut) once (wgrad_half_narrow.h, WB2 = 32)
@@ -746,13 +736,11 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
 #undef SCN_WG
     if (big.n_jobs > 0) {
         if (g_profile_events[0]) SCN_HIP(hipEventRecord(g_profile_events[0], st));
-        rc = vec_rides ? launch_wgrad256_half(big, nb, amax_z, amax_x, st, d_raw + 3, (long)P, feature_job, workspace)
-                       : launch_wgrad256(big, nb, st);
+        rc = (amax_x && amax_z && wgrad_arithmetic() == 2) ? launch_wgrad256_half(big, nb, amax_z, amax_x, st)
+                                                            : launch_wgrad256(big, nb, st);
         if (rc != 0) return rc;
         if (g_profile_events[1]) SCN_HIP(hipEventRecord(g_profile_events[1], st));
         g_profile_events[0] = g_profile_events[1] = nullptr;
-        if (vec_rides)
-            hipLaunchKernelGGL(vecmat_reduce_kernel, dim3(2), dim3(256), 0, st, workspace, nb, g + V::kWA, g + V::kBA, accumulate);
     }
     // one launch finishes all twelve GEMMs (fixed-order sums: deterministic)
     int blocks = 0;

@@ -56,15 +56,6 @@ struct Args {
     long chunk;            // samples per workgroup (multiple of 32)
     const float* amax_a;   // [n_jobs][gridDim.x] largest |dZ| of the chunk
     const float* amax_b;   // [n_jobs][gridDim.x] largest |X| of the chunk
-    // A vector-matrix product riding on job vec_job's X pieces: dv[k] = sum_p vec[4 p] X[p][k], sum_p vec[4 p]
-    // (alpha_linear's weight and bias gradient: vec = d sigma = d_raw + 3, X = the last trunk activation, which
-    // feature_linear's GEMM stages anyway -- its own pass over that 0.8 GB section was 0.25 ms of a step).  Every job
-    // does the arithmetic (no branch in the slab loop), only vec_job writes: `vec` must be readable for 4 vec_P floats
-    // in any case.  part_v: [gridDim.x][257].
-    const float* vec;
-    long vec_P;            // samples with a vec entry (X holds copies of the last valid sample beyond)
-    int vec_job;           // -1: none
-    float* part_v;
 };
 
 // 2^k with bound 2^k < 2^13 (as mlp_h3.h's scale_for)
@@ -146,9 +137,6 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad256_half_kernel(Args a) {
     const int rd_b = rd_row * kRowEl + 2 * kPlane + 128 * wk + rd_col;
 
     f32x4 raw[2][8];       // [set][operand * 4 + j * 2 + mh]
-    float dsg[2][2];       // [set][mh]: vec of the thread's two in-slab samples
-    f32x4 vsum[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    float vtot = 0.f;
     auto load_slab = [&](auto set_tag, int s, int first, int count) {
         constexpr int SET = decltype(set_tag)::value;
         s = min(s, n_slab - 1);
@@ -160,11 +148,6 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad256_half_kernel(Args a) {
             if (x < first || x >= first + count) continue;
             const int o = x >> 2, j = (x >> 1) & 1, mh = x & 1;
             raw[SET][x] = load_stream(reinterpret_cast<const f32x4*>((o ? bB : bA) + j * 4096 + mh * 32));
-            if (x >= 6) {       // with the LAST X pieces of a sample: the earlier ones of this set are still to be cut
-                const long p = p0 + (s & 1) * 16 + ml + 8 * mh;
-                const float v = a.vec[min(p, a.vec_P - 1) * 4];
-                dsg[SET][mh] = p < a.vec_P ? v : 0.f;
-            }
         }
     };
     // Cutting one staged piece in six steps of at most four instructions:
@@ -179,10 +162,6 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad256_half_kernel(Args a) {
             if constexpr (o == 0) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bsum[j][e] = add_raw(bsum[j][e], x4[e]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) vsum[j][e] = __builtin_fmaf(dsg[SET][mh], x4[e], vsum[j][e]);
-                if constexpr (j == 0) vtot += dsg[SET][mh];
             }
         } else if constexpr (STEP == 1 || STEP == 3) {
             constexpr int w = STEP == 1 ? 0 : 1;
@@ -327,21 +306,6 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad256_half_kernel(Args a) {
             v[e] = x;
         }
         if (pb_block && ml == 0) *reinterpret_cast<f32x4*>(pb_block + 4 * (fg0 + 32 * j)) = v;
-    }
-    if ((int)blockIdx.y == a.vec_job) {
-        float* const pv = a.part_v + (long)blockIdx.x * 257;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = vsum[j][e];
-                x += shfl_xor(x, 1); x += shfl_xor(x, 2); x += shfl_xor(x, 4);
-                if (ml == 0) pv[4 * (fg0 + 32 * j) + e] = x;
-            }
-        }
-        float x = vtot;
-        x += shfl_xor(x, 1); x += shfl_xor(x, 2); x += shfl_xor(x, 4);
-        if (tid == 0) pv[256] = x;
     }
 }
 
