@@ -25,6 +25,12 @@
 //   two LDS writes + the reload for four slabs ahead) = one step per slot;
 //   operand reads: products in the order (Ah Bh)(Al Bh)(Ah Bl); the A planes of the NEXT slab go into the other of two
 //   register sets at any time, Bl during the first two products, the next Bh under the third.
+//
+// Tried and reverted: alpha_linear's vector-matrix product (sum_p d sigma[p] X[p][k], X = the activation section
+// feature_linear's GEMM stages anyway) riding on the X pieces' idle cut step -- four fma per piece and two 4-byte loads
+// per slab.  The launch went from 2.03 to 2.34 ms (3.35 ms with 64-bit per-lane addresses for those loads), more than
+// the 0.12 ms the separate HBM-rate pass costs: in a kernel scheduled slot by slot every extra load re-times the
+// vmcnt waits of the operand stream.
 #pragma once
 #include <type_traits>
 #include <utility>
