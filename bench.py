@@ -76,9 +76,12 @@ def region_model(name):
         return dict(flop=8 * 2 * 256 * 256 * P, products=3 if "half" in name else 6 if "split" in name else None,
                     bytes=16 * 256 * 4 * P)
     if name.startswith("wgrad("):
-        # 8 of the 12 GEMMs (87 % of the FLOP) are the 256 x 256 ones; the rest runs on the fp32 MFMA
+        # 8 of the 12 GEMMs (87 % of the FLOP) are the 256 x 256 ones; on three fp16 products the shapes with a
+        # tile-native dZ (2 x 256 x encoded point, 128 x (256 + 32)) join them (csrc/wgrad_half_narrow.h); the rest
+        # (rgb rows, alpha_linear's vector-matrix product) is HBM-rate VALU work, priced at the fp32 rate
+        big = 8 * 2 * 256 * 256 * P
         return dict(flop=2 * mac * P, products=None, bytes=(lay.save_floats_per_sample * 4 + grad_b) * P,
-                    mixed=8 * 2 * 256 * 256 * P)
+                    mixed=big, mixed_half=big + 2 * (2 * 256 * lay.e_width + 128 * 256 + 128 * 32) * P)
     if name.startswith("layer_split_kernel"):
         m2 = re.search(r": (\d) on three fp16 products", name)
         n16 = int(m2.group(1)) if m2 else 0
@@ -93,9 +96,10 @@ def floors(name, avg_ms, wgrad_products=3):
     if md is None or not avg_ms:
         return None
     if md.get("mixed") and wgrad_products:
-        f16 = md["mixed"]
+        f16 = min(md["flop"], md["mixed_half"] if wgrad_products == 3 else md["mixed"])
         t_mfma = f16 * wgrad_products / (PEAK_16BIT_MFMA_TFLOPS * 1e12) + (md["flop"] - f16) / (PEAK_F32_MFMA_TFLOPS * 1e12)
-        pipe = "%s on the eight 256 x 256 GEMMs, fp32 MFMA on the narrow ones" % ("fp16 MFMA x3" if wgrad_products == 3 else "bf16 MFMA x6")
+        pipe = ("fp16 MFMA x3 on the eight 256 x 256 GEMMs and the narrow ones with a tile-native dZ, fp32 on the rest" if wgrad_products == 3
+                else "bf16 MFMA x6 on the eight 256 x 256 GEMMs, fp32 MFMA on the narrow ones")
     elif md["products"]:
         t_mfma = md["flop"] * md["products"] / (PEAK_16BIT_MFMA_TFLOPS * 1e12)
         pipe = "%s MFMA x%g (fp32 operands cut into 16-bit planes, fp32 accumulate)" % (
@@ -548,7 +552,11 @@ def main():
                     "split": "fp32 operands cut EXACTLY into 3 bf16 numbers each, 6 of the 9 partial products on "
                              "v_mfma_f32_32x32x16_bf16, fp32 accumulate (csrc/wgrad256_split.h)",
                     "fp32": "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32"}[ops.wgrad_arithmetic()],
-                "narrow weight gradients": "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32"},
+                "narrow weight gradients": (
+                    "256 x 64 (encoded point, twice) and 128 x (256 + 32) (views layer): three fp16 products as the 256 x 256 "
+                    "ones, scales from the same chunk maxima (csrc/wgrad_half_narrow.h); rgb rows and alpha_linear's "
+                    "vector-matrix product: fp32 VALU at the HBM rate" if ops.wgrad_arithmetic() == "half" and ops.mlp_arithmetic() == "resident"
+                    else "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32")},
             "timed_region": ("exactly the product path: every region of `kernels` is ONE C call of the host layer between "
                              "two HIP events on the launch stream (no piecewise re-issue); ms_per_step_events_off is the same "
                              "loop without the events"),

@@ -228,29 +228,54 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_half_narrow_kernel(Args a) 
         const s16x4 hi = lds_read_tr16(s + kRdStep);
         return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
-    auto compute_slab = [&](int buf) {
-        s16x8 Ah[TA], Al[TA], Bh[TB], Bl[TB];
+    // One slab.  Source order = issue order: the LDS reads of the current slab first, then the cut of the next slab (its
+    // ~100 VALU instructions cover the reads' latency; its LDS writes queue behind the reads), then the MFMAs, whose
+    // operands have arrived by then.
+    auto step_body = [&](auto next_set_tag, int s, int cur, int nxt) {
+        s16x8 Ah[TA], Al[TA], Bh[TB], Bl[TB], Ch, Cl;
 #pragma unroll
-        for (int j = 0; j < TB; ++j) { Bh[j] = read_tile(buf, rd_b, 0, wk * TB + j); Bl[j] = read_tile(buf, rd_b, 1, wk * TB + j); }
+        for (int j = 0; j < TB; ++j) { Bh[j] = read_tile(cur, rd_b, 0, wk * TB + j); Bl[j] = read_tile(cur, rd_b, 1, wk * TB + j); }
 #pragma unroll
-        for (int i = 0; i < TA; ++i) { Ah[i] = read_tile(buf, rd_a, 0, wn * TA + i); Al[i] = read_tile(buf, rd_a, 1, wn * TA + i); }
+        for (int i = 0; i < TA; ++i) { Ah[i] = read_tile(cur, rd_a, 0, wn * TA + i); Al[i] = read_tile(cur, rd_a, 1, wn * TA + i); }
+        if constexpr (WB2 > 0) {
+            if (wk == 0) { Ch = read_tile(cur, rd_a, 0, 4); Cl = read_tile(cur, rd_a, 1, 4); }
+        }
+        // the NEXT slab: registers -> image `nxt` (last read in iteration s - 2: every wave has passed the barrier that
+        // ended it), then its set is refilled five slabs ahead
+        if (s + 1 < n_slab) {
+            cut_slab(next_set_tag, nxt);
+            load_slab(next_set_tag, s + 5);
+        }
+        // product-major: the three products of one accumulator tile are TA TB MFMAs apart (back to back they would wait
+        // out each other's latency: 64 cycles per dependent 32-cycle MFMA)
 #pragma unroll
         for (int i = 0; i < TA; ++i)
 #pragma unroll
-            for (int j = 0; j < TB; ++j) {
-                acc[i][j] = mfma_32x32x16_f16(Ah[i], Bh[j], acc[i][j]);
-                acc[i][j] = mfma_32x32x16_f16(Al[i], Bh[j], acc[i][j]);
-                acc[i][j] = mfma_32x32x16_f16(Ah[i], Bl[j], acc[i][j]);
-            }
+            for (int j = 0; j < TB; ++j) acc[i][j] = mfma_32x32x16_f16(Ah[i], Bh[j], acc[i][j]);
         if constexpr (WB2 > 0) {
             if (wk == 0) {
-                const s16x8 Ch = read_tile(buf, rd_a, 0, 4), Cl = read_tile(buf, rd_a, 1, 4);
 #pragma unroll
-                for (int i = 0; i < TA; ++i) {
-                    acc2[i] = mfma_32x32x16_f16(Ah[i], Ch, acc2[i]);
-                    acc2[i] = mfma_32x32x16_f16(Al[i], Ch, acc2[i]);
-                    acc2[i] = mfma_32x32x16_f16(Ah[i], Cl, acc2[i]);
-                }
+                for (int i = 0; i < TA; ++i) acc2[i] = mfma_32x32x16_f16(Ah[i], Ch, acc2[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TA; ++i)
+#pragma unroll
+            for (int j = 0; j < TB; ++j) acc[i][j] = mfma_32x32x16_f16(Al[i], Bh[j], acc[i][j]);
+        if constexpr (WB2 > 0) {
+            if (wk == 0) {
+#pragma unroll
+                for (int i = 0; i < TA; ++i) acc2[i] = mfma_32x32x16_f16(Al[i], Ch, acc2[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TA; ++i)
+#pragma unroll
+            for (int j = 0; j < TB; ++j) acc[i][j] = mfma_32x32x16_f16(Ah[i], Bl[j], acc[i][j]);
+        if constexpr (WB2 > 0) {
+            if (wk == 0) {
+#pragma unroll
+                for (int i = 0; i < TA; ++i) acc2[i] = mfma_32x32x16_f16(Ah[i], Cl, acc2[i]);
             }
         }
     };
@@ -269,13 +294,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_half_narrow_kernel(Args a) 
     block_sync();
     int cur = 0, nxt = 1;
     auto step = [&](auto next_set_tag, int s) {
-        // the NEXT slab: registers -> image `nxt` (last read in iteration s - 2: every wave has passed the barrier that
-        // ended it), then its set is refilled five slabs ahead
-        if (s + 1 < n_slab) {
-            cut_slab(next_set_tag, nxt);
-            load_slab(next_set_tag, s + 5);
-        }
-        compute_slab(cur);
+        step_body(next_set_tag, s, cur, nxt);
         block_sync();
         cur = nxt;
         nxt = nxt == 2 ? 0 : nxt + 1;
