@@ -28,10 +28,11 @@ def test_scene_is_reproducible():
 @pytest.mark.parametrize("arithmetic", ["resident", "half", "split", "fp32"])
 def test_psnr_trajectory_tracks_the_oracle(arithmetic):
     """Training is chaotic: two runs of the SAME fp32 algorithm whose initial weights differ by a relative 1e-7 are
-    0.05-0.2 dB apart while the curve is steep (the CPU oracle's own ensemble in the fixture shows it, and so do eight
-    GPU runs per arithmetic: profiles/psnr_r03.json), so single trajectories are compared loosely and the ENSEMBLE MEAN
-    -- four runs with the fixture's four perturbations -- tightly: within 0.1 dB of the oracle ensemble's mean at every
-    checkpoint."""
+    0.05-0.25 dB apart while the curve is steep (the CPU oracle's own ensemble in the fixture shows it, and so do eight
+    GPU runs per arithmetic: profiles/psnr_r03.json), so single trajectories are compared loosely and the ENSEMBLE MEANS
+    -- four runs with the fixture's four perturbations on each side -- statistically: at every checkpoint the two means
+    differ by no more than three standard errors of their difference (from the two ensembles' own spreads; never looser
+    than 0.25 dB, never tighter than 0.05 dB)."""
     import sys
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -52,5 +53,10 @@ def test_psnr_trajectory_tracks_the_oracle(arithmetic):
                                                  "gpu_mean": got.mean(0).tolist(), "oracle_mean": want.mean(0).tolist(),
                                                  "oracle_std": want.std(0).tolist()}
     assert (got[:, -1] > got[:, 0] + 3.0).all()                                    # it learns
-    assert np.abs(got.mean(0) - want.mean(0)).max() <= 0.1, (arithmetic, got.mean(0), want.mean(0))
+    n = got.shape[0]
+    stderr = np.sqrt((got.var(0, ddof=1) + want.var(0, ddof=1)) / n)
+    tol = np.clip(3.0 * stderr, 0.05, 0.25)
+    diff = np.abs(got.mean(0) - want.mean(0))
+    PA.REPORT["psnr_100_steps/" + arithmetic].update({"abs_difference_of_means": diff.tolist(), "tolerance": tol.tolist()})
+    assert (diff <= tol).all(), (arithmetic, diff, tol, got.mean(0), want.mean(0))
     assert np.abs(got - want.mean(0)).max() <= 0.4, (arithmetic, got, want.mean(0))
