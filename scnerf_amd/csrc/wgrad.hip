@@ -691,8 +691,18 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
     }
     // feature_linear; alpha_linear (one output row) = d sigma^T . act7 with d sigma = d_raw[:, 3]
     SCN_WG(G(kGradDfeat), 256, 256, 256, 1, act(7), 256, 256, 256, 1, P, nb, ws, g + V::kWF, 256, 0, g + V::kBF)
-    rc = vecmat_impl(act(7), d_raw + 3, 4, P, n_chunks, workspace, g + V::kWA, g + V::kBA, accumulate, stream);
-    if (rc != 0) return rc;
+    {
+        // (its partials [G][257] are finished by the merged reduction below: the 256 sums and the bias sum as two jobs)
+        hipLaunchKernelGGL(vecmat_kernel, dim3(n_chunks), dim3(kThreads), 0, st, act(7), d_raw + 3, 4, (long)P, (long)(Ppad / 32), workspace);
+        rc = scn_launch_status();
+        if (rc != 0) return rc;
+        ReduceJob& Jw = jobs.j[jobs.n++];
+        Jw.part_w = workspace; Jw.part_b = nullptr; Jw.dW = g + V::kWA; Jw.db = nullptr;
+        Jw.G = n_chunks; Jw.BN = 1; Jw.BK = 257; Jw.n_out = 1; Jw.k_out = 256; Jw.ldo = 256; Jw.col0 = 0; Jw.block0 = 0;
+        ReduceJob& Jb = jobs.j[jobs.n++];
+        Jb.part_w = workspace + 256; Jb.part_b = nullptr; Jb.dW = g + V::kBA; Jb.db = nullptr;
+        Jb.G = n_chunks; Jb.BN = 1; Jb.BK = 257; Jb.n_out = 1; Jb.k_out = 1; Jb.ldo = 1; Jb.col0 = 0; Jb.block0 = 0;
+    }
     // views layer: [feature | encoded direction]
     if (half_narrow) {
         // one launch for both X operands of the views layer: dZ is read (and cut) once (wgrad_half_narrow.h, WB2 = 32)

@@ -57,6 +57,8 @@ class RenderRaysFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ray_batch, cfg, t_rand, u, noise_c, noise_f, net_c, net_f, *params):
+        # outputs the loss does not touch arrive in backward as None (it handles that), not as ten zero tensors
+        ctx.set_materialize_grads(False)
         rays = _c(ray_batch)
         if rays.shape[1] < 11:
             raise NotImplementedError("the fused network needs view directions (ray_batch [N, 11])")
