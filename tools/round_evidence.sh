@@ -1,5 +1,5 @@
 #!/bin/bash
-# final evidence collection of the round (run on the GPU box)
+# end-of-round evidence (run on the GPU box: gpurun -- "bash tools/round_evidence.sh"): GPU suite, bench line, kernel trace, counters, the other arithmetics, the 2-rank launch path; results under gpurun_out/r03, copied by hand into profiles/
 set -u
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r03
