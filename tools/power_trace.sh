@@ -11,7 +11,7 @@ while kill -0 $BPID 2> /dev/null; do
   i=$((i + 1))
   out=$(rocm-smi --showpower --showclocks 2> /dev/null)
   sclk=$(echo "$out" | grep -i "sclk" | head -1 | grep -o "([0-9]*Mhz)" | tr -dc '0-9')
-  pw=$(echo "$out" | grep -i "power" | head -1 | grep -o "[0-9]*\.[0-9]*" | head -1 | cut -d. -f1)
+  pw=$(echo "$out" | grep -i "power (W)" | head -1 | sed 's/.*: *//' | cut -d. -f1)
   printf "%5d  %8s  %8s\n" $i "${sclk:-?}" "${pw:-?}"
   sleep 0.7
 done
