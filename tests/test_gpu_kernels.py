@@ -340,6 +340,59 @@ def test_split_weight_gradient_gemm_is_fp32_grade(ops):
     assert err["half_wide_range"]["max"] <= 3 * 2.0 ** -22 and err["half_wide_range"]["rms"] <= 1e-7, err
 
 
+@pytest.mark.parametrize("shape", ["256x64", "128x256"])
+def test_narrow_weight_gradient_gemms_are_fp32_grade(ops, shape):
+    """The narrow weight-gradient GEMMs on three fp16 products (csrc/wgrad_half_narrow.h; 256 x 64: dZ x encoded point,
+    row-major X with 63 valid columns; 128 x 256: views-layer dZ x feature) against fp64, beside the fp32-MFMA kernel
+    (csrc/wgrad_tiles.h) on the same operands: the error must be that kernel's, as for the 256 x 256 GEMMs.  Maxima per
+    coarse chunk of 8 workgroups, as the resident kernels leave them."""
+    from scnerf_amd import _capi
+    from tests import parity_attribution as PA
+    lib = _capi.load()
+    wa, wb = (int(v) for v in shape.split("x"))
+    x_tiled = wb == 256
+    k_out = wb if x_tiled else wb - 1
+    P, chunks, n_coarse = 65536, 256, 32
+    g = torch.Generator(device="cuda").manual_seed(7)
+    A = (torch.randn(P, wa, device="cuda", generator=g) * torch.exp2(torch.randint(-4, 4, (P, wa), device="cuda", generator=g).float())).contiguous()
+    if x_tiled:
+        B = torch.randn(P, wb, device="cuda", generator=g) * torch.exp2(torch.randint(-4, 4, (P, wb), device="cuda", generator=g).float())
+    else:
+        B = torch.sin(torch.randn(P, wb, device="cuda", generator=g) * 40.0)           # an encoding: values in [-1, 1]
+    B = B.contiguous()
+    tiled = lambda m: m.reshape(P // 32, 32, m.shape[1] // 32, 4, 2, 4).permute(0, 2, 3, 4, 1, 5).contiguous().reshape(-1)
+    At, Bin = tiled(A), (tiled(B) if x_tiled else B.reshape(-1))
+    ref = A.double().T @ B.double()[:, :k_out]
+    scale = A.double().abs().T @ B.double().abs()[:, :k_out]
+    ws = torch.empty(lib.scnerf_wgrad_workspace_floats(wa, wb, chunks), device="cuda")
+    err = {}
+    saved = ops.wgrad_arithmetic()
+    try:
+        ops.wgrad_arithmetic("fp32")
+        dW = torch.full((wa, k_out), float("nan"), device="cuda")
+        db = torch.full((wa,), float("nan"), device="cuda")
+        _capi.check(lib.scnerf_wgrad(ops._p(At), wa, wa, wa, 1, ops._p(Bin), wb, wb, k_out, int(x_tiled), P, chunks, ops._p(ws),
+                                     ops._p(dW), k_out, 0, ops._p(db), ops._stream()), "scnerf_wgrad")
+        e = (dW.double() - ref).abs() / scale
+        err["fp32"] = {"max": float(e.max()), "rms": float((e * e).mean().sqrt())}
+    finally:
+        ops.wgrad_arithmetic(saved)
+    coarse = P // n_coarse
+    amax_a = A.abs().view(n_coarse, -1).max(1)[0].contiguous()
+    amax_b = B.abs().view(n_coarse, -1).max(1)[0].contiguous()
+    dW = torch.full((wa, k_out), float("nan"), device="cuda")
+    db = torch.full((wa,), float("nan"), device="cuda")
+    _capi.check(lib.scnerf_wgrad_half_narrow(ops._p(At), wa, ops._p(Bin), wb, k_out, int(x_tiled), P, chunks, ops._p(ws),
+                                             ops._p(dW), ops._p(db), ops._p(amax_a), ops._p(amax_b), n_coarse, coarse,
+                                             ops._stream()), "scnerf_wgrad_half_narrow")
+    e = (dW.double() - ref).abs() / scale
+    err["half"] = {"max": float(e.max()), "rms": float((e * e).mean().sqrt())}
+    eb = (db.double() - A.double().sum(0)).abs() / A.double().abs().sum(0)
+    assert float(eb.max()) <= 2e-6, float(eb.max())
+    PA.REPORT["wgrad_narrow_%s_arithmetic_65536_samples_error_over_sum_abs_products_vs_fp64" % shape] = err
+    assert err["half"]["max"] <= 2.0 * err["fp32"]["max"] + 1e-9 and err["half"]["rms"] <= 2.0 * err["fp32"]["rms"], err
+
+
 @pytest.fixture(params=["split", "half"])
 def layers(request, ops):
     """the two arithmetics of the layer GEMMs: six bf16 products everywhere, or three fp16 products where the input
