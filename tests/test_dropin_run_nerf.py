@@ -212,7 +212,9 @@ def test_gpu_training_loop_through_the_mirrored_api(tmp_path, batching, monkeypa
 @pytest.mark.gpu
 @needs_reference
 def test_gpu_unmodified_train(tmp_path, monkeypatch):
-    """Only where a GPU and the reference tree coexist (not the graft GPU box)."""
+    """The UNMODIFIED NeRF/run_nerf.py trains on the MI355X under dropin.install(): five iterations of its own train().
+    Needs the reference's sources beside a GPU: /root/reference, SCNERF_REFERENCE_ROOT, or the archive
+    `tools/ship_reference.sh pack` leaves beside the repository (tests/conftest.py unpacks it on the GPU box)."""
     mod = S.import_reference_run_nerf()
     argv = _prepare(mod, tmp_path, 5, device="cuda", n_rand=256)
     monkeypatch.setattr(sys, "argv", argv)
