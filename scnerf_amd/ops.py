@@ -640,6 +640,10 @@ def nerf_wgrad(save: Tensor, grads: Tensor, d_raw: Tensor, P: int, flat_grad: Op
     elif flat_grad.numel() != ML.layout(pd).n_params or flat_grad.dtype != torch.float32 or not flat_grad.is_contiguous():
         raise ValueError("flat_grad must be a contiguous fp32 buffer of %d elements" % ML.layout(pd).n_params)
     tag = "" if pd == 3 else "/pd4"
+    # the maxima count only when BOTH resident kernels of this pass filled them (the data-gradient kernel leaves its mark
+    # in `scales`): a half-filled table would scale one operand by 2^126
+    if maxima is not None and maxima.scales is None:
+        maxima = None
     with PROFILE.region("wgrad(12 GEMMs + reduces)%s/P=%d" % (tag, P), 2 * _MAC_PER_SAMPLE[pd] * P, group=True):
         inner = None
         if PROFILE.enabled:
@@ -653,8 +657,7 @@ def nerf_wgrad(save: Tensor, grads: Tensor, d_raw: Tensor, P: int, flat_grad: Op
             raise ValueError("chunk maxima of another chunking")
         st = lib.scnerf_nerf_wgrad_h3(pd, _p(save), _p(grads), _p(d_raw), P, chunks, _p(_wgrad_ws[key]),
                                       _p(flat_grad), int(bool(accumulate)), _p(maxima.x) if maxima else None,
-                                      _p(maxima.z) if maxima else None,
-                                      _p(maxima.scales) if maxima is not None and maxima.scales is not None else None, _stream())
+                                      _p(maxima.z) if maxima else None, _p(maxima.scales) if maxima else None, _stream())
     _capi.check(st, "scnerf_nerf_wgrad")
     return flat_grad
 
