@@ -93,6 +93,18 @@ int scnerf_camera_rays_bwd(const float* kps, const long long* cam_idx, int singl
                            const float* g_d, float* d_intr_noise, float* d_extr_noise, float* d_grid_o,
                            float* d_grid_d, float* d_extrinsic, float* workspace, int n, void* stream);
 
+/* CameraModel.get_intrinsic() / get_extrinsic() (model/camera_model.py:160-192 with model/camera_utils.py:78-133,
+ * :191-195) as one launch each way: K [4,4] = identity with fx, fy, cx, cy = intr_init + intr_noise * intr_scale (x
+ * intr_init when multiplicative); E [n_cams,4,4] = [Gram-Schmidt rotation of the first six of extr_init + extr_scale *
+ * extr_noise | translation = the last three; 0 0 0 1].  Backward: g_K [4,4] / g_E [n_cams,4,4] (each may be NULL = zero)
+ * -> d_intr_noise [4], d_extr_noise [n_cams,9] (each may be NULL). */
+int scnerf_camera_matrices_fwd(const float* intr_init, const float* intr_noise, float intr_scale, int multiplicative,
+                               const float* extr_init, const float* extr_noise, float extr_scale, int n_cams,
+                               float* K, float* E, void* stream);
+int scnerf_camera_matrices_bwd(const float* intr_init, float intr_scale, int multiplicative, const float* extr_init,
+                               const float* extr_noise, float extr_scale, int n_cams, const float* g_K,
+                               const float* g_E, float* d_intr_noise, float* d_extr_noise, void* stream);
+
 /* get_rays_kps_no_camera / get_rays_full_image_no_camera (NeRF/get_rays.py:5-23, :75-90): pinhole
  * rays at the truncated pixel coordinates kps [n, kps_stride>=2] (or every pixel when NULL) through
  * the fixed pose c2w [4,4]. */

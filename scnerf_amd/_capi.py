@@ -28,6 +28,8 @@ PROTOTYPES = {
     "scnerf_fine_sample": [P, I, P, P, P, I, P, P, P, P, P, P, I, I, I, P],
     "scnerf_camera_rays_fwd": [P, P, I, P, I, P, P, F, I, P, P, F, I, P, F, P, F, I, I, I, I, P, P, I, P],
     "scnerf_camera_rays_bwd": [P, P, I, P, I, P, P, F, I, P, P, F, I, P, F, P, F, I, I, I, I, P, P, P, P, P, P, P, P, I, P],
+    "scnerf_camera_matrices_fwd": [P, P, F, I, P, P, F, I, P, P, P],
+    "scnerf_camera_matrices_bwd": [P, F, I, P, P, F, I, P, P, P, P, P],
     "scnerf_pinhole_rays": [P, I, P, F, I, I, P, P, I, P],
     "scnerf_ndc_fwd": [I, I, P, F, P, P, P, P, I, P],
     "scnerf_ndc_bwd": [I, I, P, F, P, P, P, P, P, P, P, I, P],

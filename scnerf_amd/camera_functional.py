@@ -39,6 +39,27 @@ class CameraRaysFunction(torch.autograd.Function):
                 d_gd if need[7] else None)
 
 
+class CameraMatricesFunction(torch.autograd.Function):
+    """apply(intr_init, intr_noise, intr_scale, multiplicative, extr_init, extr_noise, extr_scale) -> K [4,4], E [C,4,4]:
+    CameraModel.get_intrinsic() and get_extrinsic() (model/camera_model.py:160-192) as one launch each way, differentiable
+    in the two noise tensors."""
+
+    @staticmethod
+    def forward(ctx, intr_init, intr_noise, intr_scale, multiplicative, extr_init, extr_noise, extr_scale):
+        ctx.set_materialize_grads(False)
+        args = (_cf(intr_init), _cf(intr_noise), float(intr_scale), bool(multiplicative), _cf(extr_init), _cf(extr_noise),
+                float(extr_scale))
+        K, E = ops.camera_matrices_fwd(*args)
+        ctx.args = args
+        return K, E
+
+    @staticmethod
+    def backward(ctx, g_K, g_E):
+        need = ctx.needs_input_grad
+        d_in, d_ex = ops.camera_matrices_bwd(*ctx.args, _cf(g_K), _cf(g_E), need[1], need[5])
+        return None, d_in, None, None, None, d_ex, None
+
+
 def camera_rays(H, W, camera_model, kps_list, idx_in_camera_param=None, extrinsic=None):
     """Shared implementation of get_rays_kps_use_camera / get_rays_full_image_use_camera."""
     dev = camera_model.intrinsics_initial.device

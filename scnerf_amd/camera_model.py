@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 from PIL import Image
 
-from .camera_functional import UpsampleGridFunction
+from .camera_functional import CameraMatricesFunction, UpsampleGridFunction
 from .camera_utils import *                                     # noqa: F401,F403  (re-exported, as the reference does)
 from .camera_utils import __all__ as _camera_utils_all
 from .camera_utils import (get_44_rotation_matrix_from_33_rotation_matrix, intrinsic_param_to_K,
@@ -123,7 +123,21 @@ class _PinholeRotNoise(CameraModel):
         r = self.intrinsics_noise[:2] * self.intrinsics_noise_scale
         return p + (r * p if self.multiplicative_noise else r)
 
+    def _matrices(self):
+        """(K, E) of the parameters where they live on the device: one launch each way (CameraMatricesFunction) instead
+        of the ~35 tensor ops below and the ~70 of their backward -- most of what one projected-ray-distance term used
+        to launch.  CPU parameters (construction, host-side logging) take the tensor ops."""
+        from . import _capi
+        if not _capi.on_device(self.intrinsics_noise):
+            return None
+        return CameraMatricesFunction.apply(self.intrinsics_initial, self.intrinsics_noise, self.intrinsics_noise_scale,
+                                            self.multiplicative_noise, self.extrinsics_initial, self.extrinsics_noise,
+                                            self.extrinsics_noise_scale)
+
     def get_intrinsic(self):
+        fused = self._matrices()
+        if fused is not None:
+            return fused[0]
         if self.multiplicative_noise:
             p = self.intrinsics_initial + self.intrinsics_noise * self.intrinsics_noise_scale * self.intrinsics_initial
         else:
@@ -131,6 +145,9 @@ class _PinholeRotNoise(CameraModel):
         return intrinsic_param_to_K(p)
 
     def get_extrinsic(self):
+        fused = self._matrices()
+        if fused is not None:
+            return fused[1]
         e = get_44_rotation_matrix_from_33_rotation_matrix(ortho2rotation(
             self.extrinsics_initial[:, :6] + self.extrinsics_noise_scale * self.extrinsics_noise[:, :6]))
         e[..., :3, 3] = self.extrinsics_initial[:, 6:] + self.extrinsics_noise_scale * self.extrinsics_noise[:, 6:]

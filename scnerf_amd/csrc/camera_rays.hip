@@ -580,6 +580,97 @@ extern "C" int scnerf_camera_rays_fwd(const float* kps, const long long* cam_idx
     return scn_launch_status();
 }
 
+// ---- the camera model's matrices: get_intrinsic() / get_extrinsic() (model/camera_model.py:160-192) ----------------
+// K [4,4] from the four learnable intrinsics, E [C,4,4] from the 6-D rotation + translation of every camera: what the
+// projected-ray-distance term and the NDC warp read each step.  As ~35 tensor ops (and ~70 in their backward) they were
+// most of the 214 launches of one PRD term; here one launch each way, thread per camera (+ one for K), the same
+// gram_schmidt the ray generator uses.
+__global__ __launch_bounds__(64) void camera_matrices_fwd_kernel(const float* __restrict__ intr_init, const float* __restrict__ intr_noise,
+                                                                 float intr_scale, int multiplicative,
+                                                                 const float* __restrict__ extr_init, const float* __restrict__ extr_noise,
+                                                                 float extr_scale, int n_cams, float* __restrict__ K, float* __restrict__ E) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == n_cams) {
+        float p[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float init = intr_init[i];
+            p[i] = multiplicative ? init + intr_noise[i] * intr_scale * init : init + intr_noise[i] * intr_scale;
+        }
+        // intrinsic_param_to_K (camera_utils.py:191-195): identity with (0,0) = fx, (1,1) = fy, (0,2) = cx, (1,2) = cy
+#pragma unroll
+        for (int i = 0; i < 16; ++i) K[i] = (i % 5 == 0) ? 1.f : 0.f;
+        K[0] = p[0]; K[5] = p[1]; K[2] = p[2]; K[6] = p[3];
+        return;
+    }
+    if (c > n_cams) return;
+    float p9[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) p9[k] = extr_init[(size_t)c * 9 + k] + extr_scale * extr_noise[(size_t)c * 9 + k];
+    GramSchmidt s;
+    const Rot R = gram_schmidt(p9, &s);
+    float* e = E + (size_t)c * 16;
+    e[0] = R.x.x; e[1] = R.y.x; e[2] = R.z.x; e[3] = p9[6];
+    e[4] = R.x.y; e[5] = R.y.y; e[6] = R.z.y; e[7] = p9[7];
+    e[8] = R.x.z; e[9] = R.y.z; e[10] = R.z.z; e[11] = p9[8];
+    e[12] = 0.f; e[13] = 0.f; e[14] = 0.f; e[15] = 1.f;
+}
+
+__global__ __launch_bounds__(64) void camera_matrices_bwd_kernel(const float* __restrict__ intr_init, float intr_scale, int multiplicative,
+                                                                 const float* __restrict__ extr_init, const float* __restrict__ extr_noise,
+                                                                 float extr_scale, int n_cams, const float* __restrict__ gK,
+                                                                 const float* __restrict__ gE, float* __restrict__ d_intr_noise,
+                                                                 float* __restrict__ d_extr_noise) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == n_cams) {
+        if (d_intr_noise) {
+            const int at[4] = {0, 5, 2, 6};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                d_intr_noise[i] = gK ? gK[at[i]] * intr_scale * (multiplicative ? intr_init[i] : 1.f) : 0.f;
+        }
+        return;
+    }
+    if (c > n_cams || !d_extr_noise) return;
+    float* d = d_extr_noise + (size_t)c * 9;
+    if (!gE) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) d[k] = 0.f;
+        return;
+    }
+    float p9[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) p9[k] = extr_init[(size_t)c * 9 + k] + extr_scale * extr_noise[(size_t)c * 9 + k];
+    GramSchmidt s;
+    gram_schmidt(p9, &s);
+    const float* g = gE + (size_t)c * 16;
+    float g6[6];
+    gram_schmidt_bwd(s, v3(g[0], g[4], g[8]), v3(g[1], g[5], g[9]), v3(g[2], g[6], g[10]), g6);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) d[k] = extr_scale * g6[k];
+    d[6] = extr_scale * g[3]; d[7] = extr_scale * g[7]; d[8] = extr_scale * g[11];
+}
+
+extern "C" int scnerf_camera_matrices_fwd(const float* intr_init, const float* intr_noise, float intr_scale,
+                                          int multiplicative, const float* extr_init, const float* extr_noise,
+                                          float extr_scale, int n_cams, float* K, float* E, void* stream) {
+    SCN_RETURN_IF(!intr_init || !intr_noise || !extr_init || !extr_noise || !K || !E || n_cams < 0, SCN_EINVAL);
+    hipLaunchKernelGGL(camera_matrices_fwd_kernel, dim3(scn_ceil_div(n_cams + 1, 64)), dim3(64), 0, (hipStream_t)stream,
+                       intr_init, intr_noise, intr_scale, multiplicative, extr_init, extr_noise, extr_scale, n_cams, K, E);
+    return scn_launch_status();
+}
+
+extern "C" int scnerf_camera_matrices_bwd(const float* intr_init, float intr_scale, int multiplicative,
+                                          const float* extr_init, const float* extr_noise, float extr_scale, int n_cams,
+                                          const float* g_K, const float* g_E, float* d_intr_noise, float* d_extr_noise,
+                                          void* stream) {
+    SCN_RETURN_IF(!intr_init || !extr_init || !extr_noise || n_cams < 0 || (!d_intr_noise && !d_extr_noise), SCN_EINVAL);
+    hipLaunchKernelGGL(camera_matrices_bwd_kernel, dim3(scn_ceil_div(n_cams + 1, 64)), dim3(64), 0, (hipStream_t)stream,
+                       intr_init, intr_scale, multiplicative, extr_init, extr_noise, extr_scale, n_cams, g_K, g_E,
+                       d_intr_noise, d_extr_noise);
+    return scn_launch_status();
+}
+
 extern "C" long long scnerf_camera_bwd_workspace_floats(int n_slots) { return 4 + 12LL * (n_slots < 1 ? 1 : n_slots); }
 
 extern "C" int scnerf_camera_rays_bwd(const float* kps, const long long* cam_idx, int single_idx,

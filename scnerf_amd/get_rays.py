@@ -62,7 +62,9 @@ class _DeferredKeypointCheck:
         except Exception:
             pass
 
-    def submit(self, kps_list, H, W):
+    def submit(self, kps_list, H, W, lower=True, what="ray-generation"):
+        """`lower=False`: the upper bounds only (what the reference's projected-ray-distance term asserts,
+        model/ray_dist_loss.py:47-50)."""
         self.poll()
         self.calls += 1
         if kps_list.numel() == 0:
@@ -70,8 +72,8 @@ class _DeferredKeypointCheck:
         xy = kps_list[:, :2]
         limit = torch.tensor([W, H], dtype=xy.dtype, device="cpu") if not xy.is_cuda else \
             self._limit(W, H, xy)
-        bad = ((xy >= limit) | (xy < 0)).any()
-        message = "key points outside the %d x %d image (ray-generation call #%d of this process)" % (W, H, self.calls)
+        bad = ((xy >= limit) | (xy < 0)).any() if lower else (xy >= limit).any()
+        message = "key points outside the %d x %d image (%s call #%d of this process)" % (W, H, what, self.calls)
         if not bad.is_cuda:
             self._raise_if_set(bad, message)
             return

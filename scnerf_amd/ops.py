@@ -706,6 +706,40 @@ def ray_reduce(d_pts, d_views, z, extra_d, d_rays, accumulate: bool):
 
 
 # ------------------------------------------------------------------------------ camera
+def camera_matrices_fwd(intr_init, intr_noise, intr_scale, multiplicative, extr_init, extr_noise, extr_scale):
+    """-> K [4,4], E [C,4,4] (scnerf_camera_matrices_fwd)"""
+    for name, t_ in (("intr_init", intr_init), ("intr_noise", intr_noise), ("extr_init", extr_init), ("extr_noise", extr_noise)):
+        _f(t_, name)
+    C = extr_init.shape[0]
+    if intr_init.numel() != 4 or intr_noise.numel() != 4 or extr_init.shape != (C, 9) or extr_noise.shape != (C, 9):
+        raise ValueError("camera parameters: intrinsics [4], extrinsics [C, 9]")
+    K = torch.empty((4, 4), dtype=torch.float32, device=intr_init.device)
+    E = torch.empty((C, 4, 4), dtype=torch.float32, device=intr_init.device)
+    st = _capi.load().scnerf_camera_matrices_fwd(_p(intr_init), _p(intr_noise), float(intr_scale), int(bool(multiplicative)),
+                                                 _p(extr_init), _p(extr_noise), float(extr_scale), C, _p(K), _p(E), _stream())
+    _capi.check(st, "scnerf_camera_matrices_fwd")
+    return K, E
+
+
+def camera_matrices_bwd(intr_init, intr_noise, intr_scale, multiplicative, extr_init, extr_noise, extr_scale, g_K, g_E,
+                        want_intr=True, want_extr=True):
+    """-> d intr_noise [4], d extr_noise [C,9] (None where not wanted); g_K / g_E may be None (= zero)"""
+    C = extr_init.shape[0]
+    for name, t_ in (("g_K", g_K), ("g_E", g_E)):
+        if t_ is not None:
+            _f(t_, name)
+    if not (want_intr or want_extr):
+        return None, None
+    dev = intr_init.device
+    d_in = torch.empty(4, dtype=torch.float32, device=dev) if want_intr else None
+    d_ex = torch.empty((C, 9), dtype=torch.float32, device=dev) if want_extr else None
+    st = _capi.load().scnerf_camera_matrices_bwd(_p(intr_init), float(intr_scale), int(bool(multiplicative)), _p(extr_init),
+                                                 _p(extr_noise), float(extr_scale), C, _p(g_K), _p(g_E), _p(d_in), _p(d_ex),
+                                                 _stream())
+    _capi.check(st, "scnerf_camera_matrices_bwd")
+    return d_in, d_ex
+
+
 def _cam_common(cam: dict):
     """(ctypes argument tuple shared by camera fwd / bwd) from a dict of tensors / scalars."""
     import ctypes

@@ -53,8 +53,11 @@ def proj_ray_dist_loss_single(kps0_list, kps1_list, img_idx0, img_idx1, rays0, r
     ground-truth extrinsic, K from the camera model if there is one (:77-95)."""
     assert mode in ["train", "val", "test"]
     assert method in ["NeRF", "NeRF++"]
-    assert kps0_list[:, 0].max() < W and kps1_list[:, 0].max() < W
-    assert kps0_list[:, 1].max() < H and kps1_list[:, 1].max() < H
+    # (:47-50) `kps*_list[:, 0].max() < W`, `[:, 1].max() < H`: four host reads of device scalars in the reference; here
+    # through the deferred check of the ray generator (verdict read at the next call / checkpoint / exit, INTEGRATION.md)
+    from .get_rays import KEYPOINT_CHECK
+    KEYPOINT_CHECK.submit(torch.as_tensor(kps0_list), H, W, lower=False, what="projected-ray-distance")
+    KEYPOINT_CHECK.submit(torch.as_tensor(kps1_list), H, W, lower=False, what="projected-ray-distance")
     if mode == "train" and camera_model is not None:
         assert intrinsic is None and extrinsic is None and i_map is not None
         intrinsic = camera_model.get_intrinsic()

@@ -220,3 +220,45 @@ def test_pack_ray_batch_matches_the_reference_composition(ndc, use_viewdirs):
         assert float((fe.grad - frf.grad).abs().max()) <= 2e-5 * float(frf.grad.abs().max())
     else:
         assert fe.grad is None
+
+
+@pytest.mark.parametrize("mult", [False, True])
+def test_camera_matrices_match_the_tensor_ops(mult):
+    """get_intrinsic() / get_extrinsic() as one launch each way (scnerf_camera_matrices_fwd / _bwd) against the tensor
+    ops the camera model runs on CPU parameters (camera_utils.ortho2rotation, intrinsic_param_to_K and torch's autograd
+    through them): values to 1e-6, gradients for random upstream gradients to 1e-5 of the largest entry, incl. a camera
+    whose second axis is (nearly) parallel to the first."""
+    from scnerf_amd.camera_utils import get_44_rotation_matrix_from_33_rotation_matrix, intrinsic_param_to_K, ortho2rotation
+    g = torch.Generator().manual_seed(4)
+    C = 7
+    intr_init = torch.tensor([400.0, 410.0, 250.0, 190.0])
+    intr_noise = (torch.randn(4, generator=g) * 3.0).requires_grad_(True)
+    extr_init = torch.randn(C, 9, generator=g)
+    extr_init[3, 3:6] = extr_init[3, 0:3] * 1.5 + 1e-3 * torch.randn(3, generator=g)
+    extr_noise = (torch.randn(C, 9, generator=g) * 0.05).requires_grad_(True)
+    si, se = 0.7, 0.3
+    p = intr_init + intr_noise * si * (intr_init if mult else 1.0)
+    K_ref = intrinsic_param_to_K(p)
+    E_ref = get_44_rotation_matrix_from_33_rotation_matrix(ortho2rotation(extr_init[:, :6] + se * extr_noise[:, :6]))
+    E_ref[..., :3, 3] = extr_init[:, 6:] + se * extr_noise[:, 6:]
+    gK, gE = torch.randn(4, 4, generator=g), torch.randn(C, 4, 4, generator=g)
+    (K_ref * gK).sum().backward(retain_graph=True)
+    (E_ref * gE).sum().backward()
+    K = np.full((4, 4), np.nan, np.float32)
+    E = np.full((C, 4, 4), np.nan, np.float32)
+    f32 = lambda t_: t_.detach().numpy().astype(np.float32).copy()
+    H.call("scnerf_camera_matrices_fwd", f32(intr_init), f32(intr_noise), ctypes.c_float(si), int(mult), f32(extr_init),
+           f32(extr_noise), ctypes.c_float(se), C, K, E, None)
+    close(K, f32(K_ref), 1e-6, "K")
+    close(E, f32(E_ref), 1e-6, "E")
+    d_in = np.full(4, np.nan, np.float32)
+    d_ex = np.full((C, 9), np.nan, np.float32)
+    H.call("scnerf_camera_matrices_bwd", f32(intr_init), ctypes.c_float(si), int(mult), f32(extr_init), f32(extr_noise),
+           ctypes.c_float(se), C, f32(gK), f32(gE), d_in, d_ex, None)
+    close(d_in, f32(intr_noise.grad), 1e-5, "d intrinsics_noise")
+    close(d_ex, f32(extr_noise.grad), 1e-5, "d extrinsics_noise")
+    # absent upstream gradients are zeros
+    d_ex2 = np.full((C, 9), np.nan, np.float32)
+    H.call("scnerf_camera_matrices_bwd", f32(intr_init), ctypes.c_float(si), int(mult), f32(extr_init), f32(extr_noise),
+           ctypes.c_float(se), C, f32(gK), None, d_in, d_ex2, None)
+    assert not d_ex2.any()
