@@ -1,3 +1,4 @@
+"""(GPU box) torch profile of one projected-ray-distance term: launches and host time per call (python tools/profile_prd.py)."""
 import sys, types, time, torch
 sys.path.insert(0, '.')
 import bench
