@@ -1,0 +1,28 @@
+"""(GPU box) torch profile of the bench's training steps: launches and host time per step, by op
+(python tools/profile_steps.py [camera])."""
+import sys
+import os
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench                                                                    # noqa: E402
+from scnerf_amd.parallel import FlatGradAllReduce                               # noqa: E402
+from torch.profiler import profile, ProfilerActivity                           # noqa: E402
+
+dev = torch.device("cuda:0")
+w = bench.build_world(dev, 0, 4096)
+if len(sys.argv) > 1 and sys.argv[1] == "camera":
+    for name in ("intrinsics_noise", "extrinsics_noise", "ray_o_noise", "ray_d_noise"):
+        getattr(w["cam"], name).requires_grad_(True)
+    red = FlatGradAllReduce([w["net_c"], w["net_f"], w["cam"]], 1)
+    step = bench.learnable_camera_step(w, red)
+else:
+    red = FlatGradAllReduce([w["net_c"], w["net_f"]], 1)
+    step = bench.fixed_camera_step(w, red)
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=30, max_name_column_width=60))
