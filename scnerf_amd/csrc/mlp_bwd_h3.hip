@@ -19,6 +19,7 @@ extern "C" int scnerf_mlp_bwd_h3(int pt_dims, const float* d_raw, const float* p
                                  float* chunk_amax, int n_chunks, long long chunk_samples, void* stream) {
     SCN_RETURN_IF(!d_raw || !pts || !viewdirs || !wpacked_bwd || !stream_bwd || !scales || !save || !grads || !d_pts || !d_views, SCN_EINVAL);
     SCN_RETURN_IF(samples_per_ray < 1 || vd_stride < 3 || n_samples < 0 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
+    SCN_RETURN_IF(n_samples >= (1LL << 31), SCN_ENOSUP);       // (the kernel indexes samples with 31 bits)
     SCN_RETURN_IF(chunk_amax && (n_chunks < 1 || chunk_samples < 32 || chunk_samples % 32), SCN_EINVAL);
     if (n_samples == 0) return 0;
     hipStream_t st = (hipStream_t)stream;

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_h3_kernel(
     constexpr int ES = V::kES, ET = V::kET;        // encoded-point slots; 32-column tiles of the d-encoding parts
     const int lane = lane_id();
     const int m = lane & 31, h = lane >> 5;
-    const long wave_tile = (long)blockIdx.x * 4 + wave_id();
+    const long wave_tile = (long)blockIdx.x * 4 + uniform(wave_id());      // (a scalar: what derives from it -- section bases, chunk index -- is SALU work)
     const long p = wave_tile * kSamplesPerWave + m;
     const bool live = p < P;
     const long pc = live ? p : P - 1;
@@ -164,11 +164,13 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_h3_kernel(
     };
     auto scale_of = [&](int layer, int what) { return sc[layer * kScaleStride + what]; };
     auto amax_of = [&](float a) { return fmaxf(a, shfl_xor(a, 32)); };
+    // (which chunk: once per wave, as a scalar -- inside the lambda it was a 64-bit division, ~100 instructions, per layer)
+    const int chunk_of_tile = cm.amax ? uniform((int)((unsigned)(wave_tile * kSamplesPerWave) / (unsigned)cm.chunk)) : 0;
     auto note_chunk_max = [&](int job, float v) __attribute__((always_inline)) {
         if (cm.amax == nullptr) return;
         v = fmaxf(v, shfl_xor(v, 16)); v = fmaxf(v, shfl_xor(v, 8)); v = fmaxf(v, shfl_xor(v, 4));
         v = fmaxf(v, shfl_xor(v, 2)); v = fmaxf(v, shfl_xor(v, 1));
-        if (lane_id() == 0) atomic_max_nonneg(cm.amax + (long)job * cm.n_chunks + (wave_tile * kSamplesPerWave) / cm.chunk, v);
+        if (lane_id() == 0) atomic_max_nonneg(cm.amax + (long)job * cm.n_chunks + chunk_of_tile, v);
     };
     using GateEpi = BwdEpi<0>;
     auto make_gate = [&](int layer, float s_in, int mask_sect, int out_offset, int out_width) {
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_h3_kernel(
         float dev[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) dev[r] = (acce[0][r] + acce[1][r]) * os;
-        const long ray = pc / samples_per_ray;
+        const long ray = (long)((unsigned)pc / (unsigned)samples_per_ray);       // (sample indices fit 31 bits)
         // max(1, |direction|) bounds every column of the encoded direction
         note_chunk_max(11, fmaxf(fmaxf(1.f, fabsf(viewdirs[ray * vd_stride + 0])),
                                  fmaxf(fabsf(viewdirs[ray * vd_stride + 1]), fabsf(viewdirs[ray * vd_stride + 2]))));

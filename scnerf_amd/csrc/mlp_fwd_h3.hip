@@ -150,6 +150,7 @@ extern "C" int scnerf_mlp_fwd_h3(int pt_dims, const float* pts, const float* vie
                                  long long n_samples, float* chunk_amax, int n_chunks, long long chunk_samples, void* stream) {
     SCN_RETURN_IF(!pts || !viewdirs || !wpacked || !stream_fwd || !scales || !raw, SCN_EINVAL);
     SCN_RETURN_IF(samples_per_ray < 1 || vd_stride < 3 || n_samples < 0 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
+    SCN_RETURN_IF(n_samples >= (1LL << 31), SCN_ENOSUP);       // (the kernels index samples with 31 bits)
     SCN_RETURN_IF(chunk_amax && (n_chunks < 1 || chunk_samples < 32 || chunk_samples % 32), SCN_EINVAL);
     if (n_samples == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -166,7 +167,7 @@ extern "C" int scnerf_coarse_stage_fwd_h3(const float* rays, int ray_stride, con
                                           void* stream) {
     SCN_RETURN_IF(!rays || !t_vals || !wpacked || !stream_fwd || !scales || !z || !pts || !raw || !rgb_map || !disp_map || !acc_map, SCN_EINVAL);
     SCN_RETURN_IF(n_rays < 0 || ray_stride < 11, SCN_EINVAL);
-    SCN_RETURN_IF(n_samples != scn::h3f::kCoarseSamples, SCN_ENOSUP);
+    SCN_RETURN_IF(n_samples != scn::h3f::kCoarseSamples || n_rays >= (1 << 25), SCN_ENOSUP);     // (31-bit sample indices)
     SCN_RETURN_IF(chunk_amax && (n_chunks < 1 || chunk_samples < 32 || chunk_samples % 32), SCN_EINVAL);
     if (n_rays == 0) return 0;
     const scn::h3f::CoarseStage cs{rays, ray_stride, n_rays, t_vals, t_rand, lindisp, z, pts, noise, white_bkgd,

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
     using V = Var<PD>;
     constexpr int ES = V::kES, NE = ES / 8;
     float* const save = TRAIN ? save_arg : nullptr;
-    const long wave_tile = (long)blockIdx.x * 4 + wave_id();
+    const long wave_tile = (long)blockIdx.x * 4 + uniform(wave_id());      // (a scalar: what derives from it -- section bases, chunk index -- is SALU work)
     const long Ppad = padded_samples(P);
     // Which sample a lane works on is needed at the start (the point), before the views layer (the direction) and at the
     // end (raw, compositing): derived afresh each time from an opaque copy of the lane number -- kept alive across the
@@ -219,12 +219,14 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
     auto scale_of = [&](int layer, int what) { return sc[layer * kScaleStride + what]; };
     auto amax_of = [&](float a) { return fmaxf(a, shfl_xor(a, 32)); };
     // the largest of the wave's 32 samples -> the weight-gradient chunk this wave tile belongs to (one atomic per wave)
+    // (which chunk: once per wave, as a scalar -- inside the lambda it was a 64-bit division, ~100 instructions, per layer)
+    const int chunk_of_tile = (TRAIN && cm.amax) ? uniform((int)((unsigned)(wave_tile * kSamplesPerWave) / (unsigned)cm.chunk)) : 0;
     auto note_chunk_max = [&](int job, float v) __attribute__((always_inline)) {
         if constexpr (TRAIN) {
             if (cm.amax == nullptr) return;
             v = fmaxf(v, shfl_xor(v, 16)); v = fmaxf(v, shfl_xor(v, 8)); v = fmaxf(v, shfl_xor(v, 4));
             v = fmaxf(v, shfl_xor(v, 2)); v = fmaxf(v, shfl_xor(v, 1));
-            if (lane_id() == 0) atomic_max_nonneg(cm.amax + (long)job * cm.n_chunks + (wave_tile * kSamplesPerWave) / cm.chunk, v);
+            if (lane_id() == 0) atomic_max_nonneg(cm.amax + (long)job * cm.n_chunks + chunk_of_tile, v);
         }
     };
 
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
     float vx, vy, vz;
     {
         const Lane L = lane_now();
-        const long ray = L.pc / samples_per_ray;
+        const long ray = (long)((unsigned)L.pc / (unsigned)samples_per_ray);      // (sample indices fit 31 bits: the workspaces of 2^31 samples would take 20 TB)
         vx = viewdirs[ray * vd_stride + 0]; vy = viewdirs[ray * vd_stride + 1]; vz = viewdirs[ray * vd_stride + 2];
     }
     const float m_ev = fmaxf(fmaxf(1.f, fabsf(vx)), fmaxf(fabsf(vy), fabsf(vz)));
