@@ -116,11 +116,92 @@ def floors(name, avg_ms, wgrad_products=3):
             "tflops": md["flop"] / t / 1e12, "gbytes_per_s": md["bytes"] / t / 1e9}
 
 
-def cpu_baseline(n_rays, iters=3):
-    """The CPU oracle (torch-CPU restatement of the reference render_rays, kind "port") on the host
-    cores of this box, forward + backward, on a bounded sample of the headline workload.  The
-    intra-op thread count is chosen by a short probe (on many-core hosts torch's CPU kernels are
-    fastest well below os.cpu_count()); the count actually used is reported as `cores`."""
+def _best_threads(step_small, ncpu):
+    """intra-op thread count by a short probe: on many-core hosts torch's CPU kernels are fastest well below os.cpu_count()"""
+    best_t, best_thr = None, 1
+    for thr in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128, ncpu)}):
+        torch.set_num_threads(thr)
+        step_small()
+        t0 = time.perf_counter()
+        step_small()
+        dt = time.perf_counter() - t0
+        if best_t is None or dt < best_t:
+            best_t, best_thr = dt, thr
+        if dt > 4 * best_t:
+            break
+    return best_thr
+
+
+def _time_steps(step, iters):
+    step()                                     # one warm-up
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[0], ts[len(ts) // 2]
+
+
+def cpu_baseline_reference(n_rays=4096, iters=3):
+    """BASELINE.md section 2 by the book: the UNMODIFIED reference `render_rays` (NeRF/render.py:186-300 with its
+    raw2outputs / sample_pdf, create_nerf.run_network, run_nerf_helpers.NeRF + Embedder) imported from the reference tree
+    (oracle/ref_ship.py: $SCNERF_REFERENCE_ROOT, the build container's tree, or the git-ignored archive that travels
+    beside the repository) on CPU tensors: `n_rays` x (64 + 128), forward + loss.backward(), 1 warm-up + `iters` timed,
+    best and median, anomaly detection off -- plus one figure with it on, as the reference ships
+    (run_nerf_helpers.py:7), at 1024 rays, and one at os.cpu_count() threads.  None when no reference tree is here."""
+    from oracle import ref_ship
+    if ref_ship.ensure() is None:
+        return None
+    from oracle.gen_golden import ref_network
+    from oracle.ref_import import load_reference
+    from scnerf_amd import synthetic as synth
+    ns = load_reference()
+    torch.autograd.set_detect_anomaly(False)       # the reference switches it on at import
+    net_c, query = ref_network(ns, synth.network_params(seed=0), S_F)
+    net_f, _ = ref_network(ns, synth.network_params(seed=1), S_F)
+
+    def make_step(n):
+        rays = synth.ray_batch(n, seed=1)
+        target = synth.target_rgb(n, seed=2)
+
+        def step():
+            for m in (net_c, net_f):
+                m.zero_grad(set_to_none=True)
+            ret = ns.render.render_rays(rays, net_c, query, S_C, retraw=True, perturb=1.0, N_importance=S_F,
+                                        network_fine=net_f, raw_noise_std=1.0)
+            (torch.mean((ret["rgb_map"] - target) ** 2) + torch.mean((ret["rgb0"] - target) ** 2)).backward()
+        return step
+
+    ncpu = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    thr = _best_threads(make_step(256), ncpu)
+    torch.set_num_threads(thr)
+    best, median = _time_steps(make_step(n_rays), iters)
+    small = make_step(1024)
+    best_1k, _ = _time_steps(small, 1)
+    torch.autograd.set_detect_anomaly(True)
+    try:
+        best_1k_anomaly, _ = _time_steps(small, 1)
+    finally:
+        torch.autograd.set_detect_anomaly(False)
+    torch.set_num_threads(ncpu)
+    best_1k_all, _ = _time_steps(small, 1)
+    torch.set_num_threads(default_threads)
+    return {"value": n_rays / best, "unit": "rays/s", "cores": thr, "kind": "reference",
+            "sample": "unmodified reference render_rays (NeRF/render.py:186-300), %d rays x (64+128), fwd+bwd, torch-CPU fp32, "
+                      "anomaly detection off, 1 warm-up + %d timed; %d intra-op threads (best of a probe over 8..%d) on a host "
+                      "with os.cpu_count() = %d" % (n_rays, iters, thr, ncpu, ncpu),
+            "best_ms": best * 1e3, "median_ms": median * 1e3, "value_median": n_rays / median,
+            "os_cpu_count": ncpu, "threads": thr,
+            "rays_per_s_1024_rays": 1024 / best_1k,
+            "rays_per_s_1024_rays_anomaly_on_as_shipped": 1024 / best_1k_anomaly,
+            "rays_per_s_1024_rays_all_%d_threads" % ncpu: 1024 / best_1k_all}
+
+
+def cpu_baseline_port(n_rays, iters=3):
+    """Fallback where no reference tree is present: the CPU oracle (torch-CPU restatement of the reference render_rays,
+    kind "port") on the host cores of this box, forward + backward, on a bounded sample of the headline workload."""
     from oracle import scnerf_oracle as O            # checker only: the CPU leg of the report
     from scnerf_amd import synthetic as synth
     pc = {k: v.clone().requires_grad_(True) for k, v in synth.network_params(seed=0).items()}
@@ -141,39 +222,19 @@ def cpu_baseline(n_rays, iters=3):
         return step
 
     ncpu = os.cpu_count() or 1
-    probe = make_step(128)
-    best_t, best_thr = None, 1
-    for thr in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128, ncpu)}):
-        torch.set_num_threads(thr)
-        probe()
-        t0 = time.perf_counter()
-        probe()
-        dt = time.perf_counter() - t0
-        if best_t is None or dt < best_t:
-            best_t, best_thr = dt, thr
-        if dt > 4 * best_t:
-            break
-    torch.set_num_threads(best_thr)
-    step = make_step(n_rays)
-    step()
-    ts = []
-    for _ in range(iters):
-        t0 = time.perf_counter()
-        step()
-        ts.append(time.perf_counter() - t0)
-    best = min(ts)
-    ratio = ""
-    pinned = os.path.join(ROOT, "profiles", "cpu_baseline_r02.json")
-    if os.path.isfile(pinned):             # port vs the unmodified reference, timed side by side in the build container
-        rec = json.load(open(pinned))
-        ratio = "; port/reference time ratio pinned in profiles/cpu_baseline_r02.json (%d threads): %s" % (
-            rec["threads"], ", ".join("%.2f at %s rays" % (v["port_over_reference_time"], k)
-                                      for k, v in sorted(rec["sizes"].items(), key=lambda kv: int(kv[0]))))
-    return {"value": n_rays / best, "unit": "rays/s", "cores": best_thr, "kind": "port",
-            "sample": "%d rays x (64+128) samples, fwd+bwd, best of %d after 1 warm-up; oracle/scnerf_oracle.py "
-                      "(torch-CPU fp32, anomaly detection off), %d intra-op threads chosen by probe on a %d-thread host%s"
-                      % (n_rays, iters, best_thr, ncpu, ratio),
-            "ms_per_step_sample": best * 1e3}
+    thr = _best_threads(make_step(128), ncpu)
+    torch.set_num_threads(thr)
+    best, median = _time_steps(make_step(n_rays), iters)
+    return {"value": n_rays / best, "unit": "rays/s", "cores": thr, "kind": "port",
+            "sample": "NO reference tree on this machine: oracle/scnerf_oracle.py (torch-CPU fp32 restatement), %d rays x "
+                      "(64+128), fwd+bwd, anomaly detection off, 1 warm-up + %d timed; %d intra-op threads by probe on a host "
+                      "with os.cpu_count() = %d" % (n_rays, iters, thr, ncpu),
+            "best_ms": best * 1e3, "median_ms": median * 1e3, "value_median": n_rays / median,
+            "os_cpu_count": ncpu, "threads": thr}
+
+
+def cpu_baseline(n_rays=4096, port_rays=512):
+    return cpu_baseline_reference(n_rays) or cpu_baseline_port(port_rays)
 
 
 IMG_H, IMG_W, N_CAMS = 378, 504, 17      # LLFF 'fern' at factor 8: the image size / view count of configs[1..3]
@@ -389,6 +450,89 @@ def rccl_allreduce_probe(dev, n_floats, dist_mod=None):
             dist.destroy_process_group()
 
 
+def self_launch(n, json_out):
+    """`python bench.py --gpus N` without a launcher: re-executes this command line under torch.distributed.run with N
+    ranks on this node and hands rank 0's JSON line through to the real stdout.  -> exit status"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        json_out.write(lines[-1] + "\n")
+        json_out.flush()
+    return r.returncode if r.returncode else (0 if lines else 1)
+
+
+COMPACT_LIMIT = 4096        # bytes: the driver parses the LAST line of a bounded stdout tail
+
+
+def compact_record(full, detail_path):
+    """The one line the driver reads: the contract's keys, `roofline` and `cpu_baseline` trimmed to their numbers, the
+    all-fp32-MFMA step beside the headline, and where the full record (per-kernel tables, other configurations, prose)
+    was written.  Stays under COMPACT_LIMIT bytes (tests/test_bench_line.py)."""
+    def pick(d, keys):
+        return None if d is None else {k: d[k] for k in keys if k in d}
+
+    def r4(x):
+        return float("%.5g" % x) if isinstance(x, float) else x
+
+    def rounded(d):
+        return None if d is None else {k: r4(v) for k, v in d.items()}
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                 "scaling", "vs_baseline", "dtype", "data") if k in full}
+    line["config"] = pick(full.get("config"), ("workload", "rays_per_gpu", "parallelism"))
+    line["roofline"] = rounded(pick(full.get("roofline"), (
+        "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic",
+        "traffic_over_survey_algorithmic", "avg_launch_ms", "frac_mfma", "frac_hbm", "algorithmic_bytes_per_launch",
+        "survey_algorithmic_bytes_per_launch", "flop_per_launch", "step_traffic_bytes", "step_traffic_over_survey_algorithmic")))
+    line["cpu_baseline"] = rounded(pick(full.get("cpu_baseline"), (
+        "value", "unit", "cores", "kind", "sample", "best_ms", "median_ms", "value_median", "os_cpu_count",
+        "rays_per_s_1024_rays_anomaly_on_as_shipped")))
+    if "speedup_vs_cpu_baseline" in full:
+        line["speedup_vs_cpu_baseline"] = r4(full["speedup_vs_cpu_baseline"])
+    fp32 = (full.get("extras") or {}).get("all_fp32_mfma_step")
+    if fp32 and "ms_per_step" in fp32:
+        line["all_fp32_mfma_step"] = {"ms_per_step": r4(fp32["ms_per_step"]), "rays_per_s": r4(fp32["rays_per_s"]),
+                                      "frac_of_157.3_TF": r4(fp32["step_tflops_over_fp32_mfma_peak"])}
+    for k in ("ms_per_step_events_off", "step_tflops", "per_rank_ms_per_step"):
+        if k in full:
+            line[k] = [r4(x) for x in full[k]] if isinstance(full[k], list) else r4(full[k])
+    if full.get("all_reduce_alone"):
+        line["all_reduce_alone"] = rounded(pick(full["all_reduce_alone"], ("ms_per_all_reduce", "floats", "world_size", "backend", "error")))
+    line["detail"] = detail_path
+    text = json.dumps(line)
+    if len(text) >= COMPACT_LIMIT:                  # (cannot happen with the fields above; never emit an unparseable tail)
+        for k in ("all_reduce_alone", "per_rank_ms_per_step", "all_fp32_mfma_step"):
+            line.pop(k, None)
+        if line.get("cpu_baseline"):
+            line["cpu_baseline"]["sample"] = str(line["cpu_baseline"].get("sample"))[:200]
+        if line.get("config"):
+            line["config"]["workload"] = str(line["config"].get("workload"))[:200]
+        text = json.dumps(line)
+    return text
+
+
+def latest_pmc_traffic():
+    """the newest profiles/pmc_traffic_r*.json whose source hash matches the kernel sources (None: stale or absent)"""
+    import glob
+    want = csrc_sha16()
+    stale = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_traffic_r*.json")), reverse=True):
+        rec = json.load(open(path))
+        if rec.get("_csrc_sha16") == want:
+            return rec, os.path.relpath(path, ROOT), None
+        stale = stale or "%s was taken at other kernel sources (%s, now %s): refused as stale" % (
+            os.path.relpath(path, ROOT), rec.get("_csrc_sha16"), want)
+    return None, None, stale
+
+
 def main():
     # stdout carries exactly ONE line, the JSON record: everything else that writes to file descriptor 1 (RCCL prints a
     # version banner there when its first communicator comes up, progress bars, ...) is sent to stderr
@@ -401,7 +545,8 @@ def main():
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=512)
+    ap.add_argument("--cpu-rays", type=int, default=4096, help="rays of the CPU reference leg (BASELINE.md section 2: 4096)")
+    ap.add_argument("--detail", default=None, help="where the full record goes (default profiles/bench_detail_n<N>.json)")
     ap.add_argument("--camera", action="store_true", help="rays from the learnable camera model also at N = 1")
     ap.add_argument("--mlp-arithmetic", choices=("resident", "split", "fp32", "half"), default=None,
                     help="forward and data-gradient chain: 'resident' (default): the whole network as one launch each on "
@@ -417,11 +562,15 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0 (functional check, with --backend gloo)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: one process per GPU through torch.distributed.run (what the driver's own command
+        # line does), rendezvous on 127.0.0.1; rank 0's JSON line is the only thing on the children's stdout
+        raise SystemExit(self_launch(a.gpus, json_out))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if a.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world))
+        raise SystemExit("--gpus %d under a launcher that started %d ranks" % (a.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -514,17 +663,26 @@ def main():
                     "measured": ("HIP events on the launch stream around each launch of this kernel inside the timed region "
                                  "(ops.PROFILE; the eight 256 x 256 weight-gradient GEMMs: events recorded by the C entry point "
                                  "around its one launch, scnerf_wgrad_profile_events)")}
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic_r03.json")
-            if os.path.isfile(pmc):
-                rec = json.load(open(pmc))
-                if rec.get("_csrc_sha16") == csrc_sha16():
-                    roof["traffic"] = rec.get("bytes_per_launch", {}).get(dom)
-                    roof["traffic_source"] = rec.get("_source")
-                    if roof["traffic"]:
-                        roof["traffic_over_algorithmic"] = roof["traffic"] / f["algorithmic_bytes_per_launch"]
-                else:
-                    roof["traffic_source"] = ("profiles/pmc_traffic_r03.json was taken at other kernel sources (%s, now %s): "
-                                              "refused as stale" % (rec.get("_csrc_sha16"), csrc_sha16()))
+            # SURVEY section 8(d)'s algorithmic bytes: what crosses HBM if nothing but the path's inputs and outputs does
+            # (the point in, raw out for a network launch; per step 5 KB per ray): the activation / gradient workspaces the
+            # weight-gradient GEMMs read are the design's own traffic, reported against it
+            md = region_model(dom)
+            pd = 4 if "/pd4" in dom else 3
+            import re as _re
+            P_dom = int(_re.search(r"/P=(\d+)", dom).group(1))
+            roof["survey_algorithmic_bytes_per_launch"] = (4 * pd + 16) * P_dom
+            rec, path, stale = latest_pmc_traffic()
+            if rec:
+                roof["traffic"] = rec.get("bytes_per_launch", {}).get(dom)
+                roof["traffic_source"] = "%s: %s" % (path, rec.get("_source"))
+                if roof["traffic"]:
+                    roof["traffic_over_algorithmic"] = roof["traffic"] / f["algorithmic_bytes_per_launch"]
+                    roof["traffic_over_survey_algorithmic"] = roof["traffic"] / roof["survey_algorithmic_bytes_per_launch"]
+                if rec.get("bytes_per_step"):
+                    roof["step_traffic_bytes"] = rec["bytes_per_step"]
+                    roof["step_traffic_over_survey_algorithmic"] = rec["bytes_per_step"] / (5000.0 * n)
+            else:
+                roof["traffic_source"] = stale or "no profiles/pmc_traffic_r*.json"
         source = ("rays from the learnable camera model (%d views, %dx%d; configs[2..3] ray source), camera parameters "
                   "in the all-reduced flat buffer" % (N_CAMS, IMG_H, IMG_W)) if with_camera else \
             "precomputed rays of a fixed camera"
@@ -532,7 +690,9 @@ def main():
             "metric": "rays/sec (64+128 samples/ray) train-step", "value": n * world / (ms * 1e-3),
             "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
             "ms_per_step_events_off": ms_off,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"resident": "f32 (3 x fp16 MFMA products per product, fp32 accumulate)", "half": "f32 (3 x fp16 / 6 x bf16 MFMA products, fp32 accumulate)",
+                      "split": "f32 (6 x bf16 MFMA products, fp32 accumulate)", "fp32": "f32 (fp32 MFMA)"}[ops.mlp_arithmetic()],
             "arithmetic": {
                 "forward and data gradients": {
                     "resident": "the whole network as ONE launch per pass (csrc/mlp_h3.h): every operand scaled by a power of "
@@ -581,7 +741,15 @@ def main():
         if world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(a.cpu_rays)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        json_out.write(json.dumps(out) + "\n")
+        # the full record goes to a file; stdout carries the compact line only (a 26 KB line once outgrew the driver's tail)
+        detail = a.detail or os.path.join("profiles", "bench_detail_n%d.json" % world)
+        try:
+            os.makedirs(os.path.dirname(os.path.join(ROOT, detail)) or ".", exist_ok=True)
+            with open(os.path.join(ROOT, detail), "w") as fh:
+                json.dump(out, fh, indent=1)
+        except OSError as e:
+            detail = "not written: %r" % (e,)
+        json_out.write(compact_record(out, detail) + "\n")
         json_out.flush()
     if world > 1:
         dist.destroy_process_group()

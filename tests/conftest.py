@@ -15,28 +15,12 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 def _unpack_shipped_reference():
     """TEST INFRASTRUCTURE.  The reference tree exists only in the build container.  `tools/ship_reference.sh pack` puts its
     sources into `.ref_ship.tgz` beside the repository (git-ignored: outside the history), which travels to the GPU box
-    with the snapshot; where /root/reference is absent and the archive present it is unpacked under the temp directory
-    and SCNERF_REFERENCE_ROOT pointed at it, so that the unmodified run_nerf.py can train on the device
-    (tests/test_dropin_run_nerf.py::test_gpu_unmodified_train).  Nothing but tests/dropin_support.py reads that root."""
-    if os.environ.get("SCNERF_REFERENCE_ROOT") or os.path.isdir("/root/reference"):
-        return
-    tgz = os.path.join(ROOT, ".ref_ship.tgz")
-    if not os.path.isfile(tgz):
-        return
-    import tarfile
-    import tempfile
-    dst = os.path.join(tempfile.gettempdir(), "scnerf_reference_ship")
-    if not os.path.isfile(os.path.join(dst, "reference", "NeRF", "run_nerf.py")):
-        tmp = "%s.%d" % (dst, os.getpid())
-        os.makedirs(tmp, exist_ok=True)
-        with tarfile.open(tgz) as tf:
-            tf.extractall(tmp)
-        try:
-            os.rename(tmp, dst)
-        except OSError:                       # another process was first
-            import shutil
-            shutil.rmtree(tmp, ignore_errors=True)
-    os.environ["SCNERF_REFERENCE_ROOT"] = os.path.join(dst, "reference")
+    with the snapshot; where /root/reference is absent and the archive present, oracle/ref_ship.py unpacks it into a
+    0700 directory of this checkout and points SCNERF_REFERENCE_ROOT at it, so that the unmodified run_nerf.py can train on
+    the device (tests/test_dropin_run_nerf.py::test_gpu_unmodified_train).  Only tests/dropin_support.py, oracle/ref_import.py
+    and bench.py's cpu_baseline leg read that root."""
+    from oracle import ref_ship
+    ref_ship.ensure()
 
 
 _unpack_shipped_reference()

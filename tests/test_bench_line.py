@@ -1,0 +1,116 @@
+"""bench.py's stdout contract: ONE line, small enough for the driver's bounded stdout tail (round 3's line had grown to
+26 KB and came back unparsed), carrying the contract's keys + `roofline` + `cpu_baseline`; everything else goes to the
+detail file.  The GPU leg starts `bench.py --gpus 2` WITHOUT a launcher (the path the driver's command line would take if
+it ever omitted torch.distributed.run) and parses what comes out."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "detail")
+
+
+def _fat_record():
+    """a full record as main() assembles it, with every free-text field and table blown up well past what a run produces"""
+    prose = "x" * 3000
+    kernels = {"kernel %d/P=786432" % i: {"avg_ms": 1.234567891234, "pipe": prose, "tflops": 301.123456789} for i in range(200)}
+    return {
+        "metric": "rays/sec (64+128 samples/ray) train-step", "value": 326015.123456789, "unit": "rays/s", "n_gpus": 8,
+        "steps": 20, "warmup": 5, "ms_per_step": 12.5612345678, "ms_per_step_events_off": 12.56, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32 (3 x fp16 MFMA products per product, fp32 accumulate)",
+        "arithmetic": {"a": prose, "b": prose}, "timed_region": prose, "data": "synthetic",
+        "config": {"workload": "configs[1]: 4096 rays x (64 coarse + 128 fine), " + "y" * 400, "rays_per_gpu": 4096,
+                   "parallelism": "ray-parallel x8, 1 RCCL all-reduce/step of 1202945 floats", "other": prose},
+        "roofline": {"bound": "mfma", "kernel": "mlp_fwd_h3_kernel/P=786432/train", "achieved": 300.812345678, "peak": 833.3333333,
+                     "unit": "TFLOP/s", "frac": 0.36097, "traffic": 8729500128, "traffic_over_algorithmic": 1.0645,
+                     "traffic_over_survey_algorithmic": 396.4, "survey_algorithmic_bytes_per_launch": 22020096,
+                     "avg_launch_ms": 3.103, "frac_mfma": 0.36, "frac_hbm": 0.33, "algorithmic_bytes_per_launch": 8200000000,
+                     "flop_per_launch": 933400000000, "step_traffic_bytes": 46e9, "step_traffic_over_survey_algorithmic": 2246.1,
+                     "peak_note": prose, "measured": prose, "pipe": prose, "traffic_source": prose},
+        "kernels": kernels, "step_flop_algorithmic": 3733400000000, "step_tflops": 297.123456,
+        "per_rank_ms_per_step": [12.5612345678] * 8,
+        "all_reduce_alone": {"ms_per_all_reduce": 0.0512345, "floats": 1202945, "world_size": 8, "backend": "nccl"},
+        "extras": {"all_fp32_mfma_step": {"ms_per_step": 28.7123456, "rays_per_s": 142812.3456, "step_tflops_over_fp32_mfma_peak": 0.8312345,
+                                          "kernels": kernels},
+                   "config2_camera_curriculum": {"states": {"none": {"kernels": kernels}}}, "psnr_vs_reference": {"note": prose}},
+        "cpu_baseline": {"value": 287.0412345, "unit": "rays/s", "cores": 16, "kind": "reference", "sample": "z" * 500,
+                         "best_ms": 14270.123456, "median_ms": 14400.123456, "value_median": 284.4, "os_cpu_count": 256, "threads": 16,
+                         "rays_per_s_1024_rays": 300.1, "rays_per_s_1024_rays_anomaly_on_as_shipped": 250.2,
+                         "rays_per_s_1024_rays_all_256_threads": 100.3},
+        "speedup_vs_cpu_baseline": 1135.812345,
+    }
+
+
+def test_compact_line_is_small_and_complete():
+    import bench
+    full = _fat_record()
+    assert len(json.dumps(full)) > 100_000
+    text = bench.compact_record(full, "profiles/bench_detail_n8.json")
+    assert "\n" not in text and len(text) < bench.COMPACT_LIMIT == 4096
+    line = json.loads(text)
+    for k in REQUIRED:
+        assert k in line, k
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"] and line["n_gpus"] == 8
+    assert set(line["config"]) == {"workload", "rays_per_gpu", "parallelism"}
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic",
+              "traffic_over_survey_algorithmic"):
+        assert k in line["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    assert abs(line["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-4
+    assert line["all_fp32_mfma_step"]["ms_per_step"] == pytest.approx(28.712, rel=1e-4)
+    assert "kernels" not in line and "extras" not in line and "arithmetic" not in line
+    assert "3 x fp16" in line["dtype"]
+
+
+def test_compact_line_survives_missing_optional_parts():
+    import bench
+    full = _fat_record()
+    for k in ("extras", "cpu_baseline", "speedup_vs_cpu_baseline", "per_rank_ms_per_step", "all_reduce_alone"):
+        full.pop(k)
+    full["roofline"] = None
+    line = json.loads(bench.compact_record(full, "x.json"))
+    assert line["roofline"] is None and line["cpu_baseline"] is None and line["value"] == full["value"]
+
+
+def _run_bench(args, timeout=600):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines[0]) < 4096
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_gpu_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher: two ranks through torch.distributed.run on 127.0.0.1 (gloo, both on
+    the one device of the box: a functional check of the launch path), ONE parseable line from rank 0."""
+    detail = str(tmp_path / "detail.json")
+    line = _run_bench(["--gpus", "2", "--backend", "gloo", "--one-device", "--steps", "2", "--warmup", "1", "--no-cpu",
+                       "--rays", "512", "--detail", detail])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1
+    assert line["value"] > 0 and len(line["per_rank_ms_per_step"]) == 2
+    assert line["roofline"]["frac"] > 0
+    full = json.load(open(detail))
+    assert "kernels" in full and full["n_gpus"] == 2
+
+
+@pytest.mark.gpu
+def test_gpu_bench_single_line(tmp_path):
+    detail = str(tmp_path / "detail.json")
+    line = _run_bench(["--steps", "2", "--warmup", "1", "--no-cpu", "--no-extras", "--rays", "1024", "--detail", detail])
+    for k in REQUIRED:
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["cpu_baseline"] is None
+    assert line["roofline"]["bound"] in ("mfma", "hbm") and 0 < line["roofline"]["frac"] < 1

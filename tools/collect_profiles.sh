@@ -4,7 +4,7 @@
 # 1. kernel trace of the default bench workload (per-kernel durations; --kernel-trace only)
 # 2. counters, ONE per pass (--pmc with --kernel-trace only, as the pool requires), of tools/profile_kernels.py
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -18,6 +18,14 @@ for c in GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONF
   [ -n "$f" ] && cp $f $OUT/pmc/${c}_counter_collection.csv
   rm -rf $OUT/pmc/$c
 done
-python tools/pmc_summary.py $OUT/pmc --json $OUT/pmc_traffic_r03.json > $OUT/pmc_kernels.txt
-rm -rf $OUT/pmc
+# 3. whole-step HBM traffic: the same two counters over PMC_STEPS plain default steps
+mkdir -p $OUT/pmc_step
+for c in FETCH_SIZE WRITE_SIZE; do
+  PMC_STEPS=3 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_step/$c -o $c -- python tools/profile_steps.py pmc > /dev/null 2> $OUT/pmc_step_$c.err
+  f=$(find $OUT/pmc_step/$c -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && cp $f $OUT/pmc_step/${c}_counter_collection.csv
+  rm -rf $OUT/pmc_step/$c
+done
+python tools/pmc_summary.py $OUT/pmc --json $OUT/pmc_traffic_$TAG.json --steps-dir $OUT/pmc_step --steps 3 > $OUT/pmc_kernels.txt
+rm -rf $OUT/pmc $OUT/pmc_step
 tail -n +1 $OUT/pmc_kernels.txt | head -80

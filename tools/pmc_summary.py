@@ -13,7 +13,7 @@ KEEP = ("mlp_fwd_kernel", "mlp_bwd_kernel", "mlp_fwd_h3_kernel", "mlp_bwd_h3_ker
         "wgrad256_half_kernel", "wgrad_half_narrow_kernel", "rows4_kernel", "copyBuffer",
         "layer_split_kernel", "wgrad_tiles_kernel", "wgrad_reduce_multi_kernel", "wgrad_kernel", "vecmat_kernel", "elementwise_kernel")
 
-# bench.py's region names of the kernels whose HBM traffic goes into profiles/pmc_traffic_r03.json (P = 786432)
+# bench.py's region names of the kernels whose HBM traffic goes into profiles/pmc_traffic_r<NN>.json (P = 786432)
 REGIONS = {"mlp_fwd_h3_kernel<3, true, false>": "mlp_fwd_h3_kernel/P=786432/train",
            "mlp_fwd_h3_kernel<3, false, false>": "mlp_fwd_h3_kernel/P=786432/infer",
            "mlp_bwd_h3_kernel<3>": "mlp_bwd_h3_kernel/P=786432",
@@ -21,7 +21,20 @@ REGIONS = {"mlp_fwd_h3_kernel<3, true, false>": "mlp_fwd_h3_kernel/P=786432/trai
            "wgrad256_half_kernel<0>": "wgrad256_kernel<8 GEMMs, half>/P=786432"}
 
 
-def traffic_json(agg, out_path, source):
+def step_traffic(d, steps):
+    """whole-step HBM bytes: every dispatch of `tools/profile_steps.py pmc` (PMC_STEPS plain steps), both counters"""
+    tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+    for c in tot:
+        f = os.path.join(d, "%s_counter_collection.csv" % c)
+        if not os.path.isfile(f):
+            return None
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == c:
+                tot[c] += float(r["Counter_Value"])
+    return int((tot["WRITE_SIZE"] * 1024 + 2 * tot["FETCH_SIZE"] * 1024) / steps)
+
+
+def traffic_json(agg, out_path, source, bytes_per_step=None):
     """bytes per launch = WRITE_SIZE KB x 1024 + 2 x FETCH_SIZE KB x 1024 (gfx950 tallies wide coalesced reads at half
     their size: MI355X_MICROARCH.md, HBM section), with the calibration copy of known size beside it"""
     import hashlib
@@ -47,6 +60,10 @@ def traffic_json(agg, out_path, source):
     cal = [{"fetch_kb_raw": max(agg[k]["FETCH_SIZE"]), "write_kb": max(agg[k]["WRITE_SIZE"])} for k in agg
            if "copyBuffer" in k and agg[k].get("FETCH_SIZE") and agg[k].get("WRITE_SIZE")]
     rec = {"_csrc_sha16": bench.csrc_sha16(), "_source": source, "bytes_per_launch": by_region, "per_kernel": per}
+    if bytes_per_step:
+        rec["bytes_per_step"] = bytes_per_step
+        rec["_bytes_per_step_source"] = ("the same two counters summed over every dispatch of `tools/profile_steps.py pmc` "
+                                         "(plain default steps, 4096 rays) / the number of steps")
     if cal:
         c = max(cal, key=lambda v: v["write_kb"])
         rec["calibration_copy_1GiB_read_1GiB_written"] = {
@@ -71,9 +88,12 @@ def main():
                 seen.add(key)
                 dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     if "--json" in sys.argv:
+        bps = None
+        if "--steps-dir" in sys.argv:
+            bps = step_traffic(sys.argv[sys.argv.index("--steps-dir") + 1], int(sys.argv[sys.argv.index("--steps") + 1]))
         traffic_json(agg, sys.argv[sys.argv.index("--json") + 1],
                      "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, one counter each, --kernel-trace only) of "
-                     "tools/profile_kernels.py at P = 786432 (tools/collect_profiles.sh)")
+                     "tools/profile_kernels.py at P = 786432 (tools/collect_profiles.sh)", bps)
     print("# rocprofv3 --pmc summary of %s (values are per-dispatch means; counters from separate passes)" % d)
     print("# gfx950 notes (MI355X_MICROARCH.md): SQ_* cycle counters are quad-cycles summed over waves; "
           "FETCH_SIZE / WRITE_SIZE are KB; FETCH_SIZE under-reports wide coalesced reads by 2x;")

@@ -1,5 +1,7 @@
 """(GPU box) torch profile of the bench's training steps: launches and host time per step, by op
-(python tools/profile_steps.py [camera])."""
+(python tools/profile_steps.py [camera]); `python tools/profile_steps.py pmc` runs PMC_STEPS (default 3) plain steps and
+nothing else -- the workload of the whole-step HBM-traffic counters (tools/collect_profiles.sh: FETCH_SIZE / WRITE_SIZE
+summed over every dispatch of the process / PMC_STEPS; the few MB of set-up kernels are in the sum)."""
 import sys
 import os
 import torch
@@ -18,6 +20,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "camera":
 else:
     red = FlatGradAllReduce([w["net_c"], w["net_f"]], 1)
     step = bench.fixed_camera_step(w, red)
+if len(sys.argv) > 1 and sys.argv[1] == "pmc":
+    for _ in range(int(os.environ.get("PMC_STEPS", "3"))):
+        step()
+    torch.cuda.synchronize()
+    sys.exit(0)
 for _ in range(3):
     step()
 torch.cuda.synchronize()

@@ -1,13 +1,19 @@
 #!/bin/bash
-# end-of-round evidence (run on the GPU box: gpurun -- "bash tools/round_evidence.sh"): GPU suite, bench line, kernel trace, counters, the other arithmetics, the 2-rank launch path; results under gpurun_out/r03, copied by hand into profiles/
+# end-of-round evidence (run on the GPU box: gpurun -- "bash tools/round_evidence.sh r04"): GPU suite, bench line (+ its
+# detail file), kernel trace, counters incl. the HBM traffic the bench line quotes (collected LAST, at the sources the
+# line was produced from, so `roofline.traffic` is never stale), the fp32 yardstick, the self-started 2-rank launch path.
+# Results under gpurun_out/$TAG; copied into profiles/ with the r04_ prefix by tools/keep_evidence.sh.
 set -u
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r03
-(timeout 900 python -m pytest tests -m gpu -q > gpurun_out/r03/gpu_tests.txt 2>&1; echo rc=$? >> gpurun_out/r03/gpu_tests.txt)
-timeout 900 python bench.py > gpurun_out/r03/bench_n1.json 2> gpurun_out/r03/bench_n1.err
-timeout 600 bash tools/collect_profiles.sh r03 > gpurun_out/r03/collect.log 2>&1
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --one-device --no-cpu > gpurun_out/r03/bench_n2_gloo_one_device.json 2> gpurun_out/r03/bench_n2.err
-for a in half split fp32; do
-  timeout 200 python bench.py --mlp-arithmetic $a --steps 10 --warmup 3 --no-cpu --no-extras > gpurun_out/r03/bench_n1_mlp_$a.json 2> /dev/null
-done
-tail -3 gpurun_out/r03/gpu_tests.txt
+O=gpurun_out/$TAG
+mkdir -p $O
+(timeout 1200 python -m pytest tests -m gpu -q > $O/gpu_tests.txt 2>&1; echo rc=$? >> $O/gpu_tests.txt)
+timeout 600 bash tools/collect_profiles.sh $TAG > $O/collect.log 2>&1
+# the counters first, the bench line after them: it picks the fresh traffic file up (same sources => same hash)
+cp $O/pmc_traffic_$TAG.json profiles/pmc_traffic_$TAG.json 2> /dev/null
+timeout 900 python bench.py --detail $O/bench_detail_n1.json > $O/bench_n1.json 2> $O/bench_n1.err
+timeout 300 python bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --one-device --no-cpu --detail $O/bench_detail_n2_gloo_one_device.json > $O/bench_n2_gloo_one_device.json 2> $O/bench_n2.err
+timeout 200 python bench.py --mlp-arithmetic fp32 --wgrad-arithmetic fp32 --steps 10 --warmup 3 --no-cpu --no-extras --detail $O/bench_detail_n1_fp32.json > $O/bench_n1_fp32.json 2> /dev/null
+tail -3 $O/gpu_tests.txt
+cat $O/bench_n1.json
