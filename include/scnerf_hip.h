@@ -451,9 +451,11 @@ int scnerf_npp_perturb_bwd(const float* g_out, const float* t_rand, float* g_z, 
 /* sample_pdf of NeRF++ (ddp_train_nerf.py:83-132): bins [n,m+1], weights [n,m] (+1e-6, normalised,
  * cumulated with a leading 0), u [n,ns]; upper index = count of cdf[0..m-1] <= u (:113), denominators
  * under 1e-6 -> 1, bin width + 1e-6 (:130).  below_above (int, lower | upper << 16) and t [n,ns] are
- * optional outputs for _bwd, which returns d bins [n,m+1] (the weights are detached by the caller). */
+ * optional outputs for _bwd, which returns d bins [n,m+1] (the weights are detached by the caller);
+ * cdf [n,m+1] (optional) is the cumulated pdf the search ran on (:95-98) -- with below_above what the
+ * parity tests compare bit for bit against the reference's own cumsum and comparison count. */
 int scnerf_npp_sample_pdf(const float* bins, const float* weights, const float* u, float* samples,
-                          int* below_above, float* t, int n, int m, int ns, void* stream);
+                          int* below_above, float* t, float* cdf, int n, int m, int ns, void* stream);
 int scnerf_npp_sample_pdf_bwd(const float* g_samples, const int* below_above, const float* t, float* g_bins,
                               int n, int m, int ns, void* stream);
 

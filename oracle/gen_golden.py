@@ -690,6 +690,80 @@ def gen_nerfpp(ns_unused):
     np.savez_compressed(os.path.join(GOLDEN, "nerfpp.npz"), **out)
 
 
+def gen_nerfpp_sampler(ns_unused):
+    """The NeRF++ sampler at the main path's standard (nerfplusplus/ddp_train_nerf.py:83-132): the cumulated pdf and the
+    comparison-count indices (:95-98, :113) beside the samples.  The reference's sample_pdf returns the samples only;
+    cdf / indices are the oracle's restatement of the same torch expressions, ACCEPTED ONLY IF the samples it forms from
+    them equal the reference function's output bit for bit (asserted here, on every vector).  Also the level-0 weights of
+    the cascade step (gen_nerfpp's `step/` case, re-run: its refined depths must reproduce the committed golden bit for
+    bit) so that the GPU sampler can be fed the reference's own weights, and level 1's full output on the reference's
+    refined depths."""
+    from oracle import nerfpp_oracle as NO
+    from oracle.ref_import import load_nerfpp
+    npp = load_nerfpp()
+    old = dict(np.load(os.path.join(GOLDEN, "nerfpp.npz")))
+    out = {}
+    bins, w, u = (torch.from_numpy(old[k]) for k in ("kat/bins", "kat/weights", "kat/u"))
+    s, cdf, below, above = NO.sample_pdf_state(bins, w, u)
+    with injected_uniforms([u]):
+        ref = npp.train.sample_pdf(bins, w, 40, det=False)
+    assert torch.equal(s, ref) and np.array_equal(np32(ref), old["kat/pdf_samples"])
+    out["kat/cdf"], out["kat/above"], out["kat/below"] = np32(cdf), above.numpy().astype(np.int32), below.numpy().astype(np.int32)
+    u_det = torch.linspace(0., 1., 40).expand(bins.shape[0], 40)
+    s, cdf_d, below, above = NO.sample_pdf_state(bins, w, u_det)
+    assert torch.equal(s, npp.train.sample_pdf(bins, w, 40, det=True)) and torch.equal(cdf_d, cdf)
+    out["kat/above_det"] = above.numpy().astype(np.int32)
+
+    args = types.SimpleNamespace(max_freq_log2=10, max_freq_log2_viewdirs=4, netdepth=8, netwidth=256, use_viewdirs=True)
+
+    def make_net(seed):
+        torch.manual_seed(seed)
+        return npp.ddp_model.NerfNet(args)
+    n, s0, s1 = 32, 64, 128
+    o, d, near = synth.nerfpp_rays(n, seed=25)
+    rnd = synth.nerfpp_randoms(n, s0, s1, seed=26)
+    nets = [make_net(779), make_net(780)]
+    target = torch.rand(n, 3, generator=torch.Generator().manual_seed(27))
+    oo, dd = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    with injected_uniforms([rnd["t_fg"], rnd["t_bg"], rnd["u_fg"], rnd["u_bg"]]):
+        far = npp.train.intersect_sphere(oo, dd)
+        step = (far - near) / (s0 - 1)
+        fg_depth = torch.stack([near + i * step for i in range(s0)], dim=-1)
+        fg_depth = npp.train.perturb_samples(fg_depth)
+        bg_depth = torch.linspace(0., 1., s0).view(1, s0).expand(n, s0)
+        bg_depth = npp.train.perturb_samples(bg_depth)
+        ret0 = nets[0](oo, dd, far, fg_depth, bg_depth)
+        fg_w = ret0["fg_weights"].clone().detach()
+        fg_mid = .5 * (fg_depth[..., 1:] + fg_depth[..., :-1])
+        fg_s = npp.train.sample_pdf(bins=fg_mid, weights=fg_w[..., 1:-1], N_samples=s1, det=False)
+        fg_depth1, _ = torch.sort(torch.cat((fg_depth, fg_s), dim=-1))
+        bg_w = ret0["bg_weights"].clone().detach()
+        bg_mid = .5 * (bg_depth[..., 1:] + bg_depth[..., :-1])
+        bg_s = npp.train.sample_pdf(bins=bg_mid, weights=bg_w[..., 1:-1], N_samples=s1, det=False)
+        bg_depth1, _ = torch.sort(torch.cat((bg_depth, bg_s), dim=-1))
+        ret1 = nets[1](oo, dd, far, fg_depth1, bg_depth1)
+    assert np.array_equal(np32(fg_depth1), old["step/fg_depth1"]) and np.array_equal(np32(bg_depth1), old["step/bg_depth1"])
+    assert np.array_equal(np32(ret1["rgb"]), old["step/rgb1"])
+    k = "step/"
+    for tag, mid, wts, uu, smp in (("fg", fg_mid, fg_w, rnd["u_fg"], fg_s), ("bg", bg_mid, bg_w, rnd["u_bg"], bg_s)):
+        s, cdf, below, above = NO.sample_pdf_state(mid.detach(), wts[..., 1:-1], uu)
+        assert torch.equal(s, smp.detach()), tag
+        out.update({k + tag + "_w0": np32(wts), k + tag + "_mid": np32(mid), k + tag + "_cdf": np32(cdf),
+                    k + tag + "_above": above.numpy().astype(np.int32), k + tag + "_samples": np32(smp)})
+    for name, v in ret0.items():
+        out[k + "ret0/" + name] = np32(v)
+    for name, v in ret1.items():
+        out[k + "ret1/" + name] = np32(v)
+    # level 1 alone: loss on ret1 only, gradients of its network (fingerprints) -- what the GPU must reproduce when it is
+    # handed the reference's refined depths
+    loss1 = ((ret1["rgb"] - target) ** 2).mean()
+    loss1.backward()
+    out[k + "loss1"] = np32(loss1)
+    for name, v in _projections([(a, b.grad) for a, b in nets[1].named_parameters()]).items():
+        out[k + "gproj1_alone/" + name] = v
+    np.savez_compressed(os.path.join(GOLDEN, "nerfpp_sampler.npz"), **out)
+
+
 def gen_prd_filter(ns):
     """filter_matches_with_gt (model/prd_evaluation.py:189-332) -- the reference's own function, executed from
     where it lies (its module imports cv2 / SuperGlue at the top, so only the function is taken) -- on synthetic
@@ -719,7 +793,7 @@ def gen_prd_filter(ns):
 
 ALL = dict(optimizer=gen_optimizer, prd_filter=gen_prd_filter, init=gen_init_check, embedder=gen_embedder, mlp=gen_mlp, sample_pdf=gen_sample_pdf,
            composite=gen_composite, render_rays=gen_render_rays, camera=gen_camera,
-           rowsum=gen_rowsum, prd=gen_prd, checkpoint=gen_checkpoint, nerfpp=gen_nerfpp)
+           rowsum=gen_rowsum, prd=gen_prd, checkpoint=gen_checkpoint, nerfpp=gen_nerfpp, nerfpp_sampler=gen_nerfpp_sampler)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -46,7 +46,7 @@ PROTOTYPES = {
     "scnerf_npp_intersect_bwd": [P, P, P, P, P, I, P],
     "scnerf_npp_perturb_fwd": [P, P, P, I, I, P],
     "scnerf_npp_perturb_bwd": [P, P, P, I, I, P],
-    "scnerf_npp_sample_pdf": [P, P, P, P, P, P, I, I, I, P],
+    "scnerf_npp_sample_pdf": [P, P, P, P, P, P, P, I, I, I, P],
     "scnerf_npp_sample_pdf_bwd": [P, P, P, P, I, I, I, P],
     "scnerf_npp_points_fwd": [P, P, P, P, P, P, P, P, I, I, I, P],
     "scnerf_npp_points_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],

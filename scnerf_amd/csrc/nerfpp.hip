@@ -151,8 +151,8 @@ __global__ void perturb_bwd_kernel(const float* __restrict__ g_out, const float*
 // bins [n, m+1], weights [n, m], u [n, ns] -> samples [n, ns]; below / t (optional, for the backward).
 __global__ __launch_bounds__(256) void npp_sample_pdf_kernel(
     const float* __restrict__ bins, const float* __restrict__ weights, const float* __restrict__ u,
-    float* __restrict__ samples, int* __restrict__ below_out, float* __restrict__ t_out, int n, int m, int ns,
-    int lds_per_wave) {
+    float* __restrict__ samples, int* __restrict__ below_out, float* __restrict__ t_out, float* __restrict__ cdf_out,
+    int n, int m, int ns, int lds_per_wave) {
     float* s_w = dynamic_lds<float>() + (size_t)wave_id() * lds_per_wave;
     float* s_cdf = s_w + m;                  // m + 1 entries
     const int lane = lane_id();
@@ -172,6 +172,8 @@ __global__ __launch_bounds__(256) void npp_sample_pdf_kernel(
         }
     }
     block_sync();
+    if (cdf_out && live)
+        for (int k = lane; k <= m; k += kWave) cdf_out[(size_t)ray * (m + 1) + k] = s_cdf[k];
     const float* b = bins + (size_t)ray * (m + 1);
     for (int j = lane; j < ns; j += kWave) {
         const float uq = u[(size_t)ray * ns + j];
@@ -621,14 +623,14 @@ extern "C" int scnerf_npp_perturb_bwd(const float* g_out, const float* t_rand, f
 }
 
 extern "C" int scnerf_npp_sample_pdf(const float* bins, const float* weights, const float* u, float* samples,
-                                     int* below_above, float* t, int n, int m, int ns, void* stream) {
+                                     int* below_above, float* t, float* cdf, int n, int m, int ns, void* stream) {
     SCN_RETURN_IF(!bins || !weights || !u || !samples || n < 0 || m < 1 || m > 32767 || ns < 1, SCN_EINVAL);
     if (n == 0) return 0;
     const int per_wave = (2 * m + 1 + 3) / 4 * 4;
     const size_t lds = (size_t)per_wave * 4 * kRaysPerBlock;
     SCN_RETURN_IF(lds > 64 * 1024, SCN_ENOSUP);
     hipLaunchKernelGGL(npp_sample_pdf_kernel, dim3(scn_ceil_div(n, kRaysPerBlock)), dim3(256), lds,
-                       (hipStream_t)stream, bins, weights, u, samples, below_above, t, n, m, ns, per_wave);
+                       (hipStream_t)stream, bins, weights, u, samples, below_above, t, cdf, n, m, ns, per_wave);
     return scn_launch_status();
 }
 

@@ -92,7 +92,7 @@ class _SamplePdf(torch.autograd.Function):
         need = ctx.needs_input_grad[0]
         ba = torch.empty((n, ns), dtype=torch.int32, device=b.device) if need else None
         t = torch.empty((n, ns), dtype=torch.float32, device=b.device) if need else None
-        _capi.check(_capi.load().scnerf_npp_sample_pdf(_p(b), _p(w), _p(uu), _p(samples), _p(ba), _p(t), n, m, ns,
+        _capi.check(_capi.load().scnerf_npp_sample_pdf(_p(b), _p(w), _p(uu), _p(samples), _p(ba), _p(t), None, n, m, ns,
                                                        _stream()), "scnerf_npp_sample_pdf")
         if need:
             ctx.save_for_backward(ba, t)
@@ -108,6 +108,22 @@ class _SamplePdf(torch.autograd.Function):
         _capi.check(_capi.load().scnerf_npp_sample_pdf_bwd(_p(g), _p(ba), _p(t), _p(gb), n, m, ns, _stream()),
                     "scnerf_npp_sample_pdf_bwd")
         return gb.view(shape), None, None
+
+
+def sample_pdf_state(bins, weights, u):
+    """What the sampler kernel computed on its way, for the parity tests: (samples [n, ns], cdf [n, m + 1] -- the
+    cumulated pdf with the leading 0 (:95-98) --, below [n, ns], above [n, ns] -- the comparison count of :113 and the
+    index under it (int64)).  Same launch as sample_pdf."""
+    m, ns = weights.shape[-1], u.shape[-1]
+    b, w, uu = _flat2(bins, m + 1), _flat2(weights.detach(), m), _flat2(u, ns)
+    n = b.shape[0]
+    samples = torch.empty((n, ns), dtype=torch.float32, device=b.device)
+    ba = torch.empty((n, ns), dtype=torch.int32, device=b.device)
+    t = torch.empty((n, ns), dtype=torch.float32, device=b.device)
+    cdf = torch.empty((n, m + 1), dtype=torch.float32, device=b.device)
+    _capi.check(_capi.load().scnerf_npp_sample_pdf(_p(b), _p(w), _p(uu), _p(samples), _p(ba), _p(t), _p(cdf), n, m, ns,
+                                                   _stream()), "scnerf_npp_sample_pdf")
+    return samples, cdf, (ba & 0xffff).long(), (ba >> 16).long()
 
 
 def sample_pdf(bins, weights, N_samples, det=False, _u=None):

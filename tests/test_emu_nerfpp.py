@@ -6,7 +6,7 @@ import torch
 
 from oracle import nerfpp_oracle as NO
 from tests.emu import harness as H
-from test_nerfpp_oracle import G, T
+from test_nerfpp_oracle import G, GS, T
 
 pytestmark = pytest.mark.emu
 
@@ -56,8 +56,11 @@ def test_perturb_samples_fwd_bwd():
     np.testing.assert_array_equal(one_out, one)
 
 
-@pytest.mark.parametrize("key,ukey", [("kat/pdf_samples", "kat/u"), ("kat/pdf_det", None)])
-def test_sample_pdf_matches_reference(key, ukey):
+@pytest.mark.parametrize("key,ukey,akey", [("kat/pdf_samples", "kat/u", "kat/above"), ("kat/pdf_det", None, "kat/above_det")])
+def test_sample_pdf_matches_reference(key, ukey, akey):
+    """Bit for bit: the cumulated pdf (:95-98: ATen's row sum, fp64-accumulated cumsum), the comparison count (:113)
+    and the samples of the reference's own sample_pdf (tests/golden/nerfpp_sampler.npz: cdf / indices restated, accepted
+    only because the samples formed from them equal the reference function's output bit for bit)."""
     bins, w = G["kat/bins"], G["kat/weights"]
     n, m = w.shape
     u = G[ukey] if ukey else np.ascontiguousarray(np.broadcast_to(torch.linspace(0.0, 1.0, 40).numpy(), (n, 40)))
@@ -65,15 +68,13 @@ def test_sample_pdf_matches_reference(key, ukey):
     out = np.full((n, ns), np.nan, np.float32)
     ba = np.full((n, ns), -1, np.int32)
     t = np.full((n, ns), np.nan, np.float32)
-    H.call("scnerf_npp_sample_pdf", bins, w, u, out, ba, t, n, m, ns, None)
-    ref = G[key]
-    e = np.abs(out - ref)
-    # bit-exact except where u sits within an ulp of a cdf knot (the count flips between two bins whose
-    # interpolants agree there up to the knot spacing): none expected on these vectors
-    assert (e == 0).mean() > 0.999, (e == 0).mean()
-    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-6)
+    cdf = np.full((n, m + 1), np.nan, np.float32)
+    H.call("scnerf_npp_sample_pdf", bins, w, u, out, ba, t, cdf, n, m, ns, None)
     below, above = ba & 0xffff, ba >> 16
-    assert below.min() >= 0 and above.max() <= m and np.all((above - below <= 1))
+    np.testing.assert_array_equal(cdf, GS["kat/cdf"])
+    np.testing.assert_array_equal(above, GS[akey])
+    np.testing.assert_array_equal(below, np.maximum(GS[akey] - 1, 0))
+    np.testing.assert_array_equal(out, G[key])
     # backward w.r.t. the bins vs autograd on the oracle
     tb = torch.tensor(bins, requires_grad=True)
     g = torch.randn(n, ns, generator=torch.Generator().manual_seed(3))
@@ -258,7 +259,7 @@ def test_empty_and_single_ray_edge_cases():
     H.call("scnerf_npp_intersect_bwd", z, z, z, z, z, 0, None)
     H.call("scnerf_npp_perturb_fwd", z, z, z, 0, 5, None)
     H.call("scnerf_npp_perturb_bwd", z, z, z, 0, 5, None)
-    H.call("scnerf_npp_sample_pdf", z, z, z, z, zi, z, 0, 7, 3, None)
+    H.call("scnerf_npp_sample_pdf", z, z, z, z, zi, z, z, 0, 7, 3, None)
     H.call("scnerf_npp_sample_pdf_bwd", z, zi, z, z, 0, 7, 3, None)
     H.call("scnerf_npp_points_fwd", z, z, z, z, z, z, z, None, 0, 4, 4, None)
     H.call("scnerf_npp_points_bwd", z, z, z, z, z, z, z, z, None, None, z, z, z, 0, 4, 4, None)

@@ -11,6 +11,7 @@ from oracle import scnerf_oracle as O
 from scnerf_amd import synthetic as synth
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "nerfpp.npz"))
+GS = np.load(os.path.join(os.path.dirname(__file__), "golden", "nerfpp_sampler.npz"))     # oracle/gen_golden.py:gen_nerfpp_sampler
 
 
 def T(k):
