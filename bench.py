@@ -73,7 +73,7 @@ def region_model(name):
         return dict(flop=2 * mac * P, products=3 if "_h3_" in name else None,
                     bytes=(grad_b + ML.MASK_WORDS_PER_SAMPLE * 4 + 16 + 4 * pd + 4 * pd + 12) * P)
     if name.startswith("wgrad256_kernel"):
-        return dict(flop=8 * 2 * 256 * 256 * P, products=3 if "half" in name else 6 if "split" in name else None,
+        return dict(flop=8 * 2 * 256 * 256 * P, products=3 if "half" in name else None,
                     bytes=16 * 256 * 4 * P)
     if name.startswith("wgrad("):
         # 8 of the 12 GEMMs (87 % of the FLOP) are the 256 x 256 ones; on three fp16 products the shapes with a
@@ -82,10 +82,6 @@ def region_model(name):
         big = 8 * 2 * 256 * 256 * P
         return dict(flop=2 * mac * P, products=None, bytes=(lay.save_floats_per_sample * 4 + grad_b) * P,
                     mixed=big, mixed_half=big + 2 * (2 * 256 * lay.e_width + 128 * 256 + 128 * 32) * P)
-    if name.startswith("layer_split_kernel"):
-        m2 = re.search(r": (\d) on three fp16 products", name)
-        n16 = int(m2.group(1)) if m2 else 0
-        return dict(flop=8 * 2 * 256 * 256 * P, products=(3 * n16 + 6 * (8 - n16)) / 8.0, bytes=8 * 2 * 256 * 4 * P)
     return None
 
 
@@ -96,14 +92,12 @@ def floors(name, avg_ms, wgrad_products=3):
     if md is None or not avg_ms:
         return None
     if md.get("mixed") and wgrad_products:
-        f16 = min(md["flop"], md["mixed_half"] if wgrad_products == 3 else md["mixed"])
+        f16 = min(md["flop"], md["mixed_half"])
         t_mfma = f16 * wgrad_products / (PEAK_16BIT_MFMA_TFLOPS * 1e12) + (md["flop"] - f16) / (PEAK_F32_MFMA_TFLOPS * 1e12)
-        pipe = ("fp16 MFMA x3 on the eight 256 x 256 GEMMs and the narrow ones with a tile-native dZ, fp32 on the rest" if wgrad_products == 3
-                else "bf16 MFMA x6 on the eight 256 x 256 GEMMs, fp32 MFMA on the narrow ones")
+        pipe = "fp16 MFMA x3 on the eight 256 x 256 GEMMs and the narrow ones with a tile-native dZ, fp32 on the rest"
     elif md["products"]:
         t_mfma = md["flop"] * md["products"] / (PEAK_16BIT_MFMA_TFLOPS * 1e12)
-        pipe = "%s MFMA x%g (fp32 operands cut into 16-bit planes, fp32 accumulate)" % (
-            "fp16" if md["products"] == 3 else "bf16" if md["products"] == 6 else "fp16 / bf16", md["products"])
+        pipe = "fp16 MFMA x%g (fp32 operands cut into two fp16 planes, fp32 accumulate)" % md["products"]
     else:
         t_mfma = md["flop"] / (PEAK_F32_MFMA_TFLOPS * 1e12)
         pipe = "fp32 MFMA"
@@ -256,7 +250,7 @@ def _kernel_table(kern, steps):
     """per timed region: launches, average time, and both floors (MFMA at the dense rate of the pipe the region runs
     on, HBM at 8 TB/s over its algorithmic bytes) with the binding one named"""
     from scnerf_amd import ops
-    products = {"fp32": 0, "split": 6, "half": 3 if ops.mlp_arithmetic() == "resident" else 6}[ops.wgrad_arithmetic()]
+    products = 3 if (ops.wgrad_arithmetic() == "half" and ops.mlp_arithmetic() == "resident") else 0
     out = {}
     for k, v in kern.items():
         e = {"avg_ms": v["avg_ms"], "launches_per_step": v["launches"] / steps}
@@ -560,15 +554,13 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=4096, help="rays of the CPU reference leg (BASELINE.md section 2: 4096)")
     ap.add_argument("--detail", default=None, help="where the full record goes (default profiles/bench_detail_n<N>.json)")
     ap.add_argument("--camera", action="store_true", help="rays from the learnable camera model also at N = 1")
-    ap.add_argument("--mlp-arithmetic", choices=("resident", "split", "fp32", "half"), default=None,
+    ap.add_argument("--mlp-arithmetic", choices=("resident", "fp32"), default=None,
                     help="forward and data-gradient chain: 'resident' (default): the whole network as one launch each on "
-                         "three fp16 products with register-resident activations; 'half' / 'split': the eight 256-wide "
-                         "layers as GEMMs over all samples (three fp16 / six bf16 products) between the fused kernels' end "
-                         "stages; 'fp32': the fused fp32-MFMA kernels")
-    ap.add_argument("--wgrad-arithmetic", choices=("half", "split", "fp32"), default=None,
-                    help="256 x 256 weight-gradient GEMMs: three fp16 products with a scale per operand and workgroup chunk "
-                         "(default; with the resident kernels), six bf16 products with exactly cut fp32 operands, or the "
-                         "exact-fp32 MFMA")
+                         "three fp16 products with register-resident activations; 'fp32': the fused fp32-MFMA kernels "
+                         "(the numerical yardstick)")
+    ap.add_argument("--wgrad-arithmetic", choices=("half", "fp32"), default=None,
+                    help="weight-gradient GEMMs: three fp16 products with a scale per operand and workgroup chunk (default; "
+                         "needs the resident kernels' chunk maxima), or the exact-fp32 MFMA")
     ap.add_argument("--backend", default=os.environ.get("SCNERF_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend (nccl = RCCL; gloo for a functional check of N ranks on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0 (functional check, with --backend gloo)")
@@ -668,8 +660,8 @@ def main():
                     "flop_per_launch": f["flop_per_launch"], "algorithmic_bytes_per_launch": f["algorithmic_bytes_per_launch"],
                     "pipe": f["pipe"],
                     "peak_note": ("TFLOP/s are algorithmic fp32 products per second; the MFMA peak is the dense 16-bit rate "
-                                  "(2500) over the partial products per fp32 product (3: two-way fp16 cut, 6: three-way bf16 "
-                                  "cut), or the fp32 MFMA's 157.3; the HBM peak is the 8 TB/s spec over the ALGORITHMIC bytes "
+                                  "(2500) over the 3 partial products per fp32 product (two-way fp16 cut), or the fp32 MFMA's "
+                                  "157.3; the HBM peak is the 8 TB/s spec over the ALGORITHMIC bytes "
                                   "of the launch.  `bound` names the larger of the two floors, `frac` = that floor / the "
                                   "measured time; frac_mfma and frac_hbm are both given"),
                     "measured": ("HIP events on the launch stream around each launch of this kernel inside the timed region "
@@ -703,27 +695,22 @@ def main():
             "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
             "ms_per_step_events_off": ms_off,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"resident": "f32 (3 x fp16 MFMA products per product, fp32 accumulate)", "half": "f32 (3 x fp16 / 6 x bf16 MFMA products, fp32 accumulate)",
-                      "split": "f32 (6 x bf16 MFMA products, fp32 accumulate)", "fp32": "f32 (fp32 MFMA)"}[ops.mlp_arithmetic()],
+            "dtype": {"resident": "f32 (3 x fp16 MFMA products per product, fp32 accumulate)", "fp32": "f32 (fp32 MFMA)"}[ops.mlp_arithmetic()],
             "arithmetic": {
                 "forward and data gradients": {
                     "resident": "the whole network as ONE launch per pass (csrc/mlp_h3.h): every operand scaled by a power of "
                                 "two (per sample from the row / column 1-norm bound x the measured input maximum; per layer for "
                                 "the weights) and cut into 2 fp16 numbers, 3 partial products on v_mfma_f32_32x32x16_f16, fp32 "
                                 "accumulate; activations register-resident from layer to layer; per-layer error vs fp64 = the "
-                                "fp32 MFMA's (profiles/parity_r03.json resident_layer_arithmetic_*)",
-                    "half": "fused fp32 end stages around GEMMs over all samples: three fp16 products where the input carries "
-                            "per-sample maxima, six bf16 products elsewhere (csrc/layer_split.h)",
-                    "split": "fused fp32 end stages around GEMMs over all samples on six bf16 products (csrc/layer_split.h)",
+                                "fp32 MFMA's (profiles/parity_r04.json resident_layer_arithmetic_*)",
                     "fp32": "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32 (fused kernels)"}[ops.mlp_arithmetic()],
                 "256x256 weight gradients": {
                     "half": "fp32 operands scaled by one power of two per operand and workgroup chunk (the chunk maxima come "
                             "from the resident kernels) and cut into 2 fp16 numbers, 3 partial products on "
                             "v_mfma_f32_32x32x16_f16, fp32 accumulate (csrc/wgrad256_half.h); error vs fp64 = the fp32 MFMA "
-                            "kernel's (profiles/parity_r03.json wgrad256_arithmetic_*)",
-                    "split": "fp32 operands cut EXACTLY into 3 bf16 numbers each, 6 of the 9 partial products on "
-                             "v_mfma_f32_32x32x16_bf16, fp32 accumulate (csrc/wgrad256_split.h)",
-                    "fp32": "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32"}[ops.wgrad_arithmetic()],
+                            "kernel's (profiles/parity_r04.json wgrad256_arithmetic_*)",
+                    "fp32": "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32"}[
+                        "half" if (ops.wgrad_arithmetic() == "half" and ops.mlp_arithmetic() == "resident") else "fp32"],
                 "narrow weight gradients": (
                     "256 x 64 (encoded point, twice) and 128 x (256 + 32) (views layer): three fp16 products as the 256 x 256 "
                     "ones, scales from the same chunk maxima (csrc/wgrad_half_narrow.h); rgb rows and alpha_linear's "

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SCNERF_ABI_VERSION 2
+#define SCNERF_ABI_VERSION 3
 
 int scnerf_abi_version(void);
 
@@ -245,86 +245,26 @@ int scnerf_vecmat(const float* x_tiled256, const float* vec, int vec_stride, lon
  * scnerf_mlp_fwd (save) and scnerf_mlp_bwd (grads) and d_raw [n_samples, 4].  workspace:
  * scnerf_nerf_wgrad_workspace_floats(n_chunks) floats. */
 int scnerf_nerf_param_count(int pt_dims);
-/* The 256 -> 256 trunk layers of the network (layers 1 .. 7 and feature_linear = 8; layer 5 with the skip input
- * [encoded point | h]: NeRF/run_nerf_helpers.py:92-103, :105-128) as per-layer GEMMs over all samples on the bf16
- * matrix pipe in the "split" arithmetic of scnerf_wgrad_arithmetic (every fp32 number cut exactly into three bf16,
- * six partial products, fp32 accumulate).
- * scnerf_pack_split_planes: flat parameters (reference order) -> the bf16 planes of those layers' weights in MFMA
- *   fragment order, scnerf_split_planes_shorts(pt_dims) 16-bit words; once per optimizer step.
- * scnerf_layer_split: act_out = act(W_layer act_in + b) for tile-native sections of width 256 (the layout of the
- *   scnerf_mlp_fwd save workspace), epts = the saved encoded points [padded samples][64 | 128] (layer 5 only),
- *   bias_table = the layer's lane-vector bias table inside the packed forward weights, mask = the layer's ReLU
- *   bit section or NULL; layers < 8 apply ReLU. */
-/* scnerf_mlp_fwd_split / scnerf_coarse_stage_fwd_split: the training forward (save != NULL) of scnerf_mlp_fwd /
- * scnerf_coarse_stage_fwd with the eight 256-wide layers run as such GEMMs between the encoding + layer 0 and the
- * heads, which stay on the fused fp32-MFMA kernel; same arguments plus `planes`, same outputs, same workspace. */
-/* scnerf_mlp_bwd_split: scnerf_mlp_bwd with the eight 256-wide transposed layers (feature_linear^T + the density
- * head, layers 7 .. 1) as such GEMMs between the heads and the encoded-point end of the fused kernel; same arguments
- * plus `planes` (the buffer holds the transposed planes too), same outputs. */
-/* The pieces of the two calls above one launch at a time (per-kernel timing): scnerf_mlp_fwd_stage (1 = encoding +
- * layer 0, 2 = heads) around scnerf_layer_split for layers 1 .. 8; scnerf_mlp_bwd_stage (1 = heads, 2 = encoded-point
- * end) around scnerf_layer_split_bwd for entries 0 .. 7 (0 = feature_linear^T + the density head's rank-1 term from
- * d_raw, e = layer (8 - e)^T; grad_in = d feature | dZ_{8-e}, grad_out = dZ_{7-e}, mask_in = ReLU bits of layer 7 - e,
- * alpha_table = the lane-vector alpha weights inside the packed backward weights). */
-int scnerf_mlp_fwd_stage(int pt_dims, int stage, const float* pts, const float* viewdirs, int vd_stride,
-                         int samples_per_ray, const float* wpacked, float* raw, float* save, long long n_samples,
-                         void* stream);
-int scnerf_mlp_bwd_stage(int pt_dims, int stage, const float* d_raw, const float* pts, const float* viewdirs,
-                         int vd_stride, int samples_per_ray, const float* wpacked_bwd, const float* save, float* grads,
-                         float* d_pts, float* d_views, long long n_samples, void* stream);
-int scnerf_layer_split_bwd(int pt_dims, int entry, const short* planes, const float* alpha_table, const float* grad_in,
-                           float* grad_out, const unsigned* mask_in, const float* d_raw, long long n_samples,
-                           void* stream);
-/* The eight layers of a pass as ONE launch (a workgroup keeps its 256-sample blocks from layer to layer, so layer
- * l + 1 reads what the same workgroup wrote: no dependency between workgroups) when every persistent workgroup owns
- * at least two blocks, else layer by layer: forward layers 1 .. 8 over the training workspace `save`, data-gradient
- * entries 0 .. 7 over `grads`.  scnerf_layer_split_workgroups: cap on the persistent workgroups per launch (default
- * 256 = one per CU; values outside 1 .. 1024 only query); returns the cap in force. */
-/* `amax` in the calls below: NULL -- every 256-wide layer on six bf16 products -- or a workspace of
- * scnerf_layer_amax_floats(n_samples) floats: the layers whose input comes with per-sample maxima (forward 2-4 and
- * 6-8, data gradients 7^T .. 1^T) then run on THREE fp16 products -- operands cut into two fp16 numbers after scaling
- * by a power of two per sample / per layer (csrc/layer_split.h) -- and every layer leaves the maxima of what it stores
- * there.  The fp16 planes and the weight scales follow the bf16 planes in `planes` (scnerf_pack_split_planes writes
- * both). */
-long long scnerf_layer_amax_floats(long long n_samples);
-int scnerf_layer_split_chain_fwd(int pt_dims, const short* planes, const float* wpacked, float* save, float* amax,
-                                 long long n_samples, void* stream);
-int scnerf_layer_split_chain_bwd(int pt_dims, const short* planes, const float* wpacked_bwd, const float* save,
-                                 float* grads, const float* d_raw, float* amax, long long n_samples, void* stream);
-int scnerf_layer_split_workgroups(int n);
-long long scnerf_split_planes_shorts(int pt_dims);
-int scnerf_mlp_bwd_split(int pt_dims, const float* d_raw, const float* pts, const float* viewdirs, int vd_stride,
-                         int samples_per_ray, const float* wpacked_bwd, const short* planes, const float* save,
-                         float* grads, float* d_pts, float* d_views, float* amax, long long n_samples, void* stream);
-int scnerf_mlp_fwd_split(int pt_dims, const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
-                         const float* wpacked, const short* planes, float* raw, float* save, float* amax,
-                         long long n_samples, void* stream);
-int scnerf_coarse_stage_fwd_split(const float* rays, int ray_stride, const float* t_vals, const float* t_rand,
-                                  int lindisp, const float* wpacked, const short* planes, float* save,
-                                  const float* noise, int white_bkgd, float* z, float* pts, float* raw,
-                                  float* rgb_map, float* disp_map, float* acc_map, float* depth_map, float* weights,
-                                  float* amax, int n_rays, int n_samples, void* stream);
-int scnerf_pack_split_planes(int pt_dims, const float* flat_params, short* planes, void* stream);
-int scnerf_layer_split(int pt_dims, int layer, const short* planes, const float* bias_table, const float* act_in,
-                       const float* epts, float* act_out, unsigned* mask, long long n_samples, void* stream);
-
-/* Arithmetic of the 256 x 256 weight-gradient GEMMs (87 % of the weight-gradient FLOPs).  mode 1 (default):
- * bf16 matrix pipe, every fp32 operand cut exactly into three bf16 numbers, six partial products per product,
- * fp32 accumulation -- the error against fp64 equals the exact-fp32 kernel's; mode 0: v_mfma_f32_32x32x2_f32; mode 2
- * (the default): three fp16 products where the operands' chunk maxima are known (scnerf_nerf_wgrad_h3), else as 1.
- * Any other value only queries.  Returns the mode in force.  Environment preset:
- * SCNERF_WGRAD_ARITHMETIC=fp32 | split.  (No reference counterpart: torch.autograd computes these GEMMs with
+/* Arithmetic of the 256 x 256 weight-gradient GEMMs (87 % of the weight-gradient FLOPs) and of the narrow ones with a
+ * tile-native dZ.  mode 1 (the default): three fp16 products per product -- every fp32 operand scaled by one power of two
+ * per operand and workgroup chunk and cut into two fp16 numbers, fp32 accumulation; the error against fp64 equals the
+ * exact-fp32 kernel's -- wherever the operands' chunk maxima are known (scnerf_nerf_wgrad_h3); mode 0, and where no
+ * maxima were left: v_mfma_f32_32x32x2_f32.  Any other value only queries.  Returns the mode in force.  Environment
+ * preset: SCNERF_WGRAD_ARITHMETIC=fp32 | half.  (No reference counterpart: torch.autograd computes these GEMMs with
  * whatever sgemm the build links.) */
 int scnerf_wgrad_arithmetic(int mode);
 long long scnerf_nerf_wgrad_workspace_floats(int n_chunks);
 /* scnerf_nerf_wgrad with the eight 256 x 256 GEMMs on THREE fp16 products (csrc/wgrad256_half.h) when the chunk maxima
  * of their operands are given -- amax_x / amax_z [8][scnerf_wgrad256_chunks(n_chunks)], left by scnerf_mlp_fwd_h3 /
- * scnerf_coarse_stage_fwd_h3 and scnerf_mlp_bwd_h3 for that chunk count -- and the arithmetic in force is 2 (the default); otherwise as
+ * scnerf_coarse_stage_fwd_h3 and scnerf_mlp_bwd_h3 for that chunk count -- and the arithmetic in force is 1 (the default); otherwise as
  * scnerf_nerf_wgrad.  With `scales` (the table of scnerf_h3_pack) as well, the narrow GEMMs with a tile-native dZ
  * (256 x 64 / 128 of the encoded-point layers, 128 x 256 of the views layer) run on three fp16 products too
  * (csrc/wgrad_half_narrow.h): amax_z then has 12 rows -- 8: dZ of the views layer, 9: dZ of layer 0, 10: max(1, |point|),
  * 11: max(1, |direction|), all left by scnerf_mlp_bwd_h3 -- and the feature is bounded through amax_x row 7 and the
  * table.
+ * ev_before / ev_after: NULL, or two hipEvent_t (created by the caller) recorded on the stream right before and after
+ * the call's one launch of the eight 256 x 256 GEMMs (bench.py's per-kernel timing; arguments of this call, nothing is
+ * kept between calls).
  * scnerf_wgrad_chunk_samples: the samples per workgroup chunk both sides use.
  * scnerf_wgrad256_half: one such GEMM with given maxima [n_chunks] (accuracy tests); workspace n_chunks * (65536 + 256). */
 long long scnerf_wgrad_chunk_samples(long long n_samples, int n_chunks);
@@ -333,7 +273,8 @@ long long scnerf_wgrad_chunk_samples(long long n_samples, int n_chunks);
 int scnerf_wgrad256_chunks(int n_chunks);
 int scnerf_nerf_wgrad_h3(int pt_dims, const float* save, const float* grads, const float* d_raw,
                          long long n_samples, int n_chunks, float* workspace, float* flat_grad,
-                         int accumulate, const float* amax_x, const float* amax_z, const float* scales, void* stream);
+                         int accumulate, const float* amax_x, const float* amax_z, const float* scales,
+                         void* ev_before, void* ev_after, void* stream);
 int scnerf_wgrad256_half(const float* dz_tiled, const float* x_tiled, long long n_samples, int n_chunks,
                          float* workspace, float* dW, float* db, const float* amax_dz, const float* amax_x,
                          void* stream);
@@ -345,9 +286,6 @@ int scnerf_wgrad_half_narrow(const float* dz_tiled, int n_load, const float* x, 
                              long long n_samples, int n_chunks, float* workspace, float* dW, float* db,
                              const float* amax_dz, const float* amax_x, int n_coarse, long long coarse_chunk,
                              void* stream);
-/* Measurement hook (bench.py): two hipEvent_t (created by the caller) that the NEXT scnerf_nerf_wgrad records on its
- * stream right before and after its one launch of the eight 256 x 256 GEMMs; cleared after use.  NULLs switch it off. */
-int scnerf_wgrad_profile_events(void* before, void* after);
  /* accumulate != 0: flat_grad += the gradients (autograd's accumulation into an attached flat .grad
  * buffer without 48 separate add kernels); 0: overwrite. */
 int scnerf_nerf_wgrad(int pt_dims, const float* save, const float* grads, const float* d_raw,

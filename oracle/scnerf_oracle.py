@@ -298,6 +298,30 @@ def ortho6d_to_rotation(p6: Tensor) -> Tensor:
     return torch.stack([x, y, z], dim=2)
 
 
+def rotation_to_ortho6d(rot: Tensor) -> Tensor:
+    """[C,3,3] -> [C,6]: the first two COLUMNS of each rotation side by side (model/camera_utils.py:136-137,
+    `rotation2orth`): the inverse of ortho6d_to_rotation on orthonormal input, and how the camera model stores its
+    initial poses (model/camera_model.py:137-141)."""
+    return torch.cat([rot[:, :, 0], rot[:, :, 1]], dim=-1)
+
+
+def camera_state(spec: dict, grad: bool = False, ray_d_from_ray_o: bool = False) -> Dict[str, Tensor]:
+    """The oracle's camera dictionary from a synthetic camera spec (scnerf_amd.synthetic.camera_spec): initial
+    intrinsics [fx, fy, cx, cy], initial extrinsics [6-D rotation | translation] (camera_model.py:130-141) and the
+    learnable residuals (leaves when `grad`).  `ray_d_from_ray_o`: the Distortion model wraps ONE tensor in two
+    Parameters (camera_model.py:224, :257-262) -- same values, two autograd leaves."""
+    poses, K = spec["poses"], spec["K_init"]
+    mk = (lambda x: x.clone().requires_grad_(True)) if grad else (lambda x: x.clone())
+    return {"intrinsics_initial": torch.stack([K[0, 0], K[1, 1], K[0, 2], K[1, 2]]),
+            "extrinsics_initial": torch.cat([rotation_to_ortho6d(poses[:, :3, :3]), poses[:, :3, 3]], -1),
+            "intrinsics_noise": mk(spec["intrinsics_noise"]), "extrinsics_noise": mk(spec["extrinsics_noise"]),
+            "ray_o_noise": mk(spec["ray_o_noise"]),
+            "ray_d_noise": mk(spec["ray_o_noise"] if ray_d_from_ray_o else spec["ray_d_noise"]),
+            "intrinsics_noise_scale": spec["intrinsics_noise_scale"], "extrinsics_noise_scale": spec["extrinsics_noise_scale"],
+            "ray_o_noise_scale": spec["ray_o_noise_scale"], "ray_d_noise_scale": spec["ray_d_noise_scale"],
+            "multiplicative_noise": spec["multiplicative_noise"]}
+
+
 def camera_intrinsic_params(cam: Dict[str, Tensor]) -> Tensor:
     """[fx, fy, cx, cy] after the learnable residual (model/camera_model.py:166-177)."""
     init, noise, s = cam["intrinsics_initial"], cam["intrinsics_noise"], cam["intrinsics_noise_scale"]

@@ -71,23 +71,11 @@ PROTOTYPES = {
     "scnerf_vecmat": [P, P, I, LL, I, P, P, P, P],
     "scnerf_wgrad_arithmetic": [I],
     "scnerf_wgrad256_chunks": [I],
-    "scnerf_wgrad_profile_events": [P, P],
-    "scnerf_pack_split_planes": [I, P, P, P],
-    "scnerf_mlp_fwd_split": [I, P, P, I, I, P, P, P, P, P, LL, P],
-    "scnerf_mlp_fwd_stage": [I, I, P, P, I, I, P, P, P, LL, P],
-    "scnerf_mlp_bwd_stage": [I, I, P, P, P, I, I, P, P, P, P, P, LL, P],
-    "scnerf_layer_split_bwd": [I, I, P, P, P, P, P, P, LL, P],
-    "scnerf_layer_split_chain_fwd": [I, P, P, P, P, LL, P],
-    "scnerf_layer_split_chain_bwd": [I, P, P, P, P, P, P, LL, P],
-    "scnerf_layer_split_workgroups": [I],
-    "scnerf_mlp_bwd_split": [I, P, P, P, I, I, P, P, P, P, P, P, P, LL, P],
-    "scnerf_coarse_stage_fwd_split": [P, I, P, P, I, P, P, P, P, I, P, P, P, P, P, P, P, P, P, I, I, P],
-    "scnerf_layer_split": [I, I, P, P, P, P, P, P, LL, P],
     "scnerf_h3_pack": [P, P, P, P, LL, P, P, LL, P, P, P, P],
     "scnerf_mlp_fwd_h3": [I, P, P, I, I, P, P, P, P, P, LL, P, I, LL, P],
     "scnerf_mlp_bwd_h3": [I, P, P, P, I, I, P, P, P, P, P, P, P, LL, P, I, LL, P],
     "scnerf_coarse_stage_fwd_h3": [P, I, P, P, I, P, P, P, P, P, I, P, P, P, P, P, P, P, P, I, I, P, I, LL, P],
-    "scnerf_nerf_wgrad_h3": [I, P, P, P, LL, I, P, P, I, P, P, P, P],
+    "scnerf_nerf_wgrad_h3": [I, P, P, P, LL, I, P, P, I, P, P, P, P, P, P],
     "scnerf_wgrad256_half": [P, P, LL, I, P, P, P, P, P, P],
     "scnerf_wgrad_half_narrow": [P, I, P, I, I, I, LL, I, P, P, P, P, P, I, LL, P],
 }
@@ -97,8 +85,6 @@ PROTOTYPES = {
 SIZE_FUNCS = {"scnerf_mlp_save_floats": [I, LL], "scnerf_mlp_grad_floats": [LL],
               "scnerf_wgrad_workspace_floats": [I, I, I],
               "scnerf_nerf_wgrad_workspace_floats": [I],
-              "scnerf_split_planes_shorts": [I],
-              "scnerf_layer_amax_floats": [LL],
               "scnerf_h3_scale_floats": [],
               "scnerf_wgrad_chunk_samples": [LL, I],
               "scnerf_camera_bwd_workspace_floats": [I]}
@@ -134,7 +120,7 @@ def load() -> ctypes.CDLL:
                 "libscnerf_hip.so is not built (%s). Run `python -m scnerf_amd.csrc.build` "
                 "(or __graft_entry__.build()); scnerf_amd has no CPU fallback." % LIB_PATH)
         _lib = bind(ctypes.CDLL(LIB_PATH))
-        if _lib.scnerf_abi_version() != 2:
+        if _lib.scnerf_abi_version() != 3:
             raise ScnerfLibraryError("ABI version mismatch")
     return _lib
 

@@ -15,7 +15,6 @@
 #include <scn_wave.h>
 
 #include "launch.h"
-#include "layer_split_api.h"
 #include "mlp_common.h"
 #include "scnerf_hip.h"
 
@@ -80,11 +79,7 @@ __device__ __forceinline__ void pe_backward(float x, float y, float z, float w, 
     }
 }
 
-// STAGE: 0 = the whole chain; 1 = the heads only (rgb^T, views^T: d feature and dZ of the views layer go to the
-// workspace, d viewdirs is final); 2 = the encoded-point end only (the skip columns of layer 5 and layer 0 on the
-// dZ_5 / dZ_0 found in the workspace, then the encoding's gradient -> d pts).  1 and 2 bracket the per-layer
-// split-arithmetic GEMMs of layer_split.h.
-template <int PD, int STAGE = 0>
+template <int PD>
 __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
     const float* __restrict__ d_raw, const float* __restrict__ pts, const float* __restrict__ viewdirs,
     int vd_stride, int samples_per_ray, const float* __restrict__ wbk, const float* __restrict__ save,
@@ -101,39 +96,10 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
 
     WStream ws;
     // stream order: rgb^T, views^T (8 tiles), its encoded-direction tile, feature^T, 7, 6, 5 main, 5 skip, 4 .. 1, 0
-    constexpr int kSkipStream = 1024 + 64 * 9 * 64 + 4 * 65536;
-    constexpr int kLayer0Stream = V::kBwdStream - 128 * ET * 64;
     float dz[128];
     float de[ES];
 #pragma unroll
     for (int s = 0; s < ES; ++s) de[s] = 0.f;
-    auto load_section = [&](int offset) {               // dz <- this wave tile of a width-256 gradient section
-        const float* tile = tile_ptr(grads + (long)offset * Ppad, wave_tile, 256, lane);
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(tile + (t * 4 + q) * 256);
-                dz[16 * t + 4 * q + 0] = v[0]; dz[16 * t + 4 * q + 1] = v[1];
-                dz[16 * t + 4 * q + 2] = v[2]; dz[16 * t + 4 * q + 3] = v[3];
-            }
-    };
-    if constexpr (STAGE == 2) {
-        ws.g = reinterpret_cast<const f32x4*>(wbk + kSkipStream);
-        stream_prime<8>(ws);
-        load_section(kGradDz + 5 * 256);
-        f32x16 acce[ET];
-        zero_acc<ET>(acce);
-        mfma_part<128, ET, ECS, 0>(dz, acce, ws);
-#pragma unroll
-        for (int t = 0; t < ES / 16; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) de[16 * t + r] = acce[t][r];
-        block_sync();                                   // every wave is done with the LDS chunks of the skip part
-        ws.g = reinterpret_cast<const f32x4*>(wbk + kLayer0Stream);
-        stream_prime<8>(ws);
-        load_section(kGradDz);
-    } else {
     ws.g = reinterpret_cast<const f32x4*>(wbk);
     stream_prime<1>(ws);           // RGBT: 4 tiles x 4 steps = 1024 floats
 
@@ -158,7 +124,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
     mfma_part<64, 8, 16, 4>(dzv, acc, ws, tile_ptr(grads + (long)kGradDzv * Ppad, wave_tile, 128, lane));
     f32x16 acce1[1];
     zero_acc<1>(acce1);
-    mfma_part<64, 1, 64, STAGE == 1 ? 0 : 8>(dzv, acce1, ws);
+    mfma_part<64, 1, 64, 8>(dzv, acce1, ws);
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -176,10 +142,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
             d_views[p * 3 + 1] = oxy;
             d_views[p * 3 + 2] = gz + oz;
         }
-    }
-    if constexpr (STAGE == 1) {
-        store_tiles<0, 8, 128>(dz, tile_ptr(grads + (long)kGradDfeat * Ppad, wave_tile, 256, lane));
-        return;
     }
 
     // ---- feature_linear^T + alpha_linear^T : d h8 = W_f^T d feature + w_alpha d sigma -----
@@ -215,14 +177,12 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
         }
         mask_to_regs<8>(acc, load_mask<PD>(save, P, l - 1, wave_tile, lane), dz);
     }
-    }
 
     // ---- layer 0^T : d encoded point, then the encoding's own gradient -> d pts ------------
     {
         f32x16 acce[ET];
         zero_acc<ET>(acce);
-        mfma_part<128, ET, ECS, 0>(dz, acce, ws,
-                                   STAGE == 2 ? nullptr : tile_ptr(grads + (long)kGradDz * Ppad, wave_tile, 256, lane));
+        mfma_part<128, ET, ECS, 0>(dz, acce, ws, tile_ptr(grads + (long)kGradDz * Ppad, wave_tile, 256, lane));
 #pragma unroll
         for (int t = 0; t < ES / 16; ++t)
 #pragma unroll
@@ -246,28 +206,16 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_kernel(
 
 }  // namespace
 
-template <int PD, int STAGE>
+template <int PD>
 static int launch_bwd(const float* d_raw, const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
                       const float* wpacked_bwd, const float* save, float* grads, float* d_pts, float* d_views,
                       long long n_samples, hipStream_t st) {
     const size_t lds = (size_t)kStreamBufs * kMaxChunkBwd * sizeof(float);      // 96 KB: needs the opt-in
-    SCN_LDS_OPT_IN((mlp_bwd_kernel<PD, STAGE>), lds);
-    hipLaunchKernelGGL((mlp_bwd_kernel<PD, STAGE>), dim3(scn_ceil_div(n_samples, kSamplesPerBlock)), dim3(kThreads), lds, st,
+    SCN_LDS_OPT_IN((mlp_bwd_kernel<PD>), lds);
+    hipLaunchKernelGGL((mlp_bwd_kernel<PD>), dim3(scn_ceil_div(n_samples, kSamplesPerBlock)), dim3(kThreads), lds, st,
                        d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views,
                        (long)n_samples);
     return scn_launch_status();
-}
-
-template <int PD>
-static int bwd_split(const float* d_raw, const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
-                     const float* wpacked_bwd, const short* planes, const float* save, float* grads, float* d_pts,
-                     float* d_views, float* amax, long long n_samples, hipStream_t st) {
-    const long P = (long)n_samples;
-    int rc = launch_bwd<PD, 1>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st);
-    if (rc) return rc;
-    rc = scn::lsp::launch_network_chain_bwd<PD>(planes, wpacked_bwd, save, grads, d_raw, amax, P, st);
-    if (rc) return rc;
-    return launch_bwd<PD, 2>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st);
 }
 
 extern "C" int scnerf_mlp_bwd(int pt_dims, const float* d_raw, const float* pts, const float* viewdirs,
@@ -278,34 +226,6 @@ extern "C" int scnerf_mlp_bwd(int pt_dims, const float* d_raw, const float* pts,
     SCN_RETURN_IF(samples_per_ray < 1 || vd_stride < 3 || n_samples < 0 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
     if (n_samples == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    return pt_dims == 3 ? launch_bwd<3, 0>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st)
-                        : launch_bwd<4, 0>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st);
-}
-
-// The pieces of scnerf_mlp_bwd_split one by one (for per-kernel timing: bench.py): stage 1 = heads, 2 = the
-// encoded-point end; the transposed layer GEMMs in between are scnerf_layer_split_bwd.
-extern "C" int scnerf_mlp_bwd_stage(int pt_dims, int stage, const float* d_raw, const float* pts, const float* viewdirs,
-                                    int vd_stride, int samples_per_ray, const float* wpacked_bwd, const float* save,
-                                    float* grads, float* d_pts, float* d_views, long long n_samples, void* stream) {
-    SCN_RETURN_IF(!d_raw || !pts || !viewdirs || !wpacked_bwd || !save || !grads || !d_pts || !d_views, SCN_EINVAL);
-    SCN_RETURN_IF((stage != 1 && stage != 2) || samples_per_ray < 1 || vd_stride < 3 || n_samples < 0 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
-    if (n_samples == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    if (pt_dims == 3)
-        return stage == 1 ? launch_bwd<3, 1>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st)
-                          : launch_bwd<3, 2>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st);
-    return stage == 1 ? launch_bwd<4, 1>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st)
-                      : launch_bwd<4, 2>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st);
-}
-
-extern "C" int scnerf_mlp_bwd_split(int pt_dims, const float* d_raw, const float* pts, const float* viewdirs,
-                                    int vd_stride, int samples_per_ray, const float* wpacked_bwd, const short* planes,
-                                    const float* save, float* grads, float* d_pts, float* d_views, float* amax,
-                                    long long n_samples, void* stream) {
-    SCN_RETURN_IF(!d_raw || !pts || !viewdirs || !wpacked_bwd || !planes || !save || !grads || !d_pts || !d_views, SCN_EINVAL);
-    SCN_RETURN_IF(samples_per_ray < 1 || vd_stride < 3 || n_samples < 0 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
-    if (n_samples == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    return pt_dims == 3 ? bwd_split<3>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, planes, save, grads, d_pts, d_views, amax, n_samples, st)
-                        : bwd_split<4>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, planes, save, grads, d_pts, d_views, amax, n_samples, st);
+    return pt_dims == 3 ? launch_bwd<3>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st)
+                        : launch_bwd<4>(d_raw, pts, viewdirs, vd_stride, samples_per_ray, wpacked_bwd, save, grads, d_pts, d_views, n_samples, st);
 }

@@ -74,14 +74,12 @@ struct BwdEpi : std::conditional_t<KIND == 1, Rank1, NoRank1>, std::conditional_
         constexpr int x = PIECE >> 2, q = PIECE & 3, T = 2 * P + x;
         constexpr int sl = 2 * T + (q >> 1), c0 = 2 * (q & 1);
         static_assert(sl < NS, "operand buffer too small for this tile");
-#ifdef SCN_H3_NO_EPI                // (timing experiment: the epilogue reduced to moving the accumulators into the planes)
-        if constexpr (SUB == 1) {
-            oh[sl][c0] = __float_as_uint(acc[x][4 * q]) & 0x3bff3bffu; oh[sl][c0 + 1] = __float_as_uint(acc[x][4 * q + 1]) & 0x3bff3bffu;
-            ol[sl][c0] = __float_as_uint(acc[x][4 * q + 2]) & 0x3bff3bffu; ol[sl][c0 + 1] = __float_as_uint(acc[x][4 * q + 3]) & 0x3bff3bffu;
-        }
-        return;
-#endif
-        if constexpr (SUB == 0) {
+        if constexpr (lab::kNoEpilogue) {
+            if constexpr (SUB == 1) {
+                oh[sl][c0] = __float_as_uint(acc[x][4 * q]) & 0x3bff3bffu; oh[sl][c0 + 1] = __float_as_uint(acc[x][4 * q + 1]) & 0x3bff3bffu;
+                ol[sl][c0] = __float_as_uint(acc[x][4 * q + 2]) & 0x3bff3bffu; ol[sl][c0 + 1] = __float_as_uint(acc[x][4 * q + 3]) & 0x3bff3bffu;
+            }
+        } else if constexpr (SUB == 0) {
         } else if constexpr (SUB <= 4) {
             constexpr int e = SUB - 1;
             float d = acc[x][4 * q + e] * os;
@@ -110,9 +108,8 @@ struct BwdEpi : std::conditional_t<KIND == 1, Rank1, NoRank1>, std::conditional_
             oh[sl][c0 + 1] = hp;
             ol[sl][c0 + 1] = pack_f16(residual_f16<0>(v[2], s_next, hp), residual_f16<1>(v[3], s_next, hp));
         } else if constexpr (SUB == 10) {
-#ifndef SCN_H3_NO_STORE             // (timing experiment)
-            store_stream_at(uniform_global_rw(save + (4 * T + q) * 1024), pinned_here(lane16), f32x4{v[0], v[1], v[2], v[3]});
-#endif
+            if constexpr (!lab::kNoStore)
+                store_stream_at(uniform_global_rw(save + (4 * T + q) * 1024), pinned_here(lane16), f32x4{v[0], v[1], v[2], v[3]});
         }
     }
 };

@@ -192,15 +192,10 @@ __device__ __forceinline__ void store_ws(f32x4* p, f32x4 v) {
 template <int N_F4>
 __device__ __forceinline__ void stream_issue(const WStream& ws, f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1]) {
     const int tid = threadIdx.x;
-#ifndef SCN_ABLATE_NO_STREAM       // (timing experiments only)
     // (scalar-base addressing of these loads -- readfirstlane'd base + 32-bit lane offset -- removes the
     // 64-bit VALU address adds but measured 1.5 % slower; plain pointer arithmetic kept)
 #pragma unroll
     for (int i = 0; i < N_F4; ++i) stage[i] = ws.g[i * kThreads + tid];
-#else
-#pragma unroll
-    for (int i = 0; i < N_F4; ++i) stage[i] = f32x4{1.f, 2.f, 3.f, (float)tid};
-#endif
 }
 
 template <int N_F4>
@@ -238,11 +233,7 @@ struct Spread {
 
 template <int N_F4>
 __device__ __forceinline__ void stream_issue_piece(const WStream& ws, f32x4 (&stage)[N_F4 > 0 ? N_F4 : 1], int i) {
-#ifndef SCN_ABLATE_NO_STREAM
     stage[i] = ws.g[i * kThreads + threadIdx.x];
-#else
-    stage[i] = f32x4{1.f, 2.f, 3.f, (float)threadIdx.x};
-#endif
 }
 
 template <int N_F4>
@@ -254,9 +245,6 @@ __device__ __forceinline__ void stream_commit_piece(const WStream& ws, const f32
 // store k (= (t - T0) * 4 + q) of store_tiles<T0, T1>
 template <int T0, int N>
 __device__ __forceinline__ void store_tile_piece(const float (&regs)[N], float* tile, int k) {
-#ifdef SCN_ABLATE_NO_ROWSTORE
-    return;
-#endif
     if (tile == nullptr) return;
     const int t = T0 + k / 4, q = k % 4;
     f32x4 v = {regs[16 * t + 4 * q + 0], regs[16 * t + 4 * q + 1], regs[16 * t + 4 * q + 2], regs[16 * t + 4 * q + 3]};
@@ -300,9 +288,6 @@ __device__ __forceinline__ void stream_prime(WStream& ws) {
 // when nothing is saved).  Lanes without a sample store too (their slot exists; values are finite).
 template <int T0, int T1, int N>
 __device__ __forceinline__ void store_tiles(const float (&regs)[N], float* tile) {
-#ifdef SCN_ABLATE_NO_ROWSTORE      // (timing experiments only)
-    return;
-#endif
     if (tile == nullptr) return;
 #pragma unroll
     for (int t = T0; t < T1; ++t)
@@ -364,9 +349,7 @@ __device__ __forceinline__ void mfma_chunk(const float (&b)[NSTEP], f32x16 (&acc
             spread_bundle<NB, N_F4, NSTEP, T0, T1>(p, ws, stage, b, save_tile);
             if (!SPREAD && p == COMMIT_AT) stream_commit<N_F4>(ws, stage);
             if (p == SYNC_AT) {
-#ifndef SCN_ABLATE_NO_BARRIER      // (timing experiments only: tools/ablate.sh)
                 block_sync();
-#endif
             }
             if (p + 1 < NB) {
 #pragma unroll
@@ -401,9 +384,7 @@ __device__ __forceinline__ void mfma_chunk(const float (&b)[NSTEP], f32x16 (&acc
         for (int f = 0; f < NF; ++f) {
             if (f == COMMIT_AT) stream_commit<N_F4>(ws, stage);
             if (f == SYNC_AT) {
-#ifndef SCN_ABLATE_NO_BARRIER
                 block_sync();
-#endif
             }
             if (f + 2 < NF) r3[(f + 2) % 3] = A[(((f + 2) % NT) * G + (f + 2) / NT) * 64];
             sched_fence();
@@ -449,9 +430,7 @@ struct LastChunk {
         spread_bundle<NQ, N_F4, NSTEP, T0, T1>(Q, ws, stage, b, save_tile);
         if constexpr (!SPREAD && Q == NQ / 2) stream_commit<N_F4>(ws, stage);
         if constexpr (Q == (NQ * 3) / 4) {
-#ifndef SCN_ABLATE_NO_BARRIER
             block_sync();
-#endif
         }
         if constexpr (Q + 1 < NQ) {
             constexpr int P1 = (Q + 1) / G, g1 = (Q + 1) % G;
@@ -609,10 +588,8 @@ __host__ __device__ inline long padded_samples(long P) {
 template <int N>
 __device__ __forceinline__ u32x4 relu_bits(const float (&v)[N]) {
     u32x4 bits = {0u, 0u, 0u, 0u};
-#ifndef SCN_ABLATE_NO_MASK         // (timing experiments only)
 #pragma unroll
     for (int i = 0; i < N; ++i) bits[i >> 5] = shift_in_positive(bits[i >> 5], v[i]);
-#endif
     return bits;
 }
 

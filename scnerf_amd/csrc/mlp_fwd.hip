@@ -13,7 +13,6 @@
 #include <scn_wave.h>
 
 #include "launch.h"
-#include "layer_split_api.h"
 #include "mlp_common.h"
 #include "ray_stage.h"
 #include "scnerf_hip.h"
@@ -105,10 +104,7 @@ constexpr int kCoarseSamples = 64;
 
 // TRAIN: also leave the activations / encodings / ReLU masks in `save` for the dgrad and wgrad kernels
 // COARSE: points come from `cs` (PD == 3, 64 samples per ray), `pts` is unused
-// STAGE: 0 = the whole network; 1 = encoding + layer 0 only (its activations go to the workspace); 2 = the heads
-// only (density, views layer, rgb; compositing if COARSE) on the layer-7 activations and features found in the
-// workspace.  1 and 2 bracket the per-layer split-arithmetic GEMMs of layer_split.h (TRAIN only).
-template <int PD, bool TRAIN, bool COARSE = false, int STAGE = 0>
+template <int PD, bool TRAIN, bool COARSE = false>
 __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     const float* __restrict__ pts, const float* __restrict__ viewdirs, int vd_stride, int samples_per_ray,
     const float* __restrict__ wpk, float* __restrict__ raw, float* __restrict__ save_arg, long P, CoarseStage cs) {
@@ -123,12 +119,10 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     using V = Var<PD>;
     constexpr int ES = V::kES;
 
-    static_assert(STAGE == 0 || TRAIN, "the staged forward runs through the activation workspace");
     WStream ws;
     // stream order: E0, layers 1-4, skip part, layer 5 main, 6, 7, feature, views, view encoding, rgb
-    constexpr int kHeadStream = 2 * ES * 8 * 64 + 8 * 65536;
-    ws.g = reinterpret_cast<const f32x4*>(wpk + (STAGE == 2 ? kHeadStream : 0));
-    stream_prime<8>(ws);   // first chunk of E0 (8 tiles x 16 steps) / of the views layer (4 tiles x 32 steps)
+    ws.g = reinterpret_cast<const f32x4*>(wpk);
+    stream_prime<8>(ws);   // first chunk of E0 (8 tiles x 16 steps)
 
     float px = 0.f, py = 0.f, pz = 0.f, pw = 0.f;
     auto coarse_depth_of_sample = [&]() {          // this lane's stratified depth (COARSE only; cheap to redo)
@@ -143,11 +137,11 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
         px = r[0] + r[3] * z;
         py = r[1] + r[4] * z;
         pz = r[2] + r[5] * z;
-        if (live && h == 0 && STAGE != 2) {
+        if (live && h == 0) {
             cs.z[p] = z;
             cs.pts[p * 3 + 0] = px; cs.pts[p * 3 + 1] = py; cs.pts[p * 3 + 2] = pz;
         }
-    } else if constexpr (STAGE != 2) {
+    } else {
         px = pts[pc * PD + 0]; py = pts[pc * PD + 1]; pz = pts[pc * PD + 2];
         if constexpr (PD == 4) pw = pts[pc * PD + (PD - 1)];
     }
@@ -171,18 +165,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
                 for (int j = 0; j < 4; ++j) sigma_part = fmaf(w[j], hreg[16 * t + 4 * q + j], sigma_part);
             }
     };
-    auto load_section = [&](int offset) {               // hreg <- this wave tile of a width-256 workspace section
-        const float* tile = tile_ptr(save + (long)offset * Ppad, wave_tile, 256, lane);
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(tile + (t * 4 + q) * 256);
-                hreg[16 * t + 4 * q + 0] = v[0]; hreg[16 * t + 4 * q + 1] = v[1];
-                hreg[16 * t + 4 * q + 2] = v[2]; hreg[16 * t + 4 * q + 3] = v[3];
-            }
-    };
-    if constexpr (STAGE != 2) {
+    {
         float e[ES];
         pe_slots<PD, 10, ES>(px, py, pz, pw, h, e);
         if (save) store_pe<PD, 10, ES>(e, save + (long)kSaveEpts * Ppad, pc, V::kEW, h, live);
@@ -192,27 +175,18 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
             park[g * kThreads] = v;
         }
         init_bias<8>(acc, wpk + V::kFwdBias, h);
-        mfma_part<ES, 8, 16, STAGE == 1 ? 0 : 8>(e, acc, ws);
+        mfma_part<ES, 8, 16, 8>(e, acc, ws);
         relu_to_regs<128>(acc, hreg, true);
         if (save) *reinterpret_cast<u32x4*>(mask_ptr<PD>(save, P, 0, wave_tile, lane)) = relu_bits<128>(hreg);
-        if constexpr (STAGE == 1) {
-            store_tiles<0, 8, 128>(hreg, tile_ptr(save + (long)kSaveAct * Ppad, wave_tile, 256, lane));
-            return;
-        }
     }
 
     // trunk layers 1..7 and the (linear) feature layer as l == 8.  In training mode the output of
     // layer l-1 (the B operand of layer l's main part) is written to HBM chunk by chunk during layer l.
     // Each layer's epilogue (ReLU -> next B operands, mask bits, next layer's bias) is folded into its last
     // chunk (FwdEpi / LastChunk), so the accumulators arrive here already holding the bias of layer l.
-    if constexpr (STAGE == 2) {
-        load_section(kSaveAct + 256 * 7);
-        density_head();
-        load_section(kSaveFeat);
-    }
-    if constexpr (STAGE == 0) init_bias<8>(acc, wpk + V::kFwdBias + 256, h);
+    init_bias<8>(acc, wpk + V::kFwdBias + 256, h);
 #pragma unroll 1
-    for (int l = 1; l <= (STAGE == 0 ? 8 : 0); ++l) {
+    for (int l = 1; l <= 8; ++l) {
         if (l == 5) {
             float e[ES];
 #pragma unroll
@@ -244,7 +218,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(
     f32x16 accv[4];
     init_bias<4>(accv, wpk + V::kFwdBiasV, h);
     mfma_part<128, 4, 32, 4>(hreg, accv, ws,             // then VE: 4 tiles x 16 steps = 4 f4
-                             TRAIN && STAGE == 0 ? tile_ptr(save + (long)kSaveFeat * Ppad, wave_tile, 256, lane) : nullptr);
+                             TRAIN ? tile_ptr(save + (long)kSaveFeat * Ppad, wave_tile, 256, lane) : nullptr);
     mfma_part<16, 4, 16, 4>(ev, accv, ws);               // then RGB: 1 tile x 64 steps = 4 f4
     float hv[64];
     relu_to_regs<64>(accv, hv, true);
@@ -328,41 +302,25 @@ extern "C" long long scnerf_mlp_grad_floats(long long n_samples) {
     return (long long)kGradPerSample * padded_samples(n_samples);
 }
 
-template <int PD, bool TRAIN, int STAGE = 0>
+template <int PD, bool TRAIN>
 static int launch_fwd(const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray,
                       const float* wpacked, float* raw, float* save, long long n_samples, hipStream_t st) {
     // weights (3 x 32 KB) + the parked encoding of the 256 threads
     const size_t lds = (size_t)(kStreamBufs * kMaxChunkFwd + Var<PD>::kES * kThreads) * sizeof(float);
-    SCN_LDS_OPT_IN((mlp_fwd_kernel<PD, TRAIN, false, STAGE>), lds);
-    hipLaunchKernelGGL((mlp_fwd_kernel<PD, TRAIN, false, STAGE>), dim3(scn_ceil_div(n_samples, kSamplesPerBlock)), dim3(kThreads), lds,
+    SCN_LDS_OPT_IN((mlp_fwd_kernel<PD, TRAIN, false>), lds);
+    hipLaunchKernelGGL((mlp_fwd_kernel<PD, TRAIN, false>), dim3(scn_ceil_div(n_samples, kSamplesPerBlock)), dim3(kThreads), lds,
                        st, pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, (long)n_samples, CoarseStage{});
     return scn_launch_status();
 }
 
-template <bool TRAIN, int STAGE = 0>
+template <bool TRAIN>
 static int launch_coarse_stage(const CoarseStage& cs, const float* wpacked, float* raw, float* save, hipStream_t st) {
     const size_t lds = (size_t)(kStreamBufs * kMaxChunkFwd + Var<3>::kES * kThreads) * sizeof(float);
     const long P = (long)cs.n_rays * kCoarseSamples;
-    SCN_LDS_OPT_IN((mlp_fwd_kernel<3, TRAIN, true, STAGE>), lds);
-    hipLaunchKernelGGL((mlp_fwd_kernel<3, TRAIN, true, STAGE>), dim3(scn_ceil_div(P, kSamplesPerBlock)), dim3(kThreads), lds, st,
+    SCN_LDS_OPT_IN((mlp_fwd_kernel<3, TRAIN, true>), lds);
+    hipLaunchKernelGGL((mlp_fwd_kernel<3, TRAIN, true>), dim3(scn_ceil_div(P, kSamplesPerBlock)), dim3(kThreads), lds, st,
                        (const float*)nullptr, cs.rays + 8, cs.ray_stride, kCoarseSamples, wpacked, raw, save, P, cs);
     return scn_launch_status();
-}
-
-// layers 1 .. 7 and feature_linear as split-arithmetic GEMMs between the two stages of the fused kernel
-template <int PD>
-static int trunk_layers_split(const float* wpacked, const short* planes, float* save, float* amax, long P, hipStream_t st) {
-    return scn::lsp::launch_network_chain_fwd<PD>(planes, wpacked, save, amax, P, st);
-}
-
-template <int PD>
-static int fwd_split(const float* pts, const float* viewdirs, int vd_stride, int samples_per_ray, const float* wpacked,
-                     const short* planes, float* raw, float* save, float* amax, long long n_samples, hipStream_t st) {
-    int rc = launch_fwd<PD, true, 1>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, n_samples, st);
-    if (rc) return rc;
-    rc = trunk_layers_split<PD>(wpacked, planes, save, amax, (long)n_samples, st);
-    if (rc) return rc;
-    return launch_fwd<PD, true, 2>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, n_samples, st);
 }
 
 extern "C" int scnerf_coarse_stage_fwd(const float* rays, int ray_stride, const float* t_vals, const float* t_rand,
@@ -378,52 +336,6 @@ extern "C" int scnerf_coarse_stage_fwd(const float* rays, int ray_stride, const 
                          rgb_map, disp_map, acc_map, depth_map, weights};
     hipStream_t st = (hipStream_t)stream;
     return save ? launch_coarse_stage<true>(cs, wpacked, raw, save, st) : launch_coarse_stage<false>(cs, wpacked, raw, save, st);
-}
-
-extern "C" int scnerf_coarse_stage_fwd_split(const float* rays, int ray_stride, const float* t_vals, const float* t_rand,
-                                             int lindisp, const float* wpacked, const short* planes, float* save,
-                                             const float* noise, int white_bkgd, float* z, float* pts, float* raw,
-                                             float* rgb_map, float* disp_map, float* acc_map, float* depth_map,
-                                             float* weights, float* amax, int n_rays, int n_samples, void* stream) {
-    SCN_RETURN_IF(!rays || !t_vals || !wpacked || !planes || !save || !z || !pts || !raw || !rgb_map || !disp_map || !acc_map, SCN_EINVAL);
-    SCN_RETURN_IF(n_rays < 0 || ray_stride < 11, SCN_EINVAL);
-    SCN_RETURN_IF(n_samples != kCoarseSamples, SCN_ENOSUP);
-    if (n_rays == 0) return 0;
-    const CoarseStage cs{rays, ray_stride, n_rays, t_vals, t_rand, lindisp, z, pts, noise, white_bkgd,
-                         rgb_map, disp_map, acc_map, depth_map, weights};
-    hipStream_t st = (hipStream_t)stream;
-    int rc = launch_coarse_stage<true, 1>(cs, wpacked, raw, save, st);
-    if (rc) return rc;
-    rc = trunk_layers_split<3>(wpacked, planes, save, amax, (long)n_rays * kCoarseSamples, st);
-    if (rc) return rc;
-    return launch_coarse_stage<true, 2>(cs, wpacked, raw, save, st);
-}
-
-// The pieces of scnerf_mlp_fwd_split one by one (for per-kernel timing: bench.py): stage 1 = encoding + layer 0,
-// 2 = heads; the layer GEMMs in between are scnerf_layer_split.
-extern "C" int scnerf_mlp_fwd_stage(int pt_dims, int stage, const float* pts, const float* viewdirs, int vd_stride,
-                                    int samples_per_ray, const float* wpacked, float* raw, float* save,
-                                    long long n_samples, void* stream) {
-    SCN_RETURN_IF(!pts || !viewdirs || !wpacked || !raw || !save || (stage != 1 && stage != 2), SCN_EINVAL);
-    SCN_RETURN_IF(samples_per_ray < 1 || vd_stride < 3 || n_samples < 0 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
-    if (n_samples == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    if (pt_dims == 3)
-        return stage == 1 ? launch_fwd<3, true, 1>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, n_samples, st)
-                          : launch_fwd<3, true, 2>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, n_samples, st);
-    return stage == 1 ? launch_fwd<4, true, 1>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, n_samples, st)
-                      : launch_fwd<4, true, 2>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, raw, save, n_samples, st);
-}
-
-extern "C" int scnerf_mlp_fwd_split(int pt_dims, const float* pts, const float* viewdirs, int vd_stride,
-                                    int samples_per_ray, const float* wpacked, const short* planes, float* raw,
-                                    float* save, float* amax, long long n_samples, void* stream) {
-    SCN_RETURN_IF(!pts || !viewdirs || !wpacked || !planes || !raw || !save, SCN_EINVAL);
-    SCN_RETURN_IF(samples_per_ray < 1 || vd_stride < 3 || n_samples < 0 || (pt_dims != 3 && pt_dims != 4), SCN_EINVAL);
-    if (n_samples == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    return pt_dims == 3 ? fwd_split<3>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, planes, raw, save, amax, n_samples, st)
-                        : fwd_split<4>(pts, viewdirs, vd_stride, samples_per_ray, wpacked, planes, raw, save, amax, n_samples, st);
 }
 
 extern "C" int scnerf_mlp_fwd(int pt_dims, const float* pts, const float* viewdirs, int vd_stride,

@@ -19,10 +19,7 @@ using namespace scn::h3;
 // encodings are saved in torch column order so the wgrad GEMM writes weight columns directly (as mlp_fwd.hip)
 template <int PD, int L, int NS>
 __device__ __forceinline__ void store_pe_rows(const float (&e)[NS], float* __restrict__ base, long p, int ld, int h, bool live) {
-#ifdef SCN_H3_NO_PESTORE            // (timing experiment)
-    return;
-#endif
-    if (!live) return;
+    if (lab::kNoPeStore || !live) return;
     float* row = base + p * ld;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -63,14 +60,12 @@ struct FwdEpi : std::conditional_t<KIND == 1, Density, NoDensity>, MaskBits<TRAI
         constexpr int x = PIECE >> 2, q = PIECE & 3, T = 2 * P + x;
         constexpr int sl = 2 * T + (q >> 1), c0 = 2 * (q & 1);
         static_assert(sl < NS, "operand buffer too small for this tile");
-#ifdef SCN_H3_NO_EPI                // (timing experiment: the epilogue reduced to moving the accumulators into the planes)
-        if constexpr (SUB == 1) {
-            oh[sl][c0] = __float_as_uint(acc[x][4 * q]) & 0x3bff3bffu; oh[sl][c0 + 1] = __float_as_uint(acc[x][4 * q + 1]) & 0x3bff3bffu;
-            ol[sl][c0] = __float_as_uint(acc[x][4 * q + 2]) & 0x3bff3bffu; ol[sl][c0 + 1] = __float_as_uint(acc[x][4 * q + 3]) & 0x3bff3bffu;
-        }
-        return;
-#endif
-        if constexpr (SUB == 0) {
+        if constexpr (lab::kNoEpilogue) {
+            if constexpr (SUB == 1) {
+                oh[sl][c0] = __float_as_uint(acc[x][4 * q]) & 0x3bff3bffu; oh[sl][c0 + 1] = __float_as_uint(acc[x][4 * q + 1]) & 0x3bff3bffu;
+                ol[sl][c0] = __float_as_uint(acc[x][4 * q + 2]) & 0x3bff3bffu; ol[sl][c0 + 1] = __float_as_uint(acc[x][4 * q + 3]) & 0x3bff3bffu;
+            }
+        } else if constexpr (SUB == 0) {
             bq = *reinterpret_cast<const f32x4*>(bias + (4 * T + q) * 8);
             if constexpr (KIND == 1) this->wq = *reinterpret_cast<const f32x4*>(this->alpha + (4 * T + q) * 8);
             if constexpr (TRAIN && KIND != 2 && PIECE == 0) { this->bits0 = 0u; this->bits1 = 0u; }
@@ -96,12 +91,10 @@ struct FwdEpi : std::conditional_t<KIND == 1, Density, NoDensity>, MaskBits<TRAI
             oh[sl][c0 + 1] = hp;
             ol[sl][c0 + 1] = pack_f16(residual_f16<0>(v[2], s_next, hp), residual_f16<1>(v[3], s_next, hp));
         } else if constexpr (SUB == 10) {
-            if constexpr (TRAIN) {
-#ifndef SCN_H3_NO_STORE             // (timing experiment)
+            if constexpr (TRAIN && !lab::kNoStore) {
                 // (wave-uniform base + the lane's 32-bit offset: as 64-bit per-lane pointers the eight piece bases of a
                 //  layer are hoisted into sixteen long-lived registers)
                 store_stream_at(uniform_global_rw(save + (4 * T + q) * 1024), pinned_here(lane16), f32x4{v[0], v[1], v[2], v[3]});
-#endif
             }
         } else {
             if constexpr (KIND == 1) {
@@ -190,12 +183,12 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
     u32x4 eh[NE], el[NE];
     {
         float e[ES];
-#ifdef SCN_H3_NO_PE                 // (timing experiment: no sines / cosines)
+        if constexpr (lab::kNoPe) {
 #pragma unroll
-        for (int i = 0; i < ES; ++i) e[i] = px * (float)i + py;
-#else
-        pe_slots<PD, 10, ES>(px, py, pz, pw, h, e);
-#endif
+            for (int i = 0; i < ES; ++i) e[i] = px * (float)i + py;
+        } else {
+            pe_slots<PD, 10, ES>(px, py, pz, pw, h, e);
+        }
         if (save) store_pe_rows<PD, 10, ES>(e, save + (long)kSaveEpts * Ppad, pc, V::kEW, h, live);
 #pragma unroll
         for (int g = 0; g < ES / 4; ++g) park[g * kThreads] = f32x4{e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3]};

@@ -45,6 +45,7 @@
 #include <type_traits>
 #include <utility>
 
+#include <scn_lab.h>
 #include <scn_wave.h>
 
 #include "mlp_common.h"
@@ -117,27 +118,19 @@ __device__ __forceinline__ void stream_prime(Stream& ws, const void* stream, cha
 // LDS in slot 3 i, and the register is refilled right away (slot 3 i + 1) with piece i of the chunk after that -- a load
 // is waited for 47 slots (~1.6 us) after it was issued.  vmcnt counts loads AND stores in issue order: the wait also
 // covers every activation store issued before the load, and those take an HBM write's time to retire (with the loads
-// issued 24 slots ahead the waits cost ~0.4 ms of a 3 ms launch: SCN_H3_LATE_LOADS is that schedule).
+// issued 24 slots ahead the waits cost ~0.4 ms of a 3 ms launch: lab::kLateLoads is that schedule).
 template <int KAPPA>
 __device__ __forceinline__ void stream_slot(Stream& ws, char* lds, unsigned tid16) {
-#ifndef SCN_H3_NO_STREAM            // (timing experiment)
-    if constexpr (KAPPA < 24 && KAPPA % 3 == 0)
+    if constexpr (!lab::kNoStream && KAPPA < 24 && KAPPA % 3 == 0)
         *reinterpret_cast<f32x4*>(lds + ws.next() + (KAPPA / 3) * 4096 + tid16) = ws.stage[KAPPA / 3];
-#endif
-#ifndef SCN_H3_NO_BARRIER           // (timing experiment: racy)
-    if constexpr (KAPPA == 30) block_sync();
-#endif
-#ifndef SCN_H3_NO_STREAM
-#ifdef SCN_H3_LATE_LOADS
-    constexpr int LOAD_PIECE = (KAPPA >= 24 && KAPPA % 3 == 0) ? (KAPPA - 24) / 3 : -1;
-#else
-    constexpr int LOAD_PIECE = (KAPPA < 24 && KAPPA % 3 == 1) ? KAPPA / 3 : -1;
-#endif
+    if constexpr (!lab::kNoBarrier && KAPPA == 30) block_sync();
+    constexpr int LOAD_PIECE = lab::kNoStream ? -1
+                               : lab::kLateLoads ? ((KAPPA >= 24 && KAPPA % 3 == 0) ? (KAPPA - 24) / 3 : -1)
+                                                 : ((KAPPA < 24 && KAPPA % 3 == 1) ? KAPPA / 3 : -1);
     if constexpr (LOAD_PIECE >= 0)
         // (opaque wave-uniform base + the thread's 32-bit offset: `global_load v, v_off, s[base]`; left to itself the
         //  compiler keeps a 64-bit per-lane pointer across the layer loop and spills it)
         ws.stage[LOAD_PIECE] = load_f32x4(uniform_global(ws.g + LOAD_PIECE * 4096), pinned_here(tid16));
-#endif
     if constexpr (KAPPA == 47) {
         ws.cur = ws.next();
         ws.g = uniform_global(ws.g + kChunkBytes);

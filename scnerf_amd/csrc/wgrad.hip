@@ -24,7 +24,6 @@
 #include "wgrad256.h"
 #include "wgrad256_half.h"
 #include "wgrad_half_narrow.h"
-#include "wgrad256_split.h"
 #include "wgrad_tiles.h"
 
 namespace {
@@ -429,26 +428,21 @@ int launch_wgrad(const WgradArgs& a, int G, hipStream_t stream) {
 
 
 
-// How the 256 x 256 GEMMs multiply: 1 = on the bf16 matrix pipe with every fp32 operand cut exactly into
-// three bf16 numbers and six of the nine partial products kept (wgrad256_split.h; error vs fp64 equal to the
-// exact-fp32 MFMA kernel's, ~1.5x faster), 0 = v_mfma_f32_32x32x2_f32 (wgrad256.h).  Process-wide;
-// SCNERF_WGRAD_ARITHMETIC=fp32 | split presets it, scnerf_wgrad_arithmetic() changes it.
+// How the 256 x 256 GEMMs (and the narrow ones with a tile-native dZ) multiply: 1 (default) = on three fp16 products per
+// product with one power-of-two scale per operand and workgroup chunk, wherever the resident kernels left the chunk maxima
+// (wgrad256_half.h, wgrad_half_narrow.h; error vs fp64 equal to the exact-fp32 MFMA kernel's); 0 = v_mfma_f32_32x32x2_f32
+// (wgrad256.h, wgrad_tiles.h: the numerical yardstick, and what runs when no maxima were left).  Process-wide;
+// SCNERF_WGRAD_ARITHMETIC=fp32 | half presets it, scnerf_wgrad_arithmetic() changes it.
 int& wgrad_arithmetic() {
     static int mode = [] {
         const char* e = getenv("SCNERF_WGRAD_ARITHMETIC");
-        return (e && (e[0] == 'f' || e[0] == '0')) ? 0 : (e && (e[0] == 's' || e[0] == '1')) ? 1 : 2;
+        return (e && (e[0] == 'f' || e[0] == '0')) ? 0 : 1;
     }();
     return mode;
 }
 
-// the 256 x 256 tile-native GEMMs of a pass in one launch, grid (chunks, jobs)
+// the 256 x 256 tile-native GEMMs of a pass in one launch on the fp32 MFMA, grid (chunks, jobs)
 int launch_wgrad256(const wg256::Args& a, int G, hipStream_t stream) {
-    if (wgrad_arithmetic() >= 1) {
-        SCN_LDS_OPT_IN((wg256s::wgrad256_split_kernel<0>), wg256s::kLdsBytes);
-        hipLaunchKernelGGL((wg256s::wgrad256_split_kernel<0>), dim3(G, a.n_jobs), dim3(wg256s::kThreads),
-                           wg256s::kLdsBytes, stream, a);
-        return scn_launch_status();
-    }
     constexpr int F = wg256::kSpread;
     SCN_LDS_OPT_IN((wg256::wgrad256_kernel<F>), wg256::kLdsBytes);
     hipLaunchKernelGGL((wg256::wgrad256_kernel<F>), dim3(G, a.n_jobs), dim3(wg256::kThreads), wg256::kLdsBytes, stream, a);
@@ -618,15 +612,14 @@ extern "C" int scnerf_nerf_param_count(int pt_dims) {
 }
 
 namespace {
-// bench.py's per-kernel timing: an event pair recorded around the next launch of the eight 256 x 256 GEMMs
-hipEvent_t g_profile_events[2] = {nullptr, nullptr};
-
 // the GEMM slabs behind the vecmat partials stay 16-byte aligned (the persistent kernel stores them as float4)
 long long vecmat_ws_floats(long long n_chunks) { return (257 * n_chunks + 3) / 4 * 4; }
 
 // amax_x / amax_z (or nullptr): [8][n_chunks] chunk maxima of the X / dZ operands of the eight 256 x 256 GEMMs in the
 // order they are queued below (layers 1 .. 7, feature_linear), left by the resident kernels: with them the eight run
-// on three fp16 products (wgrad256_half.h) unless the arithmetic is switched to fp32 / split
+// on three fp16 products (wgrad256_half.h) unless the arithmetic is switched to fp32.
+// ev_before / ev_after (or nullptr): events recorded around that one launch (bench.py's per-kernel timing) -- arguments
+// of THIS call, so that no exit path can leave them armed for a later one.
 // The eight 256 x 256 GEMMs of a pass are ONE launch of (chunks, 8) workgroups, one per CU at a time: with an eighth of
 // the chunks the narrow GEMMs use, 256 chunks become 32 x 8 = 256 workgroups -- one wave over the chip, every workgroup
 // eight times as many samples -- and the partial slabs (256 KB each) shrink from 0.5 GB to 67 MB written and re-read.
@@ -635,7 +628,8 @@ int big_chunks(int n_chunks) { return (n_chunks >= 8 && n_chunks % 8 == 0) ? n_c
 template <int PD>
 int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long long P, int n_chunks,
                float* workspace, float* g, int accumulate, void* stream, const float* amax_x = nullptr,
-               const float* amax_z = nullptr, const float* scales = nullptr) {
+               const float* amax_z = nullptr, const float* scales = nullptr, hipEvent_t ev_before = nullptr,
+               hipEvent_t ev_after = nullptr) {
     using namespace scn::mlp;
     using V = Var<PD>;
     const long long Ppad = scn::mlp::padded_samples(P);
@@ -655,7 +649,7 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
     hipStream_t st = (hipStream_t)stream;
     // the narrow GEMMs on three fp16 products: rows 8 .. 10 of the dZ maxima are dZ of the views layer, dZ of layer 0
     // and max(1, |point|) >= the encoded point (mlp_bwd_h3_kernel.h); the feature is bounded through its layer
-    const bool half_narrow = amax_x && amax_z && scales && wgrad_arithmetic() == 2;
+    const bool half_narrow = amax_x && amax_z && scales && wgrad_arithmetic() == 1;
     const long coarse_chunk = (long)scnerf_wgrad_chunk_samples(P, nb);
     auto zrow = [&](int r) { return wgnh::Bound{amax_z + (long)r * nb, nullptr, nullptr}; };
     const NarrowScales ns_l0{zrow(9), zrow(10), nb, coarse_chunk};
@@ -745,12 +739,11 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
     }
 #undef SCN_WG
     if (big.n_jobs > 0) {
-        if (g_profile_events[0]) SCN_HIP(hipEventRecord(g_profile_events[0], st));
-        rc = (amax_x && amax_z && wgrad_arithmetic() == 2) ? launch_wgrad256_half(big, nb, amax_z, amax_x, st)
+        if (ev_before) SCN_HIP(hipEventRecord(ev_before, st));
+        rc = (amax_x && amax_z && wgrad_arithmetic() == 1) ? launch_wgrad256_half(big, nb, amax_z, amax_x, st)
                                                             : launch_wgrad256(big, nb, st);
         if (rc != 0) return rc;
-        if (g_profile_events[1]) SCN_HIP(hipEventRecord(g_profile_events[1], st));
-        g_profile_events[0] = g_profile_events[1] = nullptr;
+        if (ev_after) SCN_HIP(hipEventRecord(ev_after, st));
     }
     // one launch finishes all twelve GEMMs (fixed-order sums: deterministic)
     int blocks = 0;
@@ -773,14 +766,8 @@ extern "C" int scnerf_nerf_wgrad(int pt_dims, const float* save, const float* gr
     return nerf_wgrad<4>(save, grads, d_raw, n_samples, n_chunks, workspace, flat_grad, accumulate, stream);
 }
 
-extern "C" int scnerf_wgrad_profile_events(void* before, void* after) {
-    g_profile_events[0] = (hipEvent_t)before;
-    g_profile_events[1] = (hipEvent_t)after;
-    return 0;
-}
-
 extern "C" int scnerf_wgrad_arithmetic(int mode) {
-    if (mode == 0 || mode == 1 || mode == 2) wgrad_arithmetic() = mode;
+    if (mode == 0 || mode == 1) wgrad_arithmetic() = mode;
     return wgrad_arithmetic();
 }
 
@@ -797,11 +784,11 @@ extern "C" long long scnerf_wgrad_chunk_samples(long long n_samples, int n_chunk
 extern "C" int scnerf_nerf_wgrad_h3(int pt_dims, const float* save, const float* grads, const float* d_raw,
                                     long long n_samples, int n_chunks, float* workspace, float* flat_grad,
                                     int accumulate, const float* amax_x, const float* amax_z, const float* scales,
-                                    void* stream) {
+                                    void* ev_before, void* ev_after, void* stream) {
     SCN_RETURN_IF(!save || !grads || !d_raw || !workspace || !flat_grad || n_samples < 1 || n_chunks < 1, SCN_EINVAL);
     SCN_RETURN_IF(pt_dims != 3 && pt_dims != 4, SCN_EINVAL);
-    if (pt_dims == 3) return nerf_wgrad<3>(save, grads, d_raw, n_samples, n_chunks, workspace, flat_grad, accumulate, stream, amax_x, amax_z, scales);
-    return nerf_wgrad<4>(save, grads, d_raw, n_samples, n_chunks, workspace, flat_grad, accumulate, stream, amax_x, amax_z, scales);
+    if (pt_dims == 3) return nerf_wgrad<3>(save, grads, d_raw, n_samples, n_chunks, workspace, flat_grad, accumulate, stream, amax_x, amax_z, scales, (hipEvent_t)ev_before, (hipEvent_t)ev_after);
+    return nerf_wgrad<4>(save, grads, d_raw, n_samples, n_chunks, workspace, flat_grad, accumulate, stream, amax_x, amax_z, scales, (hipEvent_t)ev_before, (hipEvent_t)ev_after);
 }
 
 // one narrow GEMM (256 x 64 / 256 x 128 with a row-major X, 128 x 256 with a tile-native X) on three fp16 products with

@@ -73,8 +73,8 @@ class RenderRaysFunction(torch.autograd.Function):
         flat_c = net_c.flat_parameters()
         wf_c = ops.pack_weights(flat_c, "fwd")
         save_c = ops.save_workspace(n * sc, dev) if train else None
-        # what the arithmetic in force (ops.mlp_arithmetic) needs besides the packed fp32 buffer: nothing (the fused fp32
-        # kernels), the planes of the 256-wide layers (split-arithmetic GEMMs), or the resident kernels' streams
+        # what the arithmetic in force (ops.mlp_arithmetic) needs besides the packed fp32 buffer: the resident kernels'
+        # streams, or nothing (the fused fp32-MFMA kernels)
         pl_c = ops.pack_for_arithmetic(flat_c, train) if n > 0 else None
         resident = isinstance(pl_c, ops.ResidentWeights)
         # (resident kernels, training: they leave the chunk maxima the fp16 weight-gradient GEMMs scale by)

@@ -64,7 +64,7 @@ class _NerfNetFunction(torch.autograd.Function):
         flat_f, flat_b = fg_net.flat_parameters(), bg_net.flat_parameters()
         save_f = ops.save_workspace(n * sf, dev, 3) if train else None
         save_b = ops.save_workspace(n * sb, dev, 4) if train else None
-        # training: the 256-wide layers as split-arithmetic GEMMs (ops.mlp_arithmetic), as in the SCNeRF step
+        # the arithmetic in force (ops.mlp_arithmetic): the resident kernels' streams, as in the SCNeRF step
         pl_f = ops.pack_for_arithmetic(flat_f, train, 3, remap=fg_net.pack_remap()) if n > 0 else None
         pl_b = ops.pack_for_arithmetic(flat_b, train, 4, remap=bg_net.pack_remap()) if n > 0 else None
         resident = train and isinstance(pl_f, ops.ResidentWeights)

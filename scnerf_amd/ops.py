@@ -202,22 +202,17 @@ def pack_weights(flat_params: Tensor, kind: str = "fwd", out: Optional[Tensor] =
     return out
 
 
-MLP_ARITHMETICS = ("fp32", "split", "half", "resident")
+MLP_ARITHMETICS = ("fp32", "resident")
 _MLP_ARITHMETIC = [os.environ.get("SCNERF_MLP_ARITHMETIC", "resident")]
 if _MLP_ARITHMETIC[0] not in MLP_ARITHMETICS:
     raise ValueError("SCNERF_MLP_ARITHMETIC must be one of %s, not %r" % ("|".join(MLP_ARITHMETICS), _MLP_ARITHMETIC[0]))
 
 
 def mlp_arithmetic(mode: Optional[str] = None) -> str:
-    """How the TRAINING forward and the data-gradient chain run the eight 256-wide layers (trunk 1 .. 7,
-    feature_linear): "fp32" -- inside the fused kernels on the exact-fp32 MFMA; "split" -- as GEMMs over all samples
-    on the bf16 matrix pipe with exactly cut fp32 operands, six products per product (csrc/layer_split.h), between the
-    fused kernels' end stages (encoding + layer 0 / heads; heads / encoded-point end); "half" -- the same, with the
-    layers whose input comes with per-sample maxima (forward 2-4 and 6-8, data gradients 7^T .. 1^T) on THREE fp16
-    products: operands scaled by a power of two per sample / per layer and cut into two fp16 numbers; "resident" (the
-    default) -- the WHOLE network, training and inference, forward and data gradients, as one launch each on three fp16
-    products with the activations register-resident as cut fp16 planes (csrc/mlp_h3.h): nothing is read back from the
-    activation workspace, which is only written for the weight-gradient GEMMs.
+    """How the network runs, training and inference, forward and data gradients: "resident" (the default) -- one launch
+    per pass on three fp16 products per product with the activations register-resident as cut fp16 planes
+    (csrc/mlp_h3.h): the activation workspace is only written, for the weight-gradient GEMMs; "fp32" -- the fused
+    kernels on the exact-fp32 MFMA (csrc/mlp_fwd.hip, mlp_bwd.hip): the numerical yardstick.
     Without an argument: the mode in force.  Environment preset: SCNERF_MLP_ARITHMETIC."""
     if mode is not None:
         if mode not in MLP_ARITHMETICS:
@@ -227,54 +222,14 @@ def mlp_arithmetic(mode: Optional[str] = None) -> str:
 
 
 def pack_for_arithmetic(flat_params: Tensor, train: bool, pd: int = 3, remap=None):
-    """What mlp_fwd / coarse_stage_fwd / mlp_bwd take as `planes` in the arithmetic in force: None ("fp32", and
-    inference of "split" / "half": the fused fp32 kernels), the bf16 / fp16 planes of the 256-wide layers ("split",
-    "half"; training), or the ResidentWeights ("resident"; training and inference)."""
-    mode = _MLP_ARITHMETIC[0]
-    if mode == "resident":
+    """What mlp_fwd / coarse_stage_fwd / mlp_bwd take as `planes` in the arithmetic in force: the ResidentWeights
+    ("resident") or None ("fp32": the fused fp32-MFMA kernels read the packed fp32 tables only)."""
+    if _MLP_ARITHMETIC[0] == "resident":
         return pack_resident(flat_params, pd, remap=remap)
-    if mode == "fp32" or not train:
-        return None
-    return pack_planes(flat_params, pd, remap=remap)
+    return None
 
 
 _canon_cache = {}
-_amax_cache = {}
-
-
-def _amax(P: int, device) -> Optional[Tensor]:
-    """the per-sample maxima workspace of the "half" arithmetic (None in the other modes)"""
-    if _MLP_ARITHMETIC[0] != "half":
-        return None
-    key = (int(P), str(device))
-    if key not in _amax_cache:
-        _amax_cache[key] = torch.empty(_capi.load().scnerf_layer_amax_floats(int(P)), dtype=torch.float32, device=device)
-    return _amax_cache[key]
-
-
-def pack_planes(flat_params: Tensor, pd: int = 3, out: Optional[Tensor] = None, remap=None) -> Tensor:
-    """flat parameter buffer (reference order) -> bf16 planes of the 256-wide layers in MFMA fragment order
-    (int16 tensor, scnerf_split_planes_shorts(pd) words); once per optimizer step.  `remap` as in pack_weights:
-    the buffer of a module that registers the same tensors in another order is first gathered into the order the
-    kernel expects."""
-    _f(flat_params, "flat_params")
-    lay = ML.layout(pd)
-    if flat_params.numel() != lay.n_params:
-        raise ValueError("expected %d parameters, got %d" % (lay.n_params, flat_params.numel()))
-    lib = _capi.load()
-    if remap is not None:
-        key = (remap[0], str(flat_params.device))
-        if key not in _canon_cache:
-            _canon_cache[key] = torch.from_numpy(np.asarray(remap[1], dtype=np.int32)).to(flat_params.device)
-        idx = _canon_cache[key]
-        canon = torch.empty(lay.n_params, dtype=torch.float32, device=flat_params.device)
-        _capi.check(lib.scnerf_gather_f32(_p(flat_params), _p(idx), _p(canon), idx.numel(), _stream()), "scnerf_gather_f32")
-        flat_params = canon
-    n = lib.scnerf_split_planes_shorts(pd)
-    if out is None:
-        out = torch.empty(n, dtype=torch.int16, device=flat_params.device)
-    _capi.check(lib.scnerf_pack_split_planes(pd, _p(flat_params), _p(out), _stream()), "scnerf_pack_split_planes")
-    return out
 
 
 class ResidentWeights:
@@ -319,7 +274,7 @@ def _h3_device_tables(pd: int, device):
 def pack_resident(flat_params: Tensor, pd: int = 3, out: Optional[ResidentWeights] = None, remap=None) -> ResidentWeights:
     """flat parameter buffer (reference order) -> the fp16 fragment streams of the forward and the data-gradient chain
     and the per-layer scale table of the resident arithmetic (csrc/mlp_h3.h); once per optimizer step.  `remap` as in
-    pack_planes."""
+    pack_weights."""
     _f(flat_params, "flat_params")
     lay = ML.layout(pd)
     if flat_params.numel() != lay.n_params:
@@ -358,40 +313,11 @@ def _vd(viewdirs: Tensor):
 _MAC_PER_SAMPLE = {3: 593408, 4: 593408 + 2 * 256 * 21}       # layer 0 and the skip layer are 21 columns wider
 
 
-def _half_note(n: int) -> str:
-    """suffix of the layer GEMMs' timing region in the "half" arithmetic: how many of the eight run on three fp16
-    products (forward: layers 2-4 and 6-8; data gradients: 7^T .. 1^T)"""
-    return ": %d on three fp16 products" % n if _MLP_ARITHMETIC[0] == "half" else ""
-
-
-def _layer_flop(pd: int, layer: int, P: int) -> int:
-    return 2 * 256 * (256 + (ML.layout(pd).in_pts if layer == 5 else 0)) * P
-
-
-def _fwd_split_piecewise(pd, P, tag, wpacked, planes, save, stage_call):
-    """stage 1, layers 1 .. 8, stage 2 of the split-arithmetic training forward as separate C calls (what
-    scnerf_mlp_fwd_split / scnerf_coarse_stage_fwd_split do inside), each in a PROFILE region"""
-    lay, lib = ML.layout(pd), _capi.load()
-    Pp = ML.padded_samples(P)
-    off, total = ML.section_offsets(lay.save_sections, P)
-    base, esz = save.data_ptr(), 4
-    names = ["act%d" % l for l in range(8)] + ["feat"]
-    with PROFILE.region("mlp_fwd_kernel<stage 1: encoding + layer 0>%s/P=%d" % (tag, P), 2 * 256 * lay.in_pts * P):
-        _capi.check(stage_call(1), "forward stage 1")
-    # (layers 1 .. 8 go out as one launch -- a chain -- when every persistent workgroup owns two blocks or more)
-    with PROFILE.region("layer_split_kernel<8 layers%s>%s/P=%d" % (_half_note(6), tag, P),
-                        sum(_layer_flop(pd, l, P) for l in range(1, 9))):
-        _capi.check(lib.scnerf_layer_split_chain_fwd(pd, _p(planes), _p(wpacked), _p(save), _p(_amax(P, save.device)), P,
-                                                     _stream()), "scnerf_layer_split_chain_fwd")
-    with PROFILE.region("mlp_fwd_kernel<stage 2: heads>%s/P=%d" % (tag, P), 2 * (128 * 283 + 3 * 128 + 256) * P):
-        _capi.check(stage_call(2), "forward stage 2")
-
-
 def mlp_fwd(pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked: Tensor,
             save: Optional[Tensor] = None, pd: int = 3, planes: Optional[Tensor] = None,
             maxima: Optional["ChunkMaxima"] = None) -> Tensor:
     """pts [P, pd] (pd = 3: x y z; pd = 4: x y z 1/r) -> raw [P, 4] (rgb logits, sigma pre-activation).
-    `planes` (pack_planes; training only): the 256-wide layers run as split-arithmetic GEMMs."""
+    `planes`: the ResidentWeights (pack_resident) -> the resident kernel; None -> the fused fp32-MFMA kernel."""
     _f(pts, "pts"), _f(wpacked, "wpacked")
     vptr, vstride = _vd(viewdirs)
     lay = ML.layout(pd)
@@ -409,21 +335,7 @@ def mlp_fwd(pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked: Tensor
     raw = torch.empty((P, 4), dtype=torch.float32, device=pts.device)
     tag = "" if pd == 3 else "/pd4"
     if planes is not None:
-        if save is None:
-            raise ValueError("the split-arithmetic forward runs through the activation workspace (training mode)")
-        with PROFILE.region("mlp_fwd(stages + 8 layer GEMMs)%s/P=%d/train" % (tag, P), 2 * _MAC_PER_SAMPLE[pd] * P, group=True):
-            if PROFILE.enabled:
-                # the same ten launches one by one, each in its own timing region
-                _fwd_split_piecewise(pd, P, tag, wpacked, planes, save,
-                                     lambda stage: _capi.load().scnerf_mlp_fwd_stage(
-                                         pd, stage, _p(pts), vptr, vstride, int(samples_per_ray), _p(wpacked), _p(raw),
-                                         _p(save), P, _stream()))
-                st = 0
-            else:
-                st = _capi.load().scnerf_mlp_fwd_split(pd, _p(pts), vptr, vstride, int(samples_per_ray), _p(wpacked),
-                                                       _p(planes), _p(raw), _p(save), _p(_amax(P, save.device)), P, _stream())
-        _capi.check(st, "scnerf_mlp_fwd_split")
-        return raw
+        raise TypeError("planes must be a ResidentWeights or None")
     with PROFILE.region("mlp_fwd_kernel%s/P=%d/%s" % (tag, P, "train" if save is not None else "infer"),
                         2 * _MAC_PER_SAMPLE[pd] * P):
         st = _capi.load().scnerf_mlp_fwd(pd, _p(pts), vptr, vstride, int(samples_per_ray), _p(wpacked), _p(raw),
@@ -501,17 +413,7 @@ def coarse_stage_fwd(rays: Tensor, t_vals: Tensor, t_rand: Optional[Tensor], lin
         _capi.check(st, "scnerf_coarse_stage_fwd_h3")
         return z, pts, raw, rgb, disp, acc, w, depth
     if planes is not None:
-        if save is None:
-            raise ValueError("the split-arithmetic forward runs through the activation workspace (training mode)")
-        with PROFILE.region("mlp_fwd(stages + 8 layer GEMMs)/P=%d/train" % P, 2 * _MAC_PER_SAMPLE[3] * P, group=True):
-            # (profiled or not: one C call; its layer launches are timed at this size by the fine pass's regions'
-            # twin below only when the fused coarse stage is not in use)
-            st = _capi.load().scnerf_coarse_stage_fwd_split(
-                _p(rays), rays.shape[1], _p(t_vals), _p(t_rand), int(bool(lindisp)), _p(wpacked), _p(planes), _p(save),
-                _p(noise), int(bool(white_bkgd)), _p(z), _p(pts), _p(raw), _p(rgb), _p(disp), _p(acc), _p(depth), _p(w),
-                _p(_amax(P, save.device)), n, s, _stream())
-        _capi.check(st, "scnerf_coarse_stage_fwd_split")
-        return z, pts, raw, rgb, disp, acc, w, depth
+        raise TypeError("planes must be a ResidentWeights or None")
     with PROFILE.region("mlp_fwd_kernel/P=%d/%s" % (P, "train" if save is not None else "infer"), 2 * _MAC_PER_SAMPLE[3] * P):
         st = _capi.load().scnerf_coarse_stage_fwd(_p(rays), rays.shape[1], _p(t_vals), _p(t_rand), int(bool(lindisp)),
                                                   _p(wpacked), _p(save), _p(noise), int(bool(white_bkgd)), _p(z), _p(pts),
@@ -524,29 +426,9 @@ def save_workspace(P: int, device, pd: int = 3) -> Tensor:
     return torch.empty(ML.layout(pd).save_floats(P), dtype=torch.float32, device=device)
 
 
-def _bwd_split_piecewise(pd, P, tag, wpacked_bwd, planes, save, grads, d_raw, stage_call):
-    """stage 1, the eight transposed layers, stage 2 of the split-arithmetic data-gradient chain as separate C calls,
-    each in a PROFILE region"""
-    lay, lib = ML.layout(pd), _capi.load()
-    Pp = ML.padded_samples(P)
-    _, total = ML.section_offsets(lay.save_sections, P)
-    goff, _ = ML.section_offsets(ML.GRAD_SECTIONS, P)
-    gnames = ["dz%d" % l for l in range(8)]
-    masks = save.data_ptr() + total * 4
-    alpha = wpacked_bwd.data_ptr() + lay.bwd_alpha_w * 4
-    with PROFILE.region("mlp_bwd_kernel<stage 1: heads>%s/P=%d" % (tag, P), 2 * (128 * 283 + 3 * 128) * P):
-        _capi.check(stage_call(1), "backward stage 1")
-    with PROFILE.region("layer_split_kernel<8 layers%s>%s/P=%d" % (_half_note(7), tag, P), 8 * 2 * 256 * 256 * P):
-        _capi.check(lib.scnerf_layer_split_chain_bwd(pd, _p(planes), _p(wpacked_bwd), _p(save), _p(grads), _p(d_raw),
-                                                     _p(_amax(P, save.device)), P, _stream()), "scnerf_layer_split_chain_bwd")
-    with PROFILE.region("mlp_bwd_kernel<stage 2: encoded-point end>%s/P=%d" % (tag, P), 2 * 2 * 256 * lay.in_pts * P):
-        _capi.check(stage_call(2), "backward stage 2")
-
-
 def mlp_bwd(d_raw: Tensor, pts: Tensor, viewdirs: Tensor, samples_per_ray: int, wpacked_bwd: Tensor,
             save: Tensor, pd: int = 3, planes: Optional[Tensor] = None, maxima: Optional["ChunkMaxima"] = None):
-    """-> (grads workspace, d_pts [P,pd], d_views [P,3]).  `planes` (pack_planes): the 256-wide transposed layers
-    run as split-arithmetic GEMMs."""
+    """-> (grads workspace, d_pts [P,pd], d_views [P,3]).  `planes`: as mlp_fwd."""
     if isinstance(planes, ResidentWeights):
         if planes.pd != pd:
             raise ValueError("resident weights of another network variant")
@@ -562,20 +444,7 @@ def mlp_bwd(d_raw: Tensor, pts: Tensor, viewdirs: Tensor, samples_per_ray: int, 
     d_pts = torch.empty((P, pd), dtype=torch.float32, device=dev)
     d_views = torch.empty((P, 3), dtype=torch.float32, device=dev)
     if planes is not None:
-        with PROFILE.region("mlp_bwd(stages + 8 layer GEMMs)%s/P=%d" % ("" if pd == 3 else "/pd4", P),
-                            2 * _MAC_PER_SAMPLE[pd] * P, group=True):
-            if PROFILE.enabled:
-                _bwd_split_piecewise(pd, P, "" if pd == 3 else "/pd4", wpacked_bwd, planes, save, grads, d_raw,
-                                     lambda stage: _capi.load().scnerf_mlp_bwd_stage(
-                                         pd, stage, _p(d_raw), _p(pts), vptr, vstride, int(samples_per_ray),
-                                         _p(wpacked_bwd), _p(save), _p(grads), _p(d_pts), _p(d_views), P, _stream()))
-                st = 0
-            else:
-                st = _capi.load().scnerf_mlp_bwd_split(pd, _p(d_raw), _p(pts), vptr, vstride, int(samples_per_ray),
-                                                       _p(wpacked_bwd), _p(planes), _p(save), _p(grads), _p(d_pts),
-                                                       _p(d_views), _p(_amax(P, save.device)), P, _stream())
-        _capi.check(st, "scnerf_mlp_bwd_split")
-        return grads, d_pts, d_views
+        raise TypeError("planes must be a ResidentWeights or None")
     with PROFILE.region("mlp_bwd_kernel%s/P=%d" % ("" if pd == 3 else "/pd4", P), 2 * _MAC_PER_SAMPLE[pd] * P):
         st = _capi.load().scnerf_mlp_bwd(pd, _p(d_raw), _p(pts), vptr, vstride, int(samples_per_ray),
                                          _p(wpacked_bwd), _p(save), _p(grads), _p(d_pts), _p(d_views), P, _stream())
@@ -617,12 +486,12 @@ _wgrad_ws = {}
 
 
 def wgrad_arithmetic(mode: Optional[str] = None) -> str:
-    """The 256 x 256 weight-gradient GEMMs: "half" (default) -- three fp16 products per product with one power-of-two
-    scale per operand and workgroup chunk, where the resident kernels left the chunk maxima (csrc/wgrad256_half.h;
-    otherwise as "split"); "split" -- the bf16 matrix pipe with exactly cut fp32 operands, six products
-    (csrc/wgrad256_split.h); "fp32": the exact-fp32 MFMA.  Without an argument: the mode in force."""
-    code = {None: -1, "fp32": 0, "split": 1, "half": 2}[mode]
-    return ("fp32", "split", "half")[_capi.load().scnerf_wgrad_arithmetic(code)]
+    """The 256 x 256 weight-gradient GEMMs and the narrow ones with a tile-native dZ: "half" (default) -- three fp16
+    products per product with one power-of-two scale per operand and workgroup chunk, where the resident kernels left
+    the chunk maxima (csrc/wgrad256_half.h, wgrad_half_narrow.h); "fp32", and wherever no maxima were left: the
+    exact-fp32 MFMA.  Without an argument: the mode in force."""
+    code = {None: -1, "fp32": 0, "half": 1}[mode]
+    return ("fp32", "half")[_capi.load().scnerf_wgrad_arithmetic(code)]
 
 
 def nerf_wgrad(save: Tensor, grads: Tensor, d_raw: Tensor, P: int, flat_grad: Optional[Tensor] = None,
@@ -645,19 +514,20 @@ def nerf_wgrad(save: Tensor, grads: Tensor, d_raw: Tensor, P: int, flat_grad: Op
     if maxima is not None and maxima.scales is None:
         maxima = None
     with PROFILE.region("wgrad(12 GEMMs + reduces)%s/P=%d" % (tag, P), 2 * _MAC_PER_SAMPLE[pd] * P, group=True):
-        inner = None
+        ev = (None, None)
         if PROFILE.enabled:
-            # the dominant launch inside this C call -- the eight 256 x 256 GEMMs -- between two events of its own
+            # the dominant launch inside this C call -- the eight 256 x 256 GEMMs -- between two events the call records
             mode = wgrad_arithmetic()
             if mode == "half" and maxima is None:
-                mode = "split"
+                mode = "fp32"
             inner = PROFILE.raw_pair("wgrad256_kernel<8 GEMMs, %s>%s/P=%d" % (mode, tag, P), 8 * 2 * 256 * 256 * P)
-            lib.scnerf_wgrad_profile_events(inner[0].cuda_event, inner[1].cuda_event)
+            ev = (inner[0].cuda_event, inner[1].cuda_event)
         if maxima is not None and maxima.chunks != lib.scnerf_wgrad256_chunks(chunks):
             raise ValueError("chunk maxima of another chunking")
         st = lib.scnerf_nerf_wgrad_h3(pd, _p(save), _p(grads), _p(d_raw), P, chunks, _p(_wgrad_ws[key]),
                                       _p(flat_grad), int(bool(accumulate)), _p(maxima.x) if maxima else None,
-                                      _p(maxima.z) if maxima else None, _p(maxima.scales) if maxima else None, _stream())
+                                      _p(maxima.z) if maxima else None, _p(maxima.scales) if maxima else None, ev[0], ev[1],
+                                      _stream())
     _capi.check(st, "scnerf_nerf_wgrad")
     return flat_grad
 

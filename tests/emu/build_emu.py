@@ -33,11 +33,12 @@ def _build(verbose=False):
     flags = ["-O2", "-g1", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-mfma",
              "-x", "c++", "-DSCNERF_SIMT_EMU_BUILD=1",
              "-I", os.path.join(HERE, "shim"), "-I", CSRC, "-I", os.path.join(ROOT, "include"),
+             "-idirafter", os.path.join(CSRC, "device"),        # scn_lab.h (scn_wave.h is the shim's: found first)
              "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-unused-variable"]
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
     srcs.append(os.path.join(HERE, "shim", "simt_emu.cpp"))
     hdrs = []
-    for d in (CSRC, os.path.join(HERE, "shim"), os.path.join(HERE, "shim", "hip"), os.path.join(ROOT, "include")):
+    for d in (CSRC, os.path.join(CSRC, "device"), os.path.join(HERE, "shim"), os.path.join(HERE, "shim", "hip"), os.path.join(ROOT, "include")):
         hdrs += [os.path.join(d, f) for f in os.listdir(d) if f.endswith(".h")]
     h = hashlib.sha256()
     for p in sorted(hdrs):

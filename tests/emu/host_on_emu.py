@@ -12,10 +12,8 @@ import contextlib
 
 @contextlib.contextmanager
 def emulated_device(mlp_arithmetic="fp32"):
-    """`mlp_arithmetic`: ops.mlp_arithmetic inside the context.  The per-layer split GEMMs work on 256-sample blocks,
-    so interpreting them for the handful of rays these host-level tests use costs minutes: the long tests stay on the
-    fused kernels, tests/test_emu_layer_split.py and test_render_rays_split_on_the_simt_interpreter cover the split
-    path."""
+    """`mlp_arithmetic`: ops.mlp_arithmetic inside the context (the long host-level tests stay on the fused fp32 kernels,
+    which the interpreter runs fastest; tests/test_emu_mlp_h3.py covers the resident kernels)."""
     from scnerf_amd import _capi, ops
     from tests.emu import harness
     saved = (_capi._lib, _capi.on_device, _capi.current_stream)
@@ -27,7 +25,6 @@ def emulated_device(mlp_arithmetic="fp32"):
     _capi.current_stream = lambda: None
     ops._index_cache.clear()
     ops._wgrad_ws.clear()
-    ops._amax_cache.clear()
     ops._h3_tables.clear()
     try:
         yield
@@ -36,6 +33,5 @@ def emulated_device(mlp_arithmetic="fp32"):
         ops._canon_cache.clear()
         _capi._lib, _capi.on_device, _capi.current_stream = saved
         ops._index_cache.clear()
-        ops._amax_cache.clear()
         ops._wgrad_ws.clear()
         ops._h3_tables.clear()

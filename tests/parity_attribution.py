@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 # everything the parity tests measured; tests/conftest.py writes it at the end of the session to
-# gpurun_out/parity_r03.json (travels back from the GPU box; the copy committed under profiles/ is this file)
+# gpurun_out/parity_r04.json (travels back from the GPU box; the copy committed under profiles/ is this file)
 # and to profiles/ in the tree the tests ran in
 REPORT = {}
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,7 +29,7 @@ def write_report():
         return
     merged = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "parity_r03.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "parity_r04.json")) as f:
             merged = json.load(f)
     except (OSError, ValueError):
         pass
@@ -37,7 +37,7 @@ def write_report():
     for d in ("gpurun_out", "profiles"):
         try:
             os.makedirs(os.path.join(ROOT, d), exist_ok=True)
-            with open(os.path.join(ROOT, d, "parity_r03.json"), "w") as f:
+            with open(os.path.join(ROOT, d, "parity_r04.json"), "w") as f:
                 json.dump(merged, f, indent=1, sort_keys=True)
         except OSError:
             pass
@@ -79,6 +79,46 @@ def classify(u, bins, cdf_a, inds_a, cdf_b, inds_b, illcond=1e-3, displaced=1e-5
     thin = ((torch.minimum(da, db) < illcond) & (moved > displaced)).any(-1)
     return dict(index=index.numpy(), branch=branch.numpy(), illcond=(thin & ~index & ~branch).numpy(),
                 moved=moved.max(-1)[0].numpy())
+
+
+def sample_state_npp(cdf, above, u, bins, tiny=1e-6):
+    """NeRF++'s sampler tail (nerfplusplus/ddp_train_nerf.py:116-130) recomputed op by op from a side's own cdf and
+    comparison-count indices: (denom before the `< TINY` guard, samples)."""
+    cdf, u, bins = torch.as_tensor(cdf).float(), torch.as_tensor(u).float(), torch.as_tensor(bins).float()
+    above = torch.as_tensor(above).long()
+    below = torch.clamp(above - 1, min=0)
+    c0, c1 = _gather(cdf, below), _gather(cdf, above)
+    b0, b1 = _gather(bins, below), _gather(bins, above)
+    denom_raw = c1 - c0
+    denom = torch.where(denom_raw < tiny, torch.ones_like(denom_raw), denom_raw)
+    return denom_raw, b0 + (u - c0) / denom * (b1 - b0 + tiny)
+
+
+def classify_npp(u, bins, cdf_a, above_a, cdf_b, above_b, illcond=1e-3, displaced=1e-5, tiny=1e-6):
+    """`classify` for the NeRF++ sampler: the index is the count of cdf knots <= u (:113), the guard `denom < 1e-6`
+    (:126-127).  Same keys."""
+    da, sa = sample_state_npp(cdf_a, above_a, u, bins, tiny)
+    db, sb = sample_state_npp(cdf_b, above_b, u, bins, tiny)
+    ia, ib = torch.as_tensor(above_a).long(), torch.as_tensor(above_b).long()
+    index = (ia != ib).any(-1)
+    branch = ((da < tiny) != (db < tiny)).any(-1)
+    moved = (sa - sb).abs()
+    thin = ((torch.minimum(da, db) < illcond) & (moved > displaced)).any(-1)
+    return dict(index=index.numpy(), branch=branch.numpy(), illcond=(thin & ~index & ~branch).numpy(),
+                moved=moved.max(-1)[0].numpy())
+
+
+def merge_causes(*cls):
+    """a ray is flagged when any of its samplers (foreground, background) flags it"""
+    out = {k: np.zeros_like(cls[0][k]) for k in ("index", "branch", "illcond")}
+    for c in cls:
+        out["index"] |= c["index"]
+        out["branch"] |= c["branch"] & ~out["index"]
+    for c in cls:
+        out["illcond"] |= c["illcond"]
+    out["illcond"] &= ~(out["index"] | out["branch"])
+    out["moved"] = np.maximum.reduce([c["moved"] for c in cls])
+    return out
 
 
 def per_ray_error(got, ref, relative=False):

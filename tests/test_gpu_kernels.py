@@ -275,12 +275,11 @@ def test_relu_gate_flips_are_attributed(ops, resident):
     PA.REPORT["relu_gate_attribution/" + ("resident" if resident else "fused_fp32")] = report
 
 
-def test_split_weight_gradient_gemm_is_fp32_grade(ops):
-    """The 256 x 256 weight-gradient GEMM on the bf16 matrix pipe (operands cut exactly into three bf16 numbers, six
-    partial products; csrc/wgrad256_split.h) against fp64, beside the exact-fp32 MFMA kernel on the same
-    operands: full 24-bit significands, magnitudes spread over 2^8, half of X zero (post-ReLU).  The split
-    kernel's error must be the fp32 kernel's (accumulation-order noise), not a reduced-precision one
-    (a plain bf16 product would be at 4e-3, a two-term split at 1e-5 of sum |a b|)."""
+def test_half_weight_gradient_gemm_is_fp32_grade(ops):
+    """The 256 x 256 weight-gradient GEMM on three fp16 products (operands scaled per workgroup chunk and cut into two fp16
+    numbers; csrc/wgrad256_half.h) against fp64, beside the exact-fp32 MFMA kernel on the same operands: full 24-bit
+    significands, magnitudes spread over 2^8, half of X zero (post-ReLU).  Its error must be the fp32 kernel's
+    (accumulation-order noise), not a reduced-precision one (a plain fp16 product would be at 5e-4 of sum |a b|)."""
     from scnerf_amd import _capi
     from tests import parity_attribution as PA
     lib = _capi.load()
@@ -299,7 +298,7 @@ def test_split_weight_gradient_gemm_is_fp32_grade(ops):
     ws = torch.empty(lib.scnerf_wgrad_workspace_floats(256, 256, chunks), device="cuda")
     err, out = {}, {}
     try:
-        for mode in ("fp32", "split"):
+        for mode in ("fp32",):
             assert ops.wgrad_arithmetic(mode) == mode
             dW = torch.full((256, 256), float("nan"), device="cuda")
             db = torch.full((256,), float("nan"), device="cuda")
@@ -330,11 +329,8 @@ def test_split_weight_gradient_gemm_is_fp32_grade(ops):
         err[tag] = {"max": float(e.max()), "rms": float((e * e).mean().sqrt())}
         eb = (db.double() - Az.double().sum(0)).abs() / Az.double().abs().sum(0)           # fp32 sums of 65 536 terms
         assert float(eb.max()) <= 2e-6, (tag, float(eb.max()))
-    PA.REPORT["wgrad256_arithmetic_65536_samples"] = {
-        "error_over_sum_abs_products_vs_fp64": err,
-        "max_difference_between_the_two_over_sum_abs_products": float(((out["split"] - out["fp32"]).double().abs() / scale).max())}
-    assert err["split"]["max"] <= 1.5 * err["fp32"]["max"] + 1e-9 and err["split"]["max"] < 2e-7, err
-    assert err["split"]["rms"] <= 2.0 * err["fp32"]["rms"], err
+    PA.REPORT["wgrad256_arithmetic_65536_samples"] = {"error_over_sum_abs_products_vs_fp64": err}
+    assert err["half"]["max"] < 2e-7, err
     assert err["half"]["max"] <= 2.0 * err["fp32"]["max"] + 1e-9 and err["half"]["rms"] <= 2.0 * err["fp32"]["rms"], err
     # (a few samples carry each sum when magnitudes differ by 2^40: bounded by one cut product, 3 x 2^-22)
     assert err["half_wide_range"]["max"] <= 3 * 2.0 ** -22 and err["half_wide_range"]["rms"] <= 1e-7, err
@@ -391,138 +387,6 @@ def test_narrow_weight_gradient_gemms_are_fp32_grade(ops, shape):
     assert float(eb.max()) <= 2e-6, float(eb.max())
     PA.REPORT["wgrad_narrow_%s_arithmetic_65536_samples_error_over_sum_abs_products_vs_fp64" % shape] = err
     assert err["half"]["max"] <= 2.0 * err["fp32"]["max"] + 1e-9 and err["half"]["rms"] <= 2.0 * err["fp32"]["rms"], err
-
-
-@pytest.fixture(params=["split", "half"])
-def layers(request, ops):
-    """the two arithmetics of the layer GEMMs: six bf16 products everywhere, or three fp16 products where the input
-    comes with per-sample maxima (ops.mlp_arithmetic)"""
-    saved = ops.mlp_arithmetic()
-    ops.mlp_arithmetic(request.param)
-    yield request.param
-    ops.mlp_arithmetic(saved)
-
-
-@pytest.mark.parametrize("pd,n_rays,spr", [(3, 21, 50), (4, 17, 70), (3, 1024, 192)])
-def test_staged_split_forward_equals_the_fused_forward(ops, pd, n_rays, spr, layers):
-    """Training forward with the eight 256-wide layers as split-arithmetic GEMMs (scnerf_mlp_fwd_split) against the
-    fused fp32-MFMA kernel: raw outputs and every saved section the backward kernels read, to accumulation-order
-    rounding; ReLU bit words may differ only where a pre-activation is within rounding of zero."""
-    from tests.emu_mlp_util import network_params
-    lay = ML.layout(pd)
-    p = network_params(4 if pd == 3 else 779, pd)
-    flat = dev(_flat(p, pd))
-    P = n_rays * spr
-    g = torch.Generator().manual_seed(5)
-    pts = dev(torch.rand(P, pd, generator=g) * 2.4 - 1.2)
-    vd = torch.randn(n_rays, 3, generator=g)
-    vd = dev(vd / vd.norm(dim=-1, keepdim=True))
-    wf = ops.pack_weights(flat, "fwd", pd=pd)
-    planes = ops.pack_planes(flat, pd)
-    save_a, save_b = ops.save_workspace(P, "cuda", pd).zero_(), ops.save_workspace(P, "cuda", pd).zero_()
-    raw_a = ops.mlp_fwd(pts, vd, spr, wf, save_a, pd=pd)
-    raw_b = ops.mlp_fwd(pts, vd, spr, wf, save_b, pd=pd, planes=planes)
-    scale = float(raw_a.abs().max())
-    assert float((raw_a - raw_b).abs().max()) <= 2e-5 * max(scale, 1.0)
-    Pp = ML.padded_samples(P)
-    off, total = ML.section_offsets(lay.save_sections, P)
-
-    def rows(save, name, w):            # live samples of a section as [P, w] (pad lanes carry whatever fed them)
-        blk = save[off[name]: off[name] + w * Pp]
-        if name in ML.TILED_SECTIONS:
-            blk = blk.view(Pp // 32, w // 32, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(Pp, w)
-        else:
-            blk = blk.view(Pp, w)
-        return blk[:P]
-    for name, w in lay.save_sections:
-        a, b = rows(save_a, name, w), rows(save_b, name, w)
-        assert float((a - b).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1.0), name
-    tiles = (P + 31) // 32
-    ma = save_a[total:].view(torch.int32).view(9, Pp // 32, 64, 4)[:, :tiles]
-    mb = save_b[total:].view(torch.int32).view(9, Pp // 32, 64, 4)[:, :tiles]
-    sample = torch.arange(tiles, device="cuda")[:, None] * 32 + (torch.arange(64, device="cuda")[None, :] & 31)
-    live = (sample < P)[None, :, :, None]
-    flipped = int(torch.count_nonzero((ma ^ mb) * live))
-    assert flipped <= max(4, P // 200), flipped          # words with a flipped bit: pre-activations within rounding of zero
-
-
-@pytest.mark.parametrize("pd,n_rays,spr", [(3, 21, 50), (4, 17, 70), (3, 1024, 192)])
-def test_staged_split_data_gradients_equal_the_fused_chain(ops, pd, n_rays, spr, layers):
-    """scnerf_mlp_bwd_split (heads, eight transposed split-arithmetic layer GEMMs, encoded-point end) against the
-    fused fp32-MFMA data-gradient kernel on the same forward workspace: every gradient section the weight-gradient
-    GEMMs read, d pts and d viewdirs, to accumulation-order rounding."""
-    from tests.emu_mlp_util import network_params
-    p = network_params(4 if pd == 3 else 779, pd)
-    flat = dev(_flat(p, pd))
-    P = n_rays * spr
-    g = torch.Generator().manual_seed(6)
-    pts = dev(torch.rand(P, pd, generator=g) * 2.4 - 1.2)
-    vd = torch.randn(n_rays, 3, generator=g)
-    vd = dev(vd / vd.norm(dim=-1, keepdim=True))
-    d_raw = dev(torch.randn(P, 4, generator=g))
-    save = ops.save_workspace(P, "cuda", pd).zero_()
-    ops.mlp_fwd(pts, vd, spr, ops.pack_weights(flat, "fwd", pd=pd), save, pd=pd)
-    wb = ops.pack_weights(flat, "bwd", pd=pd)
-    ga, pa, va = ops.mlp_bwd(d_raw, pts, vd, spr, wb, save, pd=pd)
-    gb, pb, vb = ops.mlp_bwd(d_raw, pts, vd, spr, wb, save, pd=pd, planes=ops.pack_planes(flat, pd))
-    Pp = ML.padded_samples(P)
-    off, _ = ML.section_offsets(ML.GRAD_SECTIONS, P)
-    for name, w in ML.GRAD_SECTIONS:
-        a, b = ga[off[name]: off[name] + w * Pp], gb[off[name]: off[name] + w * Pp]
-        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), name
-    assert float((pa - pb).abs().max()) <= 5e-5 * float(pa.abs().max())
-    assert float((va - vb).abs().max()) <= 5e-5 * float(va.abs().max())
-
-
-def test_split_layer_gemm_is_fp32_grade(ops):
-    """One trunk layer over 131 072 samples three ways -- the split-arithmetic GEMM (csrc/layer_split.h), the fused
-    fp32-MFMA kernel (both read from their training workspaces) and torch's fp32 matmul -- against fp64 on the same
-    inputs.  The split kernel's error must be that of the exact-fp32 paths (accumulation-order noise), nowhere near a
-    reduced-precision product (bf16: 4e-3, two-term split: 1e-5 of sum |w x|)."""
-    from tests import parity_attribution as PA
-    from tests.emu_mlp_util import network_params
-    lay = ML.layout(3)
-    p = network_params(4, 3)
-    flat = dev(_flat(p, 3))
-    n_rays, spr = 2048, 64
-    P = n_rays * spr
-    g = torch.Generator().manual_seed(8)
-    pts = dev(torch.rand(P, 3, generator=g) * 2.4 - 1.2)
-    vd = torch.randn(n_rays, 3, generator=g)
-    vd = dev(vd / vd.norm(dim=-1, keepdim=True))
-    wf = ops.pack_weights(flat, "fwd")
-    saves = {}
-    saved_mode = ops.mlp_arithmetic()
-    try:
-        for mode, planes in (("fp32", None), ("split", ops.pack_planes(flat)), ("half", ops.pack_planes(flat))):
-            ops.mlp_arithmetic(mode)
-            saves[mode] = ops.save_workspace(P, "cuda").zero_()
-            ops.mlp_fwd(pts, vd, spr, wf, saves[mode], planes=planes)
-    finally:
-        ops.mlp_arithmetic(saved_mode)
-    Pp = ML.padded_samples(P)
-    off, _ = ML.section_offsets(lay.save_sections, P)
-    rows = lambda save, name: save[off[name]: off[name] + 256 * Pp].view(Pp // 32, 8, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(Pp, 256)[:P]
-    report = {}
-    for layer in (2, 7):
-        W, b = dev(p["pts_linears.%d.weight" % layer]), dev(p["pts_linears.%d.bias" % layer])
-        for mode in ("fp32", "split", "half"):                        # (layers 2 and 7 are fp16 layers of "half")
-            x = rows(saves[mode], "act%d" % (layer - 1))              # each path judged on ITS OWN input
-            z = rows(saves[mode], "act%d" % layer)
-            ref = torch.relu(x.double() @ W.double().T + b.double())
-            scale = x.double().abs() @ W.double().abs().T + b.double().abs()
-            e = (z.double() - ref).abs() / scale
-            report.setdefault("layer%d" % layer, {})[mode] = {"max": float(e.max()), "rms": float((e * e).mean().sqrt())}
-            if mode == "split":
-                zt = torch.relu(x @ W.T + b)
-                et = (zt.double() - ref).abs() / scale
-                report["layer%d" % layer]["torch_fp32_matmul"] = {"max": float(et.max()), "rms": float((et * et).mean().sqrt())}
-    PA.REPORT["layer_gemm_arithmetic_131072_samples_error_over_sum_abs_products_vs_fp64"] = report
-    for layer, r in report.items():
-        assert r["split"]["rms"] <= 2.0 * r["fp32"]["rms"] and r["split"]["max"] <= 3.0 * r["fp32"]["max"] + 1e-9, (layer, r)
-        assert r["split"]["max"] < 1e-6, (layer, r)
-        assert r["half"]["rms"] <= 2.0 * r["fp32"]["rms"] and r["half"]["max"] <= 3.0 * r["fp32"]["max"] + 1e-9, (layer, r)
-        assert r["half"]["max"] < 1e-6, (layer, r)
 
 
 def test_resident_layers_are_fp32_grade(ops):
@@ -631,77 +495,3 @@ def test_resident_data_gradients_follow_the_fused_chain_row_by_row(ops):
         size = a.double().abs().max(1)[0]
         err = (a.double() - b.double()).abs().max(1)[0]
         assert bool((err <= 1e-4 * size + 1e-45).all()), (what, float((err / size.clamp_min(1e-300)).max()))
-
-
-def test_profiled_piecewise_launches_equal_the_single_calls(ops):
-    """With ops.PROFILE enabled (bench.py) the split-arithmetic forward / data-gradient chain is issued launch by launch
-    from Python (scnerf_mlp_fwd_stage, scnerf_layer_split, scnerf_layer_split_bwd, scnerf_mlp_bwd_stage) so that
-    every kernel gets its own HIP-event region; the results must be bit-identical to the single C calls."""
-    from tests.emu_mlp_util import network_params
-    for pd, n_rays, spr in ((3, 40, 50), (4, 33, 70)):
-        p = network_params(4 if pd == 3 else 779, pd)
-        flat = dev(_flat(p, pd))
-        P = n_rays * spr
-        g = torch.Generator().manual_seed(9)
-        pts = dev(torch.rand(P, pd, generator=g) * 2.4 - 1.2)
-        vd = torch.randn(n_rays, 3, generator=g)
-        vd = dev(vd / vd.norm(dim=-1, keepdim=True))
-        d_raw = dev(torch.randn(P, 4, generator=g))
-        wf, wb, planes = ops.pack_weights(flat, "fwd", pd=pd), ops.pack_weights(flat, "bwd", pd=pd), ops.pack_planes(flat, pd)
-        res = []
-        for profiled in (False, True):
-            ops.PROFILE.reset(enabled=profiled)
-            try:
-                save = ops.save_workspace(P, "cuda", pd).zero_()
-                raw = ops.mlp_fwd(pts, vd, spr, wf, save, pd=pd, planes=planes)
-                grads, d_pts, d_views = ops.mlp_bwd(d_raw, pts, vd, spr, wb, save, pd=pd, planes=planes)
-            finally:
-                names = set(ops.PROFILE.records)
-                ops.PROFILE.reset(enabled=False)
-            res.append((raw, save, grads, d_pts, d_views))
-        assert any(k.startswith("layer_split_kernel") for k in names)
-        for a, b in zip(*res):
-            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
-
-
-def test_three_product_layers_across_forty_orders_of_magnitude(ops):
-    """The data-gradient chain is linear in d_raw sample by sample.  With every sample's d_raw scaled by its own power
-    of ten between 1e-30 and 1e+10 -- far outside what fp16 holds -- the layers on three fp16 products (per-sample
-    power-of-two scales from the maxima the producing layer leaves; here as chains: 1024 x 192 samples) must reproduce
-    the six-bf16-product chain row by row, relative to each row's own size; all-zero samples stay zero."""
-    from tests.emu_mlp_util import network_params
-    pd, n_rays, spr = 3, 1024, 192
-    p = network_params(4, pd)
-    flat = dev(_flat(p, pd))
-    P = n_rays * spr
-    g = torch.Generator().manual_seed(16)
-    pts = dev(torch.rand(P, pd, generator=g) * 2.4 - 1.2)
-    vd = torch.randn(n_rays, 3, generator=g)
-    vd = dev(vd / vd.norm(dim=-1, keepdim=True))
-    decades = torch.rand(P, generator=g) * 40.0 - 30.0
-    d_raw = dev(torch.randn(P, 4, generator=g) * (10.0 ** decades)[:, None])
-    d_raw[::97] = 0.0
-    save = ops.save_workspace(P, "cuda", pd).zero_()
-    ops.mlp_fwd(pts, vd, spr, ops.pack_weights(flat, "fwd", pd=pd), save, pd=pd)
-    wb, planes = ops.pack_weights(flat, "bwd", pd=pd), ops.pack_planes(flat, pd)
-    out = {}
-    saved = ops.mlp_arithmetic()
-    try:
-        for mode in ("split", "half"):
-            ops.mlp_arithmetic(mode)
-            grads, d_pts, _ = ops.mlp_bwd(d_raw, pts, vd, spr, wb, save, pd=pd, planes=planes)
-            out[mode] = (grads.clone(), d_pts.clone())
-    finally:
-        ops.mlp_arithmetic(saved)
-    Pp = ML.padded_samples(P)
-    off, _ = ML.section_offsets(ML.GRAD_SECTIONS, P)
-    for name, w in ML.GRAD_SECTIONS:
-        rows = lambda t: t[off[name]: off[name] + w * Pp].view(Pp // 32, w // 32, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(Pp, w)[:P]
-        a, b = rows(out["split"][0]).double(), rows(out["half"][0]).double()
-        assert bool(torch.isfinite(b).all()), name
-        size = a.abs().amax(dim=1)
-        err = (a - b).abs().amax(dim=1)
-        assert bool((err <= 2e-5 * size + 1e-44).all()), (name, float((err / (size + 1e-300)).max()))
-        assert not bool(b[::97].any()), name
-    a, b = out["split"][1].double(), out["half"][1].double()
-    assert bool(((a - b).abs().amax(dim=1) <= 1e-4 * a.abs().amax(dim=1) + 1e-44).all())

@@ -8,7 +8,9 @@ import torch
 
 from oracle import nerfpp_oracle as NO
 from scnerf_amd import synthetic as synth
-from test_nerfpp_oracle import G, T
+from test_nerfpp_oracle import G, GS, T
+from tests import parity_attribution as PA
+from tests.parity_attribution import REPORT
 
 pytestmark = pytest.mark.gpu
 ARGS = types.SimpleNamespace(max_freq_log2=10, max_freq_log2_viewdirs=4, netdepth=8, netwidth=256, use_viewdirs=True)
@@ -16,6 +18,24 @@ ARGS = types.SimpleNamespace(max_freq_log2=10, max_freq_log2_viewdirs=4, netdept
 
 def C(k):
     return torch.from_numpy(G[k]).cuda()
+
+
+def CS(k):
+    return torch.from_numpy(GS[k]).cuda()
+
+
+BAR = 1e-4
+
+
+def within_bar(got, ref, what):
+    """the main path's bar: |got - ref| / max(|ref|, 1) <= 1e-4 on EVERY element (absolute for colours, weights and
+    lambda, which live in [0, 1]; relative for metric depths, which do not)"""
+    got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert np.isfinite(got).all(), what
+    e = np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)
+    assert e.max() <= BAR, "%s: max err %g at %s" % (what, e.max(), np.unravel_index(e.argmax(), e.shape))
+    return float(e.max())
 
 
 def close(a, b, tol, what, atol=0.0):
@@ -68,10 +88,17 @@ def test_sampling_helpers_match_reference():
         TR.intersect_sphere(C("kat/ray_o") * 3.0, C("kat/ray_d"))
     z = TR.perturb_samples(C("kat/z"), _t_rand=C("kat/t_rand"))
     np.testing.assert_array_equal(z.cpu().numpy(), G["kat/perturbed"])
-    s = TR.sample_pdf(C("kat/bins"), C("kat/weights"), 40, _u=C("kat/u"))
-    np.testing.assert_allclose(s.cpu().numpy(), G["kat/pdf_samples"], rtol=0, atol=2e-6)
+    # sample_pdf (:83-132) on identical bins / weights / u: cumulated pdf, comparison-count indices and samples BIT-EXACT
+    s, cdf, below, above = TR.sample_pdf_state(C("kat/bins"), C("kat/weights"), C("kat/u"))
+    np.testing.assert_array_equal(cdf.cpu().numpy(), GS["kat/cdf"])
+    np.testing.assert_array_equal(above.cpu().numpy(), GS["kat/above"])
+    np.testing.assert_array_equal(below.cpu().numpy(), GS["kat/below"])
+    np.testing.assert_array_equal(s.cpu().numpy(), G["kat/pdf_samples"])
+    np.testing.assert_array_equal(TR.sample_pdf(C("kat/bins"), C("kat/weights"), 40, _u=C("kat/u")).cpu().numpy(), G["kat/pdf_samples"])
     s_det = TR.sample_pdf(C("kat/bins"), C("kat/weights"), 40, det=True)
-    np.testing.assert_allclose(s_det.cpu().numpy(), G["kat/pdf_det"], rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(s_det.cpu().numpy(), G["kat/pdf_det"])
+    u_det = torch.linspace(0., 1., 40).expand(48, 40).contiguous().cuda()
+    np.testing.assert_array_equal(TR.sample_pdf_state(C("kat/bins"), C("kat/weights"), u_det)[3].cpu().numpy(), GS["kat/above_det"])
     from scnerf_amd.nerfplusplus.ddp_model import depth2pts_outside
     n = 48
     pts, real = depth2pts_outside(C("kat/ray_o")[:, None].expand(n, 16, 3), C("kat/ray_d")[:, None].expand(n, 16, 3),
@@ -90,8 +117,7 @@ def test_nerfnet_forward_and_gradients_vs_reference():
     fg_z = near[:, None] + C("fwd/frac") * (far - near)[:, None]
     ret = net(o, d, far, fg_z, C("fwd/bg_z"))
     assert list(ret.keys()) == ["rgb", "fg_weights", "bg_weights", "fg_rgb", "fg_depth", "bg_rgb", "bg_depth", "bg_lambda"]
-    for name in ret:
-        np.testing.assert_allclose(ret[name].detach().cpu().numpy(), G["fwd/ret/" + name], rtol=5e-4, atol=5e-6, err_msg=name)
+    REPORT["nerfpp_NerfNet_forward_max_err"] = {name: within_bar(ret[name], G["fwd/ret/" + name], name) for name in ret}
     loss = ((ret["rgb"] - C("fwd/target")) ** 2).mean() + (ret["fg_weights"] * C("fwd/gw")).sum() \
         + ret["bg_depth"].mean() * 0.1 + ret["fg_depth"].mean() * 0.1
     assert abs(loss.item() - float(G["fwd/loss"])) <= 2e-5 * abs(float(G["fwd/loss"]))
@@ -105,52 +131,103 @@ def test_nerfnet_forward_and_gradients_vs_reference():
         grad_close(sd[name].grad, G["fwd/g/" + name], name, q=0.99, tol_q=2e-3)
 
 
-def test_two_level_cascade_training_step_vs_reference():
-    """The inner loop of ddp_train_nerf.py:430-489 (64 + 128 samples, foreground and background) with the
-    uniforms injected: both levels' colours, the refined depths, the loss and every gradient."""
+def _cascade_inputs():
     from scnerf_amd.nerfplusplus import ddp_train_nerf as TR
     n, s0, s1 = 32, 64, 128
     rnd = {k: v.cuda() for k, v in synth.nerfpp_randoms(n, s0, s1, seed=26).items()}
-    nets = [make_net(779), make_net(780)]
     o, d = C("step/ray_o").requires_grad_(True), C("step/ray_d").requires_grad_(True)
     near = torch.full((n,), 1e-4, device="cuda")
-    target = C("step/target")
     far = TR.intersect_sphere(o, d)
     step = (far - near) / (s0 - 1)
     fg = torch.stack([near + i * step for i in range(s0)], dim=-1)
     fg = TR.perturb_samples(fg, _t_rand=rnd["t_fg"])
     bg = torch.linspace(0., 1., s0).view(1, s0).expand(n, s0).cuda()
     bg = TR.perturb_samples(bg, _t_rand=rnd["t_bg"])
+    return TR, n, s0, s1, rnd, o, d, far, fg, bg
+
+
+def test_cascade_sampler_on_the_reference_weights_is_bit_exact():
+    """(ddp_train_nerf.py:455-468) the inverse-CDF sampler fed with the REFERENCE's level-0 weights and bin mid points
+    (identical cdf inputs, identical u): cumulated pdf, comparison-count indices (:113) and the 128 new depths bit for bit,
+    foreground and background."""
+    TR = _cascade_inputs()[0]
+    rnd = {k: v.cuda() for k, v in synth.nerfpp_randoms(32, 64, 128, seed=26).items()}
+    for tag in ("fg", "bg"):
+        s, cdf, below, above = TR.sample_pdf_state(CS("step/%s_mid" % tag), CS("step/%s_w0" % tag)[..., 1:-1].contiguous(), rnd["u_" + tag])
+        np.testing.assert_array_equal(cdf.cpu().numpy(), GS["step/%s_cdf" % tag])
+        np.testing.assert_array_equal(above.cpu().numpy(), GS["step/%s_above" % tag])
+        np.testing.assert_array_equal(s.cpu().numpy(), GS["step/%s_samples" % tag])
+
+
+def test_cascade_level_1_on_the_reference_depths():
+    """Level 1 (nets[1], 192 + 192 samples) handed the reference's refined depths: every output within 1e-4 on every ray,
+    the loss, and the gradient of every parameter tensor (fingerprints) at NerfNet's own tolerance."""
+    TR, n, s0, s1, rnd, o, d, far, fg, bg = _cascade_inputs()
+    net = make_net(780)
+    ret1 = net(o, d, far, C("step/fg_depth1"), C("step/bg_depth1"))
+    REPORT["nerfpp_cascade_level1_on_reference_depths_max_err"] = {
+        name: within_bar(ret1[name], GS["step/ret1/" + name], "level 1 " + name) for name in ret1}
+    loss1 = ((ret1["rgb"] - C("step/target")) ** 2).mean()
+    assert abs(loss1.item() - float(GS["step/loss1"])) <= 2e-5 * float(GS["step/loss1"])
+    loss1.backward()
+    for name, p in net.named_parameters():
+        ref_norm, ref_dot = GS["step/gproj1_alone/" + name]
+        norm, dot = NO.grad_fingerprint(name, p.grad)
+        assert abs(norm - ref_norm) <= 5e-3 * ref_norm + 1e-12, (name, norm, ref_norm)
+        assert abs(dot - ref_dot) <= 1.5e-2 * ref_norm + 1e-12, (name, dot, ref_dot)
+
+
+def test_two_level_cascade_training_step_vs_reference():
+    """The inner loop of ddp_train_nerf.py:430-489 (64 + 128 samples, foreground and background) end to end with the
+    uniforms injected.  Level 0: every output of every ray within 1e-4.  Level 1 sits behind the sampler, which is
+    discontinuous in the level-0 weights (search index, `denom < 1e-6` guard; tests/parity_attribution.py): every ray
+    whose samples sit where the reference puts them is within 1e-4, and every ray beyond the bar owns a sample the
+    reference's own algorithm places discontinuously -- none unexplained.  (The sampler itself and level 1 on the
+    reference's depths are pinned strictly by the two tests above.)"""
+    TR, n, s0, s1, rnd, o, d, far, fg, bg = _cascade_inputs()
+    nets = [make_net(779), make_net(780)]
+    target = C("step/target")
     np.testing.assert_allclose(fg.detach().cpu().numpy(), G["step/fg_depth0"], rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(bg.detach().cpu().numpy(), G["step/bg_depth0"], rtol=2e-6, atol=1e-7)
     ret0 = nets[0](o, d, far, fg, bg)
+    REPORT["nerfpp_cascade_level0_max_err"] = {name: within_bar(ret0[name], GS["step/ret0/" + name], "level 0 " + name) for name in ret0}
     loss = ((ret0["rgb"] - target) ** 2).mean()
-    fg_w = ret0["fg_weights"].clone().detach()
-    fg_mid = .5 * (fg[..., 1:] + fg[..., :-1])
-    fg_s = TR.sample_pdf(bins=fg_mid, weights=fg_w[..., 1:-1], N_samples=s1, det=False, _u=rnd["u_fg"])
-    fg1, _ = torch.sort(torch.cat((fg, fg_s), dim=-1))
-    bg_w = ret0["bg_weights"].clone().detach()
-    bg_mid = .5 * (bg[..., 1:] + bg[..., :-1])
-    bg_s = TR.sample_pdf(bins=bg_mid, weights=bg_w[..., 1:-1], N_samples=s1, det=False, _u=rnd["u_bg"])
-    bg1, _ = torch.sort(torch.cat((bg, bg_s), dim=-1))
-    for got, key in ((fg1, "step/fg_depth1"), (bg1, "step/bg_depth1")):
-        # new samples = inverse cdf of the level-0 weights: a 1e-7 difference in a cdf knot moves a sample by
-        # 1e-7 / pdf -- bulk tight, a tail from flat stretches of the cdf
-        e = np.abs(got.detach().cpu().numpy() - G[key])
-        assert (e < 1e-5).mean() > 0.85 and (e < 1e-3).mean() > 0.995, (key, (e < 1e-5).mean(), (e < 1e-3).mean())
-    ret1 = nets[1](o, d, far, fg1, bg1)
+    cls = []
+    depth1 = {}
+    for tag, z in (("fg", fg), ("bg", bg)):
+        w = ret0[tag + "_weights"].clone().detach()
+        mid = .5 * (z[..., 1:] + z[..., :-1])
+        new = TR.sample_pdf(bins=mid, weights=w[..., 1:-1], N_samples=s1, det=False, _u=rnd["u_" + tag])
+        depth1[tag], _ = torch.sort(torch.cat((z, new), dim=-1))
+        _, cdf, _, above = TR.sample_pdf_state(mid.detach(), w[..., 1:-1].contiguous(), rnd["u_" + tag])
+        cls.append(PA.classify_npp(rnd["u_" + tag].cpu(), GS["step/%s_mid" % tag], cdf.cpu(), above.cpu(),
+                                   GS["step/%s_cdf" % tag], GS["step/%s_above" % tag]))
+    cause = PA.merge_causes(*cls)
+    flagged = cause["index"] | cause["branch"] | cause["illcond"]
+    ret1 = nets[1](o, d, far, depth1["fg"], depth1["bg"])
     loss = loss + ((ret1["rgb"] - target) ** 2).mean()
-    np.testing.assert_allclose(ret0["rgb"].detach().cpu().numpy(), G["step/rgb0"], rtol=0, atol=1e-4)
-    e1 = np.abs(ret1["rgb"].detach().cpu().numpy() - G["step/rgb1"]).max(1)
-    assert (e1 < 1e-4).mean() >= 0.9 and e1.max() < 2e-2, ((e1 < 1e-4).mean(), e1.max())
-    assert abs(loss.item() - float(G["step/loss"])) <= 5e-4 * float(G["step/loss"])
+    rep = {"rays": n, "rays_with_a_discontinuously_placed_sample": int(flagged.sum()),
+           "rays_index": int(cause["index"].sum()), "rays_branch": int(cause["branch"].sum()), "rays_illcond": int(cause["illcond"].sum())}
+    REPORT["nerfpp_cascade_32x(64+128)"] = rep
+    for name in ret1:
+        err = PA.per_ray_error(ret1[name], GS["step/ret1/" + name], relative=True)
+        rep[name] = PA.summary(err, cause)
+        assert rep[name]["over_bar_unexplained"] == 0 and rep[name]["max_among_clean_rays"] <= BAR, (name, rep[name])
+    # refined depths: rays whose samplers agree with the reference's carry the same depths (to depth rounding)
+    for tag in ("fg", "bg"):
+        e = np.abs(depth1[tag].detach().cpu().numpy() - G["step/%s_depth1" % tag]).max(1)
+        assert e[~flagged].max() <= 2e-5, (tag, e[~flagged].max())
     loss.backward()
-    grad_close(o.grad, G["step/g_ray_o"], "g_ray_o", q=0.9, tol_q=2e-2, tol_max=0.3)
-    grad_close(d.grad, G["step/g_ray_d"], "g_ray_d", q=0.9, tol_q=2e-2, tol_max=0.3)
-    # level 1 is evaluated at re-sampled depths (see above): its gradients inherit that spread.  The strict
-    # parity of NerfNet itself is test_nerfnet_forward_and_gradients_vs_reference.
+    assert abs(loss.item() - float(G["step/loss"])) <= 5e-4 * float(G["step/loss"])
     check_fingerprints("step/gproj0/", nets[0], rtol=3e-2)
-    check_fingerprints("step/gproj1/", nets[1], rtol=0.15)
+    if not flagged.any():
+        check_fingerprints("step/gproj1/", nets[1], rtol=5e-3)
+        grad_close(o.grad, G["step/g_ray_o"], "g_ray_o", q=0.97, tol_q=2e-3)
+        grad_close(d.grad, G["step/g_ray_d"], "g_ray_d", q=0.97, tol_q=2e-3)
+    else:
+        # (with moved samples in the batch the sums over rays inherit them: level 1's gradients are pinned on the
+        #  reference's depths by test_cascade_level_1_on_the_reference_depths; here only that nothing blows up)
+        check_fingerprints("step/gproj1/", nets[1], rtol=0.15)
 
 
 @pytest.mark.parametrize("tag,key", [("plain", "pinhole_rot_noise_10k_rayo_rayd"), ("dist", "pinhole_rot_noise_10k_rayo_rayd_dist")])

@@ -25,11 +25,11 @@ def test_scene_is_reproducible():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("arithmetic", ["resident", "half", "split", "fp32"])
+@pytest.mark.parametrize("arithmetic", ["resident", "fp32"])
 def test_psnr_trajectory_tracks_the_oracle(arithmetic):
     """Training is chaotic: two runs of the SAME fp32 algorithm whose initial weights differ by a relative 1e-7 are
     0.05-0.25 dB apart while the curve is steep (the CPU oracle's own ensemble in the fixture shows it, and so do eight
-    GPU runs per arithmetic: profiles/psnr_r03.json), so single trajectories are compared loosely and the ENSEMBLE MEANS
+    GPU runs per arithmetic: profiles/psnr_r03.json, collected in round 3 incl. the two retired arithmetics), so single trajectories are compared loosely and the ENSEMBLE MEANS
     -- four runs with the fixture's four perturbations on each side -- statistically: at every checkpoint the two means
     differ by no more than three standard errors of their difference (from the two ensembles' own spreads; never looser
     than 0.25 dB, never tighter than 0.05 dB)."""

@@ -67,10 +67,10 @@ def rays_within(got, ref, tol):
     return float((e <= tol).mean()), float(e.max())
 
 
-@pytest.fixture(params=["split", "fp32", "half", "resident"])
+@pytest.fixture(params=["resident", "fp32"])
 def arithmetic(request):
-    """the golden render_rays cases run in both arithmetic modes of the training step (ops.mlp_arithmetic /
-    ops.wgrad_arithmetic): the default split-arithmetic layer GEMMs and the all-fp32-MFMA kernels"""
+    """the golden render_rays cases run in both arithmetics of the training step (ops.mlp_arithmetic /
+    ops.wgrad_arithmetic): the default resident kernels on three fp16 products and the all-fp32-MFMA yardstick"""
     from scnerf_amd import ops
     saved = (ops.mlp_arithmetic(), ops.wgrad_arithmetic())
     ops.mlp_arithmetic(request.param)
@@ -132,7 +132,7 @@ def test_render_rays_vs_reference_golden(R, golden, tag, arithmetic):
             assert rep[name]["over_bar_unexplained"] == 0, (name, rep[name])
             assert rep[name]["max"] < 1e-2, (name, rep[name])
         rep["coarse_rerun_bit_identical"] = bool(same)      # the re-run IS the coarse stage inside render_rays
-        REPORT["golden/" + tag + ("" if arithmetic == "split" else "/all_fp32_mfma")] = rep
+        REPORT["golden/" + tag + ("" if arithmetic == "resident" else "/all_fp32_mfma")] = rep
         zs = np.abs(ret["z_std"].cpu().numpy() - g[k + "z_std"])
         assert zs[clean].max(initial=0.0) <= 1e-5 + 1e-3 * np.abs(g[k + "z_std"]).max()
     else:
@@ -149,7 +149,7 @@ def test_render_rays_vs_reference_golden(R, golden, tag, arithmetic):
     # rays whose samples sit where the reference places them: the ray gradient holds to 1e-3 of the largest entry
     # but for single ReLU-flip rays -- at most 3 of the 24, and those within 5e-3 (a flipped gate changes one
     # sample's contribution, not the ray); rays with a moved sample are only bounded
-    REPORT.setdefault("golden/" + tag + ("" if arithmetic == "split" else "/all_fp32_mfma"), {})["d_ray_batch"] = dict(
+    REPORT.setdefault("golden/" + tag + ("" if arithmetic == "resident" else "/all_fp32_mfma"), {})["d_ray_batch"] = dict(
         clean_rays=int(clean.sum()), clean_within_1e3=float((ge[clean] < 1e-3).mean()), clean_max=float(ge[clean].max()),
         all_max=float(ge.max()))
     assert (ge[clean] >= 1e-3).sum() <= 3 and ge[clean].max(initial=0.0) < 5e-3 and ge.max() < 0.1, (
@@ -273,7 +273,7 @@ def _headline_oracle(n, sc, sf):
     return _HEADLINE_ORACLE["o32"], _HEADLINE_ORACLE["o64"]
 
 
-@pytest.mark.parametrize("mode", ["resident", "half", "split", "fp32"])
+@pytest.mark.parametrize("mode", ["resident", "fp32"])
 def test_headline_size_against_oracle(R, mode):
     """4096 rays x (64 + 128): the BASELINE.json configuration, against the CPU oracle on the same seeded inputs, in
     every arithmetic of the training step (the report carries the moved-ray counts of each).

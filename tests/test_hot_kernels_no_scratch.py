@@ -11,7 +11,7 @@ import pytest
 from scnerf_amd import _capi
 
 LLVM = "/opt/rocm/lib/llvm/bin"
-HOT = ("mlp_fwd_h3_kernel", "mlp_bwd_h3_kernel", "wgrad256_half_kernel", "wgrad_half_narrow_kernel", "wgrad256_split_kernel", "wgrad256_kernel", "wgrad_tiles_kernel")
+HOT = ("mlp_fwd_h3_kernel", "mlp_bwd_h3_kernel", "wgrad256_half_kernel", "wgrad_half_narrow_kernel", "wgrad256_kernel", "wgrad_tiles_kernel")
 
 
 def _code_objects(tmp_path):
@@ -52,7 +52,7 @@ def test_hot_kernels_have_no_scratch(tmp_path):
                 assert int(pv.group(1)) == 0, (nm.group(1), "private segment", pv.group(1))
     # every variant of the resident kernels and of the big weight-gradient GEMM is there and clean
     for want in ("mlp_fwd_h3_kernelILi3ELb1ELb0", "mlp_fwd_h3_kernelILi3ELb1ELb1", "mlp_fwd_h3_kernelILi3ELb0ELb0",
-                 "mlp_fwd_h3_kernelILi4ELb1ELb0", "mlp_bwd_h3_kernelILi3E", "mlp_bwd_h3_kernelILi4E", "wgrad256_half_kernel", "wgrad256_split_kernel"):
+                 "mlp_fwd_h3_kernelILi4ELb1ELb0", "mlp_bwd_h3_kernelILi3E", "mlp_bwd_h3_kernelILi4E", "wgrad256_half_kernel"):
         assert any(want in k for k in seen), (want, sorted(seen))
     dirty = {k: v for k, v in seen.items() if v}
     assert not dirty, dirty

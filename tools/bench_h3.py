@@ -1,5 +1,5 @@
 """Microbenchmark + parity probe of the resident-arithmetic kernels (csrc/mlp_fwd_h3.hip, mlp_bwd_h3.hip) against the
-fused fp32 kernels and the split-arithmetic path, on the GPU:   python tools/bench_h3.py [--rays 4096] [--out file.json]"""
+fused fp32 kernels, on the GPU:   python tools/bench_h3.py [--rays 4096] [--out file.json]"""
 import argparse
 import json
 import os
@@ -42,7 +42,6 @@ def main():
     flat = torch.cat([p[name].reshape(-1) for name, _ in lay.param_shapes]).float().to(dev)
     wpk = ops.pack_weights(flat, "fwd")
     wbk = ops.pack_weights(flat, "bwd")
-    planes = ops.pack_planes(flat)
     rw = ops.pack_resident(flat)
     P = a.rays * a.spr
     g = torch.Generator().manual_seed(5)
@@ -67,8 +66,6 @@ def main():
         return
     run("fused fp32 train", lambda: ops.mlp_fwd(pts, vd, a.spr, wpk, save_a))
     run("fused fp32 infer", lambda: ops.mlp_fwd(pts, vd, a.spr, wpk, None))
-    ops.mlp_arithmetic("half")
-    run("split(half) train", lambda: ops.mlp_fwd(pts, vd, a.spr, wpk, save_b, planes=planes))
     run("resident train", lambda: ops.mlp_fwd_resident(pts, vd, a.spr, wpk, rw, save_b))
     run("resident infer", lambda: ops.mlp_fwd_resident(pts, vd, a.spr, wpk, rw, None))
     run("pack_resident", lambda: ops.pack_resident(flat, out=rw))
@@ -77,7 +74,6 @@ def main():
     d_raw = torch.randn(P, 4, generator=g).to(dev) * 1e-3
     ops.mlp_fwd(pts, vd, a.spr, wpk, save_a)
     run("fused fp32 dgrad", lambda: ops.mlp_bwd(d_raw, pts, vd, a.spr, wbk, save_a))
-    run("split(half) dgrad", lambda: ops.mlp_bwd(d_raw, pts, vd, a.spr, wbk, save_a, planes=planes))
     run("resident dgrad", lambda: ops.mlp_bwd_resident(d_raw, pts, vd, a.spr, wbk, rw, save_a))
     ga, dpa, dva = ops.mlp_bwd(d_raw, pts, vd, a.spr, wbk, save_a)
     gb, dpb, dvb = ops.mlp_bwd_resident(d_raw, pts, vd, a.spr, wbk, rw, save_a)

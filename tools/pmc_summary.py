@@ -9,15 +9,14 @@ import glob
 import os
 import sys
 
-KEEP = ("mlp_fwd_kernel", "mlp_bwd_kernel", "mlp_fwd_h3_kernel", "mlp_bwd_h3_kernel", "wgrad256_kernel", "wgrad256_split_kernel",
+KEEP = ("mlp_fwd_kernel", "mlp_bwd_kernel", "mlp_fwd_h3_kernel", "mlp_bwd_h3_kernel", "wgrad256_kernel",
         "wgrad256_half_kernel", "wgrad_half_narrow_kernel", "rows4_kernel", "copyBuffer",
-        "layer_split_kernel", "wgrad_tiles_kernel", "wgrad_reduce_multi_kernel", "wgrad_kernel", "vecmat_kernel", "elementwise_kernel")
+        "wgrad_tiles_kernel", "wgrad_reduce_multi_kernel", "wgrad_kernel", "vecmat_kernel", "elementwise_kernel")
 
 # bench.py's region names of the kernels whose HBM traffic goes into profiles/pmc_traffic_r<NN>.json (P = 786432)
 REGIONS = {"mlp_fwd_h3_kernel<3, true, false>": "mlp_fwd_h3_kernel/P=786432/train",
            "mlp_fwd_h3_kernel<3, false, false>": "mlp_fwd_h3_kernel/P=786432/infer",
            "mlp_bwd_h3_kernel<3>": "mlp_bwd_h3_kernel/P=786432",
-           "wgrad256_split_kernel<0>": "wgrad256_kernel<8 GEMMs, split>/P=786432",
            "wgrad256_half_kernel<0>": "wgrad256_kernel<8 GEMMs, half>/P=786432"}
 
 
@@ -51,7 +50,7 @@ def traffic_json(agg, out_path, source, bytes_per_step=None):
         f, w = mean(k, "FETCH_SIZE"), mean(k, "WRITE_SIZE")
         if f is None or w is None:
             continue
-        short = k.replace("void ", "").replace("scn::wg256s::", "").replace("scn::wg256h::", "").replace("scn::wgnh::", "")
+        short = k.replace("void ", "").replace("scn::wg256h::", "").replace("scn::wgnh::", "")
         per[short] = {"fetch_kb_raw": f, "write_kb": w, "bytes": int(w * 1024 + 2 * f * 1024)}
         for pat, region in REGIONS.items():
             if pat in short:
