@@ -1,6 +1,8 @@
 """autograd nodes over the camera kernels (scnerf_amd/csrc/camera_rays.hip)."""
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import ops
@@ -39,25 +41,44 @@ class CameraRaysFunction(torch.autograd.Function):
                 d_gd if need[7] else None)
 
 
+class MatricesMemo:
+    """one (key, (K, E)) entry; see CameraMatricesFunction"""
+    __slots__ = ("key", "pair", "__weakref__")
+
+    def __init__(self):
+        self.key = self.pair = None
+
+
 class CameraMatricesFunction(torch.autograd.Function):
-    """apply(intr_init, intr_noise, intr_scale, multiplicative, extr_init, extr_noise, extr_scale) -> K [4,4], E [C,4,4]:
-    CameraModel.get_intrinsic() and get_extrinsic() (model/camera_model.py:160-192) as one launch each way, differentiable
-    in the two noise tensors."""
+    """apply(intr_init, intr_noise, intr_scale, multiplicative, extr_init, extr_noise, extr_scale, memo) -> K [4,4],
+    E [C,4,4]: CameraModel.get_intrinsic() and get_extrinsic() (model/camera_model.py:160-192) as one launch each way,
+    differentiable in the two noise tensors.  The four tensors are kept with save_for_backward, so an in-place update
+    between forward and backward (an optimizer step) is caught by autograd's version check instead of silently
+    recomputing the Gram-Schmidt step from the new values.  `memo`: the caller's one-entry cache of this node's outputs
+    (a MatricesMemo, or None; held weakly -- the cached outputs own this node); it is emptied when the node's backward
+    runs: the graph behind the cached outputs is gone then."""
 
     @staticmethod
-    def forward(ctx, intr_init, intr_noise, intr_scale, multiplicative, extr_init, extr_noise, extr_scale):
+    def forward(ctx, intr_init, intr_noise, intr_scale, multiplicative, extr_init, extr_noise, extr_scale, memo=None):
         ctx.set_materialize_grads(False)
-        args = (_cf(intr_init), _cf(intr_noise), float(intr_scale), bool(multiplicative), _cf(extr_init), _cf(extr_noise),
-                float(extr_scale))
-        K, E = ops.camera_matrices_fwd(*args)
-        ctx.args = args
+        K, E = ops.camera_matrices_fwd(_cf(intr_init), _cf(intr_noise), float(intr_scale), bool(multiplicative),
+                                       _cf(extr_init), _cf(extr_noise), float(extr_scale))
+        ctx.save_for_backward(intr_init, intr_noise, extr_init, extr_noise)
+        ctx.consts = (float(intr_scale), bool(multiplicative), float(extr_scale))
+        ctx.memo = None if memo is None else weakref.ref(memo)
         return K, E
 
     @staticmethod
     def backward(ctx, g_K, g_E):
+        memo = ctx.memo() if ctx.memo is not None else None
+        if memo is not None:
+            memo.key = memo.pair = None
         need = ctx.needs_input_grad
-        d_in, d_ex = ops.camera_matrices_bwd(*ctx.args, _cf(g_K), _cf(g_E), need[1], need[5])
-        return None, d_in, None, None, None, d_ex, None
+        intr_init, intr_noise, extr_init, extr_noise = ctx.saved_tensors
+        intr_scale, multiplicative, extr_scale = ctx.consts
+        d_in, d_ex = ops.camera_matrices_bwd(_cf(intr_init), _cf(intr_noise), intr_scale, multiplicative, _cf(extr_init),
+                                             _cf(extr_noise), extr_scale, _cf(g_K), _cf(g_E), need[1], need[5])
+        return None, d_in, None, None, None, d_ex, None, None
 
 
 def camera_rays(H, W, camera_model, kps_list, idx_in_camera_param=None, extrinsic=None):

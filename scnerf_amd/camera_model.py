@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 from PIL import Image
 
-from .camera_functional import CameraMatricesFunction, UpsampleGridFunction
+from .camera_functional import CameraMatricesFunction, MatricesMemo, UpsampleGridFunction
 from .camera_utils import *                                     # noqa: F401,F403  (re-exported, as the reference does)
 from .camera_utils import __all__ as _camera_utils_all
 from .camera_utils import (get_44_rotation_matrix_from_33_rotation_matrix, intrinsic_param_to_K,
@@ -124,15 +124,26 @@ class _PinholeRotNoise(CameraModel):
         return p + (r * p if self.multiplicative_noise else r)
 
     def _matrices(self):
-        """(K, E) of the parameters where they live on the device: one launch each way (CameraMatricesFunction) instead
-        of the ~35 tensor ops below and the ~70 of their backward -- most of what one projected-ray-distance term used
-        to launch.  CPU parameters (construction, host-side logging) take the tensor ops."""
+        """(K, E) of the parameters where they live on the device: ONE launch each way for the pair
+        (CameraMatricesFunction) instead of the ~35 tensor ops below and the ~70 of their backward -- most of what one
+        projected-ray-distance term used to launch.  get_intrinsic() and get_extrinsic() of the same parameter values
+        share the node: the pair is memoised per version of the four tensors (and per grad mode) until the node's
+        backward has run.  CPU parameters (construction, host-side logging) take the tensor ops."""
         from . import _capi
         if not _capi.on_device(self.intrinsics_noise):
             return None
-        return CameraMatricesFunction.apply(self.intrinsics_initial, self.intrinsics_noise, self.intrinsics_noise_scale,
+        tensors = (self.intrinsics_initial, self.intrinsics_noise, self.extrinsics_initial, self.extrinsics_noise)
+        key = tuple((t.data_ptr(), t._version, bool(t.requires_grad)) for t in tensors) + (torch.is_grad_enabled(),)
+        memo = self.__dict__.get("_matrices_memo")
+        if memo is None:
+            memo = self.__dict__["_matrices_memo"] = MatricesMemo()
+        if memo.key == key:
+            return memo.pair
+        pair = CameraMatricesFunction.apply(self.intrinsics_initial, self.intrinsics_noise, self.intrinsics_noise_scale,
                                             self.multiplicative_noise, self.extrinsics_initial, self.extrinsics_noise,
-                                            self.extrinsics_noise_scale)
+                                            self.extrinsics_noise_scale, memo)
+        memo.key, memo.pair = key, pair
+        return pair
 
     def get_intrinsic(self):
         fused = self._matrices()

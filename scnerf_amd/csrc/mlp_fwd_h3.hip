@@ -26,12 +26,16 @@ using namespace scn::h3;
 //   h3_scale_partial_kernel  grid (12 layers, 16 row blocks): a block's 16 rows (a wave per row, coalesced along it) ->
 //                            the block's largest |w|, largest row 1-norm, largest |b| and its partial column sums
 //   h3_scale_finish_kernel   grid (12): column sums = the 16 partials added in order; the layer's five numbers
+// A parameter that is not finite (a diverged run) must stay visible at the loss as it does in the reference, where
+// torch.relu and the matrix products carry a NaN through to the colours: the kernels' v_max-based ReLU and maxima drop
+// NaNs, so the scale pass looks at every weight and bias anyway and, if one is NaN or infinite, leaves a NaN in the rgb
+// layer's kPoison slot, which the forward kernel adds to the rgb layer's output scale -- every colour of the launch is NaN.
 constexpr int kScaleBlocks = 16, kScaleCols = 512;
 constexpr int kScalePartial = 4 + kScaleCols;      // floats per (layer, row block)
 
 __global__ __launch_bounds__(256) void h3_scale_partial_kernel(const float* __restrict__ params, const int* __restrict__ jobs,
-                                                               float* __restrict__ partial) {
-    float* red = dynamic_lds<float>();              // [4 waves][3] + [4 waves][512] column partials
+                                                               float* __restrict__ partial, float* __restrict__ table) {
+    float* red = dynamic_lds<float>();              // [4 waves][4] + [4 waves][512] column partials
     float* cols_w = red + 16;
     const int l = blockIdx.x, blk = blockIdx.y, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const float* wt = params + jobs[4 * l];
@@ -39,7 +43,8 @@ __global__ __launch_bounds__(256) void h3_scale_partial_kernel(const float* __re
     const float* bs = params + jobs[4 * l + 3];
     const int per = (rows + kScaleBlocks - 1) / kScaleBlocks;
     const int r0 = blk * per, r1 = min(rows, r0 + per);
-    float mx = 0.f, rowsum = 0.f, bmax = 0.f;
+    if (l == kLayerRgb && blk == 0 && tid == 0) table[kLayerRgb * kScaleStride + kPoison] = 0.f;     // (the finish pass may set it)
+    float mx = 0.f, rowsum = 0.f, bmax = 0.f, bad = 0.f;
     float colp[kScaleCols / 64];
 #pragma unroll
     for (int k = 0; k < kScaleCols / 64; ++k) colp[k] = 0.f;
@@ -56,14 +61,16 @@ __global__ __launch_bounds__(256) void h3_scale_partial_kernel(const float* __re
         for (int o = 32; o > 0; o >>= 1) s += shfl_xor(s, o);
         rowsum = fmaxf(rowsum, s);
         bmax = fmaxf(bmax, fabsf(bs[r]));
+        // (a NaN or an infinity among the row's weights is in its sum; fmaxf drops NaNs)
+        if (!(s < __builtin_huge_valf()) || !(fabsf(bs[r]) < __builtin_huge_valf())) bad = 1.f;
     }
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, shfl_xor(mx, o));
 #pragma unroll
     for (int k = 0; k < kScaleCols / 64; ++k) cols_w[wave * kScaleCols + lane + 64 * k] = colp[k];
-    if (lane == 0) { red[wave * 3] = mx; red[wave * 3 + 1] = rowsum; red[wave * 3 + 2] = bmax; }
+    if (lane == 0) { red[wave * 4] = mx; red[wave * 4 + 1] = rowsum; red[wave * 4 + 2] = bmax; red[wave * 4 + 3] = bad; }
     block_sync();
     float* out = partial + ((long)l * kScaleBlocks + blk) * kScalePartial;
-    if (tid < 3) out[tid] = fmaxf(fmaxf(red[tid], red[3 + tid]), fmaxf(red[6 + tid], red[9 + tid]));
+    if (tid < 4) out[tid] = fmaxf(fmaxf(red[tid], red[4 + tid]), fmaxf(red[8 + tid], red[12 + tid]));
     for (int c = tid; c < kScaleCols; c += 256)
         out[4 + c] = ((cols_w[c] + cols_w[kScaleCols + c]) + cols_w[2 * kScaleCols + c]) + cols_w[3 * kScaleCols + c];
 }
@@ -87,12 +94,14 @@ __global__ __launch_bounds__(256) void h3_scale_finish_kernel(const float* __res
         block_sync();
     }
     if (tid == 0) {
-        float mx = 0.f, rowsum = 0.f, bmax = 0.f;
+        float mx = 0.f, rowsum = 0.f, bmax = 0.f, bad = 0.f;
         for (int b = 0; b < kScaleBlocks; ++b) {
             mx = fmaxf(mx, p[b * kScalePartial]);
             rowsum = fmaxf(rowsum, p[b * kScalePartial + 1]);
             bmax = fmaxf(bmax, p[b * kScalePartial + 2]);
+            bad = fmaxf(bad, p[b * kScalePartial + 3]);
         }
+        if (bad > 0.f) table[kLayerRgb * kScaleStride + kPoison] = __builtin_nanf("");
         const float sw = scn::h3::scale_for(mx);
         float* t = table + l * kScaleStride;
         t[kSw] = sw;
@@ -101,7 +110,8 @@ __global__ __launch_bounds__(256) void h3_scale_finish_kernel(const float* __res
         t[kBoundA] = rowsum * 1.0001f;
         t[kBoundB] = bmax;
         t[kBoundAT] = red[0] * 1.0001f;
-        t[5] = mx; t[6] = 0.f; t[7] = 0.f;
+        t[5] = mx; t[6] = 0.f;
+        if (l != kLayerRgb) t[kPoison] = 0.f;
     }
 }
 
@@ -134,7 +144,7 @@ extern "C" int scnerf_h3_pack(const float* flat_params, const int* jobs, const i
     hipStream_t st = (hipStream_t)stream;
     float* partial = scales + kScaleLayers * kScaleStride;
     hipLaunchKernelGGL(h3_scale_partial_kernel, dim3(kScaleLayers, kScaleBlocks), dim3(256), (16 + 4 * kScaleCols) * 4, st,
-                       flat_params, jobs, partial);
+                       flat_params, jobs, partial, scales);
     hipLaunchKernelGGL(h3_scale_finish_kernel, dim3(kScaleLayers), dim3(256), 1024, st, partial, jobs, scales);
     if (frags_fwd > 0)
         hipLaunchKernelGGL(h3_pack_kernel, dim3(scn_ceil_div(frags_fwd * 512, 256)), dim3(256), 0, st, flat_params, idx_fwd,

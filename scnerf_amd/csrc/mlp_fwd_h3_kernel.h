@@ -386,7 +386,8 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
         constexpr int s = decltype(s_tag)::value;
         xh = bh[1][s]; xl = bl[1][s];
     }, NoFill{});
-    const float os_rgb = inv_pow2(epiv.s_next) * scale_of(kLayerRgb, kSwInv);
+    // (+ 0, or + NaN when a parameter of the network is not finite: mlp_fwd_h3.hip's scale pass)
+    const float os_rgb = __builtin_fmaf(inv_pow2(epiv.s_next), scale_of(kLayerRgb, kSwInv), scale_of(kLayerRgb, kPoison));
     const float sigma = epi7.sg + shfl_xor(epi7.sg, 32) + tables[kTabAlphaB];
     // rows 0, 1, 2 of the single tile are registers 0, 1, 2 of the h == 0 half
     const f32x4 brgb = *reinterpret_cast<const f32x4*>(tables + kTabRgb);

@@ -59,7 +59,7 @@ constexpr int kChunkBytes = 32768;
 constexpr int kStreamLds = 3 * kChunkBytes;
 constexpr int kTableFloats = 2816;                 // the lane-vector tables of the packed buffer (2724 floats), padded
 constexpr int kScaleStride = 8;
-enum : int { kSw = 0, kSwInv = 1, kBoundA = 2, kBoundB = 3, kBoundAT = 4 };
+enum : int { kSw = 0, kSwInv = 1, kBoundA = 2, kBoundB = 3, kBoundAT = 4, kPoison = 7 };   // (kPoison: the rgb layer's row only)
 enum : int { kLayerFeat = 8, kLayerViews = 9, kLayerRgb = 10, kLayerAlpha = 11, kScaleLayers = 12 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));

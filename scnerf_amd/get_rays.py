@@ -29,11 +29,15 @@ class _DeferredKeypointCheck:
     difference.  `flush()` waits for whatever is pending: the host layer calls it where a training loop reaches a
     boundary anyway -- optimizer checkpoints (FusedAdam.state_dict), full-image renders (render_path) -- and at
     interpreter exit (reported on stderr there), so the last batches of a run are checked too; the message names the
-    call it belongs to.  CPU tensors are checked at once."""
+    call it belongs to.  CPU tensors are checked at once.  SCNERF_SYNC_KEYPOINT_CHECK=1 (or `.synchronous = True`)
+    restores the reference's behaviour -- the assertion is raised by the faulty call itself, at the price of the host
+    reads -- for scripts that catch it around the call."""
 
     def __init__(self):
+        import os
         self.pending = []          # (event, pinned flag, message)
         self.calls = 0
+        self.synchronous = os.environ.get("SCNERF_SYNC_KEYPOINT_CHECK", "0") not in ("", "0")
 
     def _raise_if_set(self, flag, message):
         assert not bool(flag.item()), message
@@ -74,7 +78,7 @@ class _DeferredKeypointCheck:
             self._limit(W, H, xy)
         bad = ((xy >= limit) | (xy < 0)).any() if lower else (xy >= limit).any()
         message = "key points outside the %d x %d image (%s call #%d of this process)" % (W, H, what, self.calls)
-        if not bad.is_cuda:
+        if not bad.is_cuda or self.synchronous:
             self._raise_if_set(bad, message)
             return
         host = torch.empty((), dtype=torch.bool, device="cpu", pin_memory=True)      # (explicit: the reference script makes CUDA the default tensor type)

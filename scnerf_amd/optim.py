@@ -196,8 +196,6 @@ class FusedAdam(torch.optim.Optimizer):
         """Same layout as torch.optim.Adam / the reference's CustomAdamOptimizer (`state[i] = {step,
         exp_avg, exp_avg_sq}` per parameter index that has been stepped, `param_groups`): checkpoints
         are interchangeable with the reference's (run_nerf.py:626-641, create_nerf.py:142-172)."""
-        from .get_rays import KEYPOINT_CHECK
-        KEYPOINT_CHECK.flush()                   # a checkpoint boundary: report any out-of-range key-point batch now
         self.state.clear()
         by_id = {id(p): p for p in self.param_groups[0]["params"]}
         for pid, (step, m, v) in self._per_parameter_state().items():
@@ -208,6 +206,15 @@ class FusedAdam(torch.optim.Optimizer):
                              "exp_avg": m.reshape(p.shape).clone(), "exp_avg_sq": v.reshape(p.shape).clone()}
         sd = super().state_dict()
         self.state.clear()
+        # a checkpoint boundary: report any out-of-range key-point batch of the steps so far -- AFTER the state has been
+        # assembled and as a warning: one bad batch (which the reference would have refused when it was drawn) must not
+        # cost the run its checkpoint
+        from .get_rays import KEYPOINT_CHECK
+        try:
+            KEYPOINT_CHECK.flush()
+        except AssertionError as e:
+            import warnings
+            warnings.warn("scnerf_amd.get_rays: %s (found while writing a checkpoint)" % e, RuntimeWarning)
         return sd
 
     def load_state_dict(self, state_dict):

@@ -262,3 +262,50 @@ def test_camera_matrices_match_the_tensor_ops(mult):
     H.call("scnerf_camera_matrices_bwd", f32(intr_init), ctypes.c_float(si), int(mult), f32(extr_init), f32(extr_noise),
            ctypes.c_float(se), C, f32(gK), None, d_in, d_ex2, None)
     assert not d_ex2.any()
+
+
+def test_intrinsic_and_extrinsic_share_one_node_until_its_backward():
+    """CameraModel.get_intrinsic() / get_extrinsic() (model/camera_model.py:160-192) of the same parameter values come from
+    ONE CameraMatricesFunction node (one launch each way for the pair); the pair is dropped when the node's backward has
+    run or a parameter changed; and an in-place parameter update between forward and backward is caught by autograd's
+    version check (save_for_backward) instead of silently differentiating at the new values."""
+    import types
+    from tests.emu.host_on_emu import emulated_device
+    from scnerf_amd.camera_dict import camera_dict
+    H, W = 48, 64
+    spec = synth.camera_spec(H, W, n_cams=3, seed=4, multiplicative=True)
+    args = types.SimpleNamespace(camera_model="pinhole_rot_noise_10k_rayo_rayd", grid_size=10,
+                                 ray_o_noise_scale=spec["ray_o_noise_scale"], ray_d_noise_scale=spec["ray_d_noise_scale"],
+                                 extrinsics_noise_scale=spec["extrinsics_noise_scale"],
+                                 intrinsics_noise_scale=spec["intrinsics_noise_scale"], multiplicative_noise=True)
+    with emulated_device():
+        cm = camera_dict["pinhole_rot_noise_10k_rayo_rayd"](spec["K_init"], list(spec["poses"].numpy()), args, H, W)
+        with torch.no_grad():
+            cm.intrinsics_noise.copy_(spec["intrinsics_noise"])
+            cm.extrinsics_noise.copy_(spec["extrinsics_noise"])
+        K, E = cm.get_intrinsic(), cm.get_extrinsic()
+        assert K.grad_fn is E.grad_fn and K.grad_fn is not None
+        assert cm.get_intrinsic() is K and cm.get_extrinsic() is E
+        with torch.no_grad():
+            assert cm.get_intrinsic() is not K                          # another grad mode: another entry
+        cam = O.camera_state(spec, grad=True)
+        Rw, tw = O.camera_extrinsics(cam)
+        fx, fy, cx, cy = O.camera_intrinsic_params(cam)
+        gK = torch.randn(4, 4, generator=torch.Generator().manual_seed(1))
+        gE = torch.randn(3, 4, 4, generator=torch.Generator().manual_seed(2))
+        K, E = cm.get_intrinsic(), cm.get_extrinsic()
+        ((K * gK).sum() + (E * gE).sum()).backward()
+        ((fx * gK[0, 0] + fy * gK[1, 1] + cx * gK[0, 2] + cy * gK[1, 2]) + (Rw * gE[:, :3, :3]).sum()
+         + (tw * gE[:, :3, 3]).sum()).backward()
+        close(cm.intrinsics_noise.grad.numpy(), cam["intrinsics_noise"].grad.numpy(), 1e-5, "d intrinsics_noise")
+        close(cm.extrinsics_noise.grad.numpy(), cam["extrinsics_noise"].grad.numpy(), 1e-4, "d extrinsics_noise")
+        K2 = cm.get_intrinsic()                                         # the graph behind K is gone: a fresh node
+        assert K2 is not K and torch.equal(K2, K)
+        (K2.sum() + cm.get_extrinsic().sum()).backward()                # ... that can be differentiated again
+        K3 = cm.get_intrinsic()
+        with torch.no_grad():
+            cm.intrinsics_noise.add_(0.01)
+        K4 = cm.get_intrinsic()
+        assert K4 is not K3 and not torch.equal(K4, K3)                 # a new parameter version: recomputed
+        with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+            K3.sum().backward()

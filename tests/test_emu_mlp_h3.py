@@ -229,3 +229,30 @@ def test_narrow_half_weight_gradient_gemms_on_the_interpreter(shape):
     err = np.abs(dW - ref) / scale
     assert err.max() < 3 * 2.0 ** -22 and np.sqrt((err * err).mean()) < 1e-7, (err.max(), np.sqrt((err * err).mean()))
     assert (np.abs(db - dz.astype(np.float64).sum(0)) / np.abs(dz).astype(np.float64).sum(0)).max() < 1e-6
+
+
+@pytest.mark.parametrize("where,value", [("pts_linears.3.weight", float("nan")), ("views_linears.0.bias", float("inf")),
+                                         ("alpha_linear.weight", float("nan"))])
+def test_a_parameter_that_is_not_finite_shows_in_the_colours(where, value):
+    """The reference carries a NaN parameter through torch.relu and every matrix product to the loss
+    (NeRF/run_nerf_helpers.py:105-128).  The resident kernels' ReLU and maxima are v_max-based and drop NaNs, so the scale
+    pass flags a network with a NaN / infinite weight or bias and the forward makes every colour of the launch NaN: a
+    diverged run cannot produce finite-looking renders.  A finite network leaves the flag at exactly 0."""
+    p = network_params(0)
+    wpk = pack_forward(p, 3)
+    fwd, _, sc = pack_h3(p, 3, directions=("fwd",))
+    assert sc[:96].reshape(12, 8)[10, 7] == 0.0 and np.isfinite(sc[:96]).all()
+    bad = {k: v.clone() for k, v in p.items()}
+    bad[where].reshape(-1)[5] = value
+    fwd_b, _, sc_b = pack_h3(bad, 3, directions=("fwd",))
+    assert np.isnan(sc_b[:96].reshape(12, 8)[10, 7])
+    P = 64
+    g = torch.Generator().manual_seed(3)
+    pts = (torch.rand(P, 3, generator=g) * 3 - 1.5)
+    vd = torch.nn.functional.normalize(torch.randn(2, 3, generator=g), dim=-1)
+    raw = np.zeros((P, 4), np.float32)
+    H.call("scnerf_mlp_fwd_h3", 3, pts.numpy(), vd.numpy(), 3, 32, pack_forward(bad, 3), fwd_b, sc_b, raw, None, P, None, 0, 0, None)
+    assert np.isnan(raw[:, :3]).all()
+    raw_ok = np.zeros((P, 4), np.float32)
+    H.call("scnerf_mlp_fwd_h3", 3, pts.numpy(), vd.numpy(), 3, 32, wpk, fwd, sc, raw_ok, None, P, None, 0, 0, None)
+    assert np.isfinite(raw_ok).all()

@@ -268,3 +268,19 @@ def test_key_point_range_check_is_deferred_but_raised(M):
     ro3, _ = M.gr.get_rays_kps_use_camera(HH, WW, cm, good, idx_in_camera_param=4)
     assert torch.equal(ro2, ro3)
     KEYPOINT_CHECK.flush()
+    # the reference's timing on request (SCNERF_SYNC_KEYPOINT_CHECK=1): the faulty call itself raises
+    KEYPOINT_CHECK.synchronous = True
+    try:
+        with pytest.raises(AssertionError):
+            M.gr.get_rays_kps_use_camera(HH, WW, cm, bad, idx_in_camera_param=1)
+        M.gr.get_rays_kps_use_camera(HH, WW, cm, good, idx_in_camera_param=1)
+    finally:
+        KEYPOINT_CHECK.synchronous = False
+    # a pending failure at a checkpoint: a warning after the state is assembled, not a lost checkpoint
+    from scnerf_amd.optim import FusedAdam
+    M.gr.get_rays_kps_use_camera(HH, WW, cm, bad, idx_in_camera_param=1)
+    opt = FusedAdam(list(cm.parameters()), lr=1e-3)
+    with pytest.warns(RuntimeWarning, match="key points outside"):
+        sd = opt.state_dict()
+    assert "param_groups" in sd
+    KEYPOINT_CHECK.flush()

