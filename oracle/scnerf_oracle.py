@@ -214,7 +214,7 @@ def stratified_z(near: Tensor, far: Tensor, n_samples: int, lindisp=False,
 def render_rays(ray_batch: Tensor, coarse, fine, n_samples: int, n_importance: int,
                 t_rand=None, u=None, noise_c=None, noise_f=None, lindisp=False,
                 white_bkgd=False, multires=10, multires_views=4, rowsum="torch",
-                retraw=True):
+                retraw=True, skips=(4,)):
     """render_rays (NeRF/render.py:186-300) with injected randomness.
 
     ray_batch [N, 8 or 11] = [o(3), d(3), near, far, (viewdirs(3))].  `fine` may be
@@ -228,7 +228,7 @@ def render_rays(ray_batch: Tensor, coarse, fine, n_samples: int, n_importance: i
     near, far = ray_batch[:, 6:7], ray_batch[:, 7:8]
     z_c = stratified_z(near, far, n_samples, lindisp, t_rand)
     pts = rays_o[:, None, :] + rays_d[:, None, :] * z_c[:, :, None]
-    raw_c = query_network(coarse, pts, viewdirs, multires, multires_views)
+    raw_c = query_network(coarse, pts, viewdirs, multires, multires_views, skips)
     rgb, disp, acc, w, depth = composite(raw_c, z_c, rays_d, noise_c, white_bkgd)
     out = {"z_coarse": z_c, "weights_coarse": w}
     raw = raw_c
@@ -242,7 +242,7 @@ def render_rays(ray_batch: Tensor, coarse, fine, n_samples: int, n_importance: i
         z_f, _ = torch.sort(torch.cat([z_c, z_s], dim=-1), dim=-1)
         pts = rays_o[:, None, :] + rays_d[:, None, :] * z_f[:, :, None]
         raw = query_network(coarse if fine is None else fine, pts, viewdirs,
-                            multires, multires_views)
+                            multires, multires_views, skips)
         rgb, disp, acc, w, depth = composite(raw, z_f, rays_d, noise_f, white_bkgd)
         out.update(z_samples=z_s, inds=inds, cdf=cdf, z_fine=z_f, weights_fine=w,
                    z_std=torch.std(z_s, dim=-1, unbiased=False))         # :294

@@ -52,38 +52,52 @@ class _QueryFunction(torch.autograd.Function):
         return (d_pts.view(shape), d_v, None, *gs)
 
 
+def _fused_applies(net, embed_fn, embeddirs_fn, viewdirs_given=True) -> bool:
+    """the one configuration the fused kernels are built for: the standard network with multires 10 / 4 encodings"""
+    return (isinstance(net, NeRF) and net.is_standard() and viewdirs_given
+            and getattr(embed_fn, "num_freqs", None) == ML.L_PTS and getattr(embeddirs_fn, "num_freqs", None) == ML.L_VIEWS)
+
+
 def run_network(inputs, viewdirs, fn, embed_fn=None, embeddirs_fn=None, netchunk=1024 * 64):
     """Prepares inputs and applies network `fn` (reference :18-32).  inputs [N, S, 3], viewdirs
-    [N, 3] -> [N, S, 4].  The encodings and the MLP run as one fused kernel, so `netchunk` (a memory
-    workaround of the reference) is accepted and ignored."""
+    [N, 3] -> [N, S, 4].  Standard network + encodings: the encodings and the MLP run as one fused kernel, and
+    `netchunk` (a memory workaround of the reference) is accepted and ignored.  Anything else -- another network
+    shape, other encoding widths, no view directions, a foreign module -- goes exactly the reference's way: embed
+    (the stand-alone encoding kernel), concatenate, `batchify(fn, netchunk)`."""
     net = _unwrap(fn)
-    if not isinstance(net, NeRF):
-        raise TypeError("run_network needs a scnerf_amd.NeRF")
-    net.require_standard()
-    for emb, want in ((embed_fn, ML.L_PTS), (embeddirs_fn, ML.L_VIEWS)):
-        if emb is not None and getattr(emb, "num_freqs", want) != want:
-            raise NotImplementedError("fused kernels are built for multires %d / %d" % (ML.L_PTS, ML.L_VIEWS))
-    if viewdirs is None:
-        raise NotImplementedError("the fused network is the use_viewdirs=True one")
-    return _QueryFunction.apply(inputs, viewdirs, net, *net.ordered_parameters())
+    if _fused_applies(net, embed_fn, embeddirs_fn, viewdirs is not None):
+        return _QueryFunction.apply(inputs, viewdirs, net, *net.ordered_parameters())
+    inputs_flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
+    embedded = embed_fn(inputs_flat)
+    if viewdirs is not None:
+        input_dirs = viewdirs[:, None].expand(inputs.shape)
+        embedded = torch.cat([embedded, embeddirs_fn(torch.reshape(input_dirs, [-1, input_dirs.shape[-1]]).contiguous())], -1)
+    outputs_flat = batchify(fn, netchunk)(embedded)
+    return torch.reshape(outputs_flat, list(inputs.shape[:-1]) + [outputs_flat.shape[-1]])
 
 
 class FusedNetworkQuery:
-    """Callable stand-in for the reference's `network_query_fn` closure (:67-69)."""
+    """Callable stand-in for the reference's `network_query_fn` closure (:67-69): carries the embedders so that
+    render_rays can tell whether the fused kernels apply (`fused_for(net)`) and can otherwise call it like any
+    other closure."""
     is_fused_query = True
 
     def __init__(self, embed_fn, embeddirs_fn, netchunk=None):
         self.embed_fn, self.embeddirs_fn, self.netchunk = embed_fn, embeddirs_fn, netchunk
 
+    def fused_for(self, net) -> bool:
+        return _fused_applies(_unwrap(net), self.embed_fn, self.embeddirs_fn)
+
     def check(self, net: NeRF):
+        """raises unless the fused kernels apply to `net` with these encodings"""
         net.require_standard()
-        if getattr(self.embed_fn, "num_freqs", None) != ML.L_PTS or \
-                getattr(self.embeddirs_fn, "num_freqs", None) != ML.L_VIEWS:
+        if not self.fused_for(net):
             raise NotImplementedError("fused kernels are built for multires %d / multires_views %d"
                                       % (ML.L_PTS, ML.L_VIEWS))
 
     def __call__(self, inputs, viewdirs, network_fn):
-        return run_network(inputs, viewdirs, network_fn, self.embed_fn, self.embeddirs_fn, self.netchunk)
+        return run_network(inputs, viewdirs, network_fn, self.embed_fn, self.embeddirs_fn,
+                           self.netchunk if self.netchunk is not None else 1024 * 64)
 
 
 def batchify(fn, chunk):

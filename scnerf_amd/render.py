@@ -52,13 +52,12 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     dict(t_rand=, u=, noise_c=, noise_f=) instead of drawing them."""
     net_c = _unwrap(network_fn)
     net_f = _unwrap(network_fine) if network_fine is not None else None
-    if not isinstance(net_c, NeRF) or (net_f is not None and not isinstance(net_f, NeRF)):
-        raise TypeError("render_rays needs scnerf_amd.NeRF networks (got %s)" % type(net_c).__name__)
-    if not getattr(network_query_fn, "is_fused_query", False):
-        raise TypeError("network_query_fn must come from scnerf_amd.create_nerf (FusedNetworkQuery)")
-    network_query_fn.check(net_c)
     if not ops._capi.on_device(ray_batch):
         raise RuntimeError("ray_batch must be on the GPU: scnerf_amd has no CPU path")
+    # the fused path: the standard network(s) behind a query object that carries the standard encodings, view directions in
+    # the batch.  Anything else at this boundary is an opaque callable, as in the reference (:186-300): called as it is.
+    fused_for = getattr(network_query_fn, "fused_for", None)
+    fused = (fused_for is not None and fused_for(net_c) and (net_f is None or fused_for(net_f)) and ray_batch.shape[-1] > 8)
     n = ray_batch.shape[0]
     dev = ray_batch.device
     r = _randoms or {}
@@ -85,6 +84,10 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
                 noise_f = torch.Tensor(np.random.rand(n, tot) * raw_noise_std).to(dev)
             else:
                 noise_f = torch.randn((n, tot), device=dev) * raw_noise_std
+    if not fused:
+        return _render_rays_opaque(ray_batch, network_fn, network_query_fn, int(N_samples), retraw, bool(lindisp),
+                                   int(N_importance), network_fine, bool(white_bkgd), t_rand, u, noise_c, noise_f,
+                                   CHECK_NUMERICS or verbose)
     cfg = RenderConfig(int(N_samples), int(N_importance), bool(lindisp), bool(white_bkgd))
     params = list(net_c.ordered_parameters()) + (list(net_f.ordered_parameters()) if net_f is not None else [])
     (rgb_map, disp_map, acc_map, depth_map, raw, rgb0, disp0, acc0, depth0, z_std, z_vals,
@@ -103,6 +106,47 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
             if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():
                 print(f"! [Numerical Error] {k} contains nan or inf.")
     return ret
+
+
+def _render_rays_opaque(ray_batch, network_fn, network_query_fn, N_samples, retraw, lindisp, N_importance, network_fine,
+                        white_bkgd, t_rand, u, noise_c, noise_f, check):
+    """render_rays with `network_query_fn(pts, viewdirs, network_fn)` as an opaque callable (reference :186-300): a
+    network shape the fused kernels do not cover, other encoding widths, `use_viewdirs=False`, or a closure of the
+    caller's own.  Only the network evaluation is the callable's; the per-ray work around it stays on the HIP kernels:
+    stratified depths (coarse_sample), compositing forward / backward (RawToOutputsFunction), the cdf, the wave-ballot
+    search, the inverse cdf and the rank merge (fine_sample) -- same kernels, hence the same sample indices, as the fused
+    path.  The sample positions `o + z d` are the reference's own one-line tensor expression (differentiable in the rays)."""
+    n = ray_batch.shape[0]
+    dev = ray_batch.device
+    rays = ray_batch.contiguous().float()
+    rays_o, rays_d = rays[:, 0:3], rays[:, 3:6]
+    viewdirs = rays[:, -3:] if rays.shape[-1] > 8 else None
+    z_vals, _ = ops.coarse_sample(rays.detach(), host_linspace(N_samples, dev), None if t_rand is None else t_rand.contiguous().float(),
+                                  lindisp)
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+    raw = network_query_fn(pts, viewdirs, network_fn)
+    rgb_map, disp_map, acc_map, weights, _ = RawToOutputsFunction.apply(raw, z_vals, rays_d, noise_c, white_bkgd)
+    ret = {}
+    if N_importance > 0:
+        rgb_map_0, disp_map_0, acc_map_0 = rgb_map, disp_map, acc_map
+        if u is None:                                  # perturb == 0: the deterministic draw (:424-427)
+            u = host_linspace(N_importance, dev)
+        z_vals, _, z_samples, z_std, _, _ = ops.fine_sample(rays.detach(), z_vals, weights.detach().contiguous(),
+                                                            u.contiguous().float())
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+        run_fn = network_fn if network_fine is None else network_fine
+        raw = network_query_fn(pts, viewdirs, run_fn)
+        rgb_map, disp_map, acc_map, weights, _ = RawToOutputsFunction.apply(raw, z_vals, rays_d, noise_f, white_bkgd)
+        ret.update(rgb0=rgb_map_0, disp0=disp_map_0, acc0=acc_map_0, z_std=z_std)
+    out = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map}
+    if retraw:
+        out['raw'] = raw
+    out.update(ret)
+    if check:
+        for k in out:
+            if torch.isnan(out[k]).any() or torch.isinf(out[k]).any():
+                print(f"! [Numerical Error] {k} contains nan or inf.")
+    return out
 
 
 _COLOUR_KEYS = ("rgb0", "rgb1", "rgb_map")

@@ -198,7 +198,8 @@ class NeRF(nn.Module):
         perturbed or partly zeroed encoding raises instead of silently returning the result for other inputs.
         Gradient: d x is placed on those leading columns ONLY (it already contains the encoding's chain rule), so
         embed -> forward differentiates correctly end to end, while x.grad of the sin / cos columns stays zero."""
-        self.require_standard()
+        if not self.is_standard():
+            return self._forward_layer_by_layer(x)
         if x.shape[-1] != self.input_ch + self.input_ch_views:
             raise ValueError("expected %d columns, got %d" % (self.input_ch + self.input_ch_views, x.shape[-1]))
         lead = x.shape[:-1]
@@ -216,6 +217,28 @@ class NeRF(nn.Module):
         from .create_nerf import _QueryFunction
         raw = _QueryFunction.apply(pts.reshape(-1, 1, 3), views, self, *self.ordered_parameters())
         return raw.reshape(*lead, 4)
+
+    def _forward_layer_by_layer(self, x):
+        """Any other shape (D, W, skips, no view directions, another encoding width): the reference's forward as it stands
+        (:105-128), layer by layer on the device's GEMM library -- `x` really is [encoded point | encoded direction] here.
+        The fused kernels exist for the one shape every SCNeRF configuration uses; render_rays takes this route through the
+        caller's `network_query_fn` (render.render_rays: the opaque-callable path) with the sampling, search and compositing
+        still on the HIP kernels."""
+        import torch.nn.functional as F
+        input_pts, input_views = torch.split(x, [self.input_ch, self.input_ch_views], dim=-1)
+        h = input_pts
+        for i, layer in enumerate(self.pts_linears):
+            h = F.relu(layer(h))
+            if i in self.skips:
+                h = torch.cat([input_pts, h], -1)
+        if self.use_viewdirs:
+            alpha = self.alpha_linear(h)
+            feature = self.feature_linear(h)
+            h = torch.cat([feature, input_views], -1)
+            for layer in self.views_linears:
+                h = F.relu(layer(h))
+            return torch.cat([self.rgb_linear(h), alpha], -1)
+        return self.output_linear(h)
 
     def load_weights_from_keras(self, weights):
         """Same tensor order as the reference (:130-157)."""
