@@ -67,7 +67,8 @@ def region_model(name):
     fwd_io = 4 * pd + 16                               # the point in, raw out
     if name.startswith("mlp_fwd_h3_kernel") or name.startswith("mlp_fwd_kernel"):
         products = 3 if "_h3_" in name else None
-        b = fwd_io + (save_b if "/train" in name else 0) + (16 if "coarse stage" in name else 0)
+        # (the fused stages also write the depths and points of their samples: 4 + 12 bytes; the fine stage reads no points)
+        b = fwd_io + (save_b if "/train" in name else 0) + (16 if ("coarse stage" in name or "fine stage" in name) else 0)
         return dict(flop=2 * mac * P, products=products, bytes=b * P)
     if name.startswith("mlp_bwd_h3_kernel") or name.startswith("mlp_bwd_kernel"):
         return dict(flop=2 * mac * P, products=3 if "_h3_" in name else None,

@@ -328,6 +328,22 @@ int scnerf_coarse_stage_fwd_h3(const float* rays, int ray_stride, const float* t
                                float* rgb_map, float* disp_map, float* acc_map, float* depth_map, float* weights,
                                int n_rays, int n_samples, float* chunk_amax, int n_chunks, long long chunk_samples,
                                void* stream);
+/* The whole FINE stage of render_rays (NeRF/render.py:269-285) as one launch in the resident arithmetic: scnerf_fine_sample
+ * (bins = mid points of z_c, weights w_c[1:-1], inverse cdf at u, merge by rank: the stand-alone kernel's own instructions,
+ * csrc/ray_sample.h -- same indices, same depths) in front of the network, raw2outputs (:302-355) behind it.  A workgroup
+ * takes whole rays through passes of 128 samples: n_coarse must be 64 and n_importance 64, 128 or 192 (SCN_ENOSUP
+ * otherwise: use scnerf_fine_sample + scnerf_mlp_fwd_h3 + scnerf_composite_fwd).  Inputs as scnerf_fine_sample (u
+ * [n_rays, n_importance], or one row with u_row_stride 0) and scnerf_mlp_fwd_h3; outputs: z_f [n, 64 + n_importance] and
+ * pts_f [n, 64 + n_importance, 3] (what the data-gradient pass reads), z_samples [n, n_importance], z_std [n], optionally
+ * inds (int64 [n, n_importance]) and cdf [n, 63]; raw [n, 64 + n_importance, 4]; rgb_map [n,3], disp_map, acc_map [n] and
+ * optionally depth_map [n], weights [n, 64 + n_importance]; noise: the density noise [n, 64 + n_importance] or NULL;
+ * save / chunk_amax as scnerf_mlp_fwd_h3. */
+int scnerf_fine_stage_fwd_h3(const float* rays, int ray_stride, const float* z_c, const float* w_c, const float* u,
+                             int u_row_stride, const float* wpacked, const short* stream_fwd, const float* scales,
+                             float* save, const float* noise, int white_bkgd, float* z_f, float* pts_f, float* z_samples,
+                             float* z_std, long long* inds, float* cdf, float* raw, float* rgb_map, float* disp_map,
+                             float* acc_map, float* depth_map, float* weights, int n_rays, int n_coarse, int n_importance,
+                             float* chunk_amax, int n_chunks, long long chunk_samples, void* stream);
 
 /* ------------------------------------------------------------------ PRD loss --------- */
 

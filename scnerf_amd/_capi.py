@@ -75,6 +75,7 @@ PROTOTYPES = {
     "scnerf_mlp_fwd_h3": [I, P, P, I, I, P, P, P, P, P, LL, P, I, LL, P],
     "scnerf_mlp_bwd_h3": [I, P, P, P, I, I, P, P, P, P, P, P, P, LL, P, I, LL, P],
     "scnerf_coarse_stage_fwd_h3": [P, I, P, P, I, P, P, P, P, P, I, P, P, P, P, P, P, P, P, I, I, P, I, LL, P],
+    "scnerf_fine_stage_fwd_h3": [P, I, P, P, P, I, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P, I, LL, P],
     "scnerf_nerf_wgrad_h3": [I, P, P, P, LL, I, P, P, I, P, P, P, P, P, P],
     "scnerf_wgrad256_half": [P, P, LL, I, P, P, P, P, P, P],
     "scnerf_wgrad_half_narrow": [P, I, P, I, I, I, LL, I, P, P, P, P, P, I, LL, P],

@@ -114,6 +114,33 @@ __device__ __forceinline__ unsigned pinned_here(unsigned x) {
     asm volatile("" : "+v"(x));
     return x;
 }
+// The kernel's own argument block, through a pointer the optimiser cannot connect with the arguments it has already loaded:
+// a field read through it is fetched (s_load) where it is used.  For arguments needed only at the very end of a long kernel
+// -- the fine stage's compositing outputs -- this keeps two dozen SGPRs from living across the whole body.  `mirror`: the
+// parameter list restated as a struct (the argument block IS that struct: same members, same order, natural alignment);
+// ignored here, it is what the CPU interpreter's twin of this function returns the address of.
+template <class Args>
+__device__ __forceinline__ const __attribute__((address_space(4))) Args* late_args(const Args& mirror) {
+    (void)mirror;
+    const unsigned long long v = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return reinterpret_cast<const __attribute__((address_space(4))) Args*>(((unsigned long long)hi << 32) | lo);
+}
+// A wave-uniform integer the optimiser must take as NEW where this is called (a volatile empty asm on its SGPR halves):
+// address arithmetic built on it is not invariant in an enclosing loop, so it is not hoisted into registers that then live
+// -- and spill -- across the whole loop body (the fine stage's loop over a workgroup's wave tiles).
+__device__ __forceinline__ long fresh_uniform(long v) {
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long)v >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return (long)(((unsigned long)hi << 32) | lo);
+}
+__device__ __forceinline__ int fresh_uniform(int v) {
+    int x = __builtin_amdgcn_readfirstlane(v);
+    asm volatile("" : "+s"(x));
+    return x;
+}
 __device__ __forceinline__ f32x4 load_f32x4(global_bytes base, unsigned lane_off) {
     return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(base + lane_off);
 }

@@ -185,3 +185,28 @@ extern "C" int scnerf_coarse_stage_fwd_h3(const float* rays, int ray_stride, con
     const scn::h3f::ChunkMaxima cm{chunk_amax, n_chunks, (long)chunk_samples};
     return scn::h3f::fwd_h3_coarse(cs, rays, ray_stride, wpacked, stream_fwd, scales, raw, save, cm, (hipStream_t)stream);
 }
+
+extern "C" int scnerf_fine_stage_fwd_h3(const float* rays, int ray_stride, const float* z_c, const float* w_c, const float* u,
+                                        int u_row_stride, const float* wpacked, const short* stream_fwd, const float* scales,
+                                        float* save, const float* noise, int white_bkgd, float* z_f, float* pts_f,
+                                        float* z_samples, float* z_std, long long* inds, float* cdf, float* raw, float* rgb_map,
+                                        float* disp_map, float* acc_map, float* depth_map, float* weights, int n_rays,
+                                        int n_coarse, int n_importance, float* chunk_amax, int n_chunks,
+                                        long long chunk_samples, void* stream) {
+    SCN_RETURN_IF(!rays || !z_c || !w_c || !u || !wpacked || !stream_fwd || !scales, SCN_EINVAL);
+    SCN_RETURN_IF(!z_f || !pts_f || !z_samples || !z_std || !raw || !rgb_map || !disp_map || !acc_map, SCN_EINVAL);
+    SCN_RETURN_IF(n_rays < 0 || ray_stride < 11 || (u_row_stride != 0 && u_row_stride != n_importance), SCN_EINVAL);
+    // a workgroup takes whole rays through passes of 128 samples: 64 + N_importance in {128, 192, 256}
+    SCN_RETURN_IF(n_coarse != scn::h3f::kCoarseSamples || (n_importance != 64 && n_importance != 128 && n_importance != 192), SCN_ENOSUP);
+    SCN_RETURN_IF((long long)n_rays * (n_coarse + n_importance) >= (1LL << 31), SCN_ENOSUP);     // (31-bit sample indices)
+    SCN_RETURN_IF(chunk_amax && (n_chunks < 1 || chunk_samples < 32 || chunk_samples % 32), SCN_EINVAL);
+    if (n_rays == 0) return 0;
+    const int tot = n_coarse + n_importance;
+    const int rays_per_block = tot == 192 ? 2 : 1, tiles = tot * rays_per_block / 128;
+    const scn::h3f::FineStage fs{rays, ray_stride, n_rays, z_c, w_c, u, u_row_stride, n_importance, z_f, pts_f, z_samples, z_std,
+                                 reinterpret_cast<int64_t*>(inds), cdf, noise, white_bkgd, rgb_map, disp_map, acc_map,
+                                 depth_map, weights, rays_per_block, tiles};
+    const scn::h3f::ChunkMaxima cm{chunk_amax, n_chunks, (long)chunk_samples};
+    return save ? scn::h3f::fwd_h3_fine_train(fs, wpacked, stream_fwd, scales, raw, save, cm, (hipStream_t)stream)
+                : scn::h3f::fwd_h3_fine_infer(fs, wpacked, stream_fwd, scales, raw, cm, (hipStream_t)stream);
+}

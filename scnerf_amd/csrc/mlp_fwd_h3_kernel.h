@@ -7,6 +7,7 @@
 #include "launch.h"
 #include "mlp_fwd_h3_api.h"
 #include "mlp_h3.h"
+#include "ray_sample.h"
 #include "ray_stage.h"
 
 namespace scn {
@@ -112,21 +113,84 @@ struct FwdEpi : std::conditional_t<KIND == 1, Density, NoDensity>, MaskBits<TRAI
 constexpr int kTabFeat = 8 * 256, kTabViews = kTabFeat + 256, kTabRgb = kTabViews + 128, kTabAlpha = kTabRgb + 32,
               kTabAlphaB = kTabAlpha + 256;
 
-template <int PD>
+// STAGE: what the launch does around the network
+//   kPoints  the points are given (`pts`), one wave tile of 32 samples per wave, raw out
+//   kCoarse  the whole coarse stage (NeRF/render.py:235-262): stratified depths in front, compositing behind; a workgroup =
+//            2 rays x 64 samples
+//   kFine    the whole fine stage (NeRF/render.py:269-285): the inverse-CDF sampler + merge in front (ray_sample.h, the
+//            stand-alone sampler's own instructions), compositing behind.  A ray has 64 + N_importance samples, a workgroup
+//            128 per pass over the weight stream: it takes `fs.rays_per_block` whole rays (1, 2, 1 for 128, 192, 256
+//            samples per ray) through `fs.tiles` passes (1, 3, 2), the depths and the raw outputs of its rays parked in LDS.
+enum : int { kPoints = 0, kCoarse = 1, kFine = 2 };
+constexpr int kFineMaxSamples = 384;               // samples of a fine-stage workgroup (rays_per_block x samples per ray)
+
+template <int PD, int STAGE = kPoints>
 __host__ __device__ constexpr unsigned fwd_lds_bytes() {
-    return (unsigned)(kStreamLds + kTableFloats * 4 + Var<PD>::kES * kThreads * 4);
+    return (unsigned)(kStreamLds + kTableFloats * 4 + Var<PD>::kES * kThreads * 4 + (STAGE == kFine ? kFineMaxSamples * 20 : 0));
 }
 
-template <int PD, bool TRAIN, bool COARSE>
+// the parameter list of mlp_fwd_h3_kernel as its argument block lays it out (late_args)
+struct FwdKernelArgs {
+    const float* pts; const float* viewdirs; int vd_stride; int samples_per_ray; const float* wpk; const short* wh3;
+    const float* sc; float* raw; float* save; long P; CoarseStage cs; FineStage fs; ChunkMaxima cm;
+};
+static_assert(sizeof(FwdKernelArgs) == 72 + sizeof(CoarseStage) + sizeof(FineStage) + sizeof(ChunkMaxima), "argument block layout");
+
+template <int PD, bool TRAIN, int STAGE>
 __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
     const float* __restrict__ pts, const float* __restrict__ viewdirs, int vd_stride, int samples_per_ray,
     const float* __restrict__ wpk, const short* __restrict__ wh3, const float* __restrict__ sc,
-    float* __restrict__ raw, float* __restrict__ save_arg, long P, CoarseStage cs, ChunkMaxima cm) {
+    float* __restrict__ raw, float* __restrict__ save_arg, long P, CoarseStage cs, FineStage fs, ChunkMaxima cm) {
     using V = Var<PD>;
     constexpr int ES = V::kES, NE = ES / 8;
+    constexpr bool COARSE = STAGE == kCoarse, FINE = STAGE == kFine;
     float* const save = TRAIN ? save_arg : nullptr;
-    const long wave_tile = (long)blockIdx.x * 4 + uniform(wave_id());      // (a scalar: what derives from it -- section bases, chunk index -- is SALU work)
-    const long Ppad = padded_samples(P);
+    const long Ppad_kernel = padded_samples(P);
+
+    Wave w;
+    w.lds = dynamic_lds<char>();
+    float* const tables = reinterpret_cast<float*>(w.lds + kStreamLds);
+    // fine stage: the merged depths and the raw outputs of the workgroup's rays (behind the parked encoding)
+    float* const zbuf = reinterpret_cast<float*>(w.lds + kStreamLds + kTableFloats * 4 + ES * kThreads * 4);      // [384]
+    f32x4* const rawbuf = reinterpret_cast<f32x4*>(zbuf + kFineMaxSamples);                                        // [384]
+    for (int i = threadIdx.x; i < V::kFwdTotal - V::kFwdBias; i += kThreads) tables[i] = wpk[V::kFwdBias + i];
+    const int tiles = FINE ? uniform(fs.tiles) : 1;
+    if constexpr (FINE) {
+        static_assert(PD == 3, "the fine stage samples 3-D points");
+        // every wave runs the sampler (its pieces synchronise the workgroup): waves 0 .. rays_per_block - 1 own the
+        // workgroup's rays, the others repeat one of them into scratch of their own and write nothing
+        const int wv = uniform(wave_id());
+        const int slot = wv % fs.rays_per_block;
+        long ray = (long)blockIdx.x * fs.rays_per_block + slot;
+        const bool mine = wv < fs.rays_per_block && ray < fs.n_rays;
+        if (ray >= fs.n_rays) ray = fs.n_rays - 1;
+        const int tot = kCoarseSamples + fs.n_importance;
+        float* scratch = reinterpret_cast<float*>(w.lds + kStreamLds + kTableFloats * 4) + wv * ray::fine_sample_lds_floats(kCoarseSamples, fs.n_importance);
+        const float* sorted = ray::fine_sample_ray(
+            fs.rays + ray * fs.ray_stride, fs.z_c + ray * kCoarseSamples, fs.w_c + ray * kCoarseSamples,
+            fs.u + ray * fs.u_row_stride, kCoarseSamples, fs.n_importance, scratch, lane_id(), mine, fs.z_f + ray * tot,
+            fs.pts_f + ray * tot * 3, fs.z_samples + ray * fs.n_importance, fs.z_std + ray,
+            fs.inds ? fs.inds + ray * fs.n_importance : nullptr, fs.cdf ? fs.cdf + ray * (kCoarseSamples - 1) : nullptr);
+        if (wv < fs.rays_per_block)
+            for (int e = lane_id(); e < tot; e += kWave) zbuf[slot * tot + e] = sorted[e];
+        block_sync();                   // the depths are in place; the sampler's scratch (the park area) is free
+    }
+    // (the passes as straight-line code, not a loop: around a loop the register allocation of this 3 600-MFMA body falls
+    //  apart -- 160 spilled registers, with one 16-byte value carried from pass to pass)
+    static_for<FINE ? 3 : 1>([&](auto tile_tag) __attribute__((always_inline)) {
+    constexpr int tile = decltype(tile_tag)::value;
+    // (the last workgroup of an odd ray count: a pass wholly behind the last sample has no slot in the workspaces)
+    if (tile < tiles && (!FINE || ((long)blockIdx.x * tiles + tile) * kSamplesPerBlock < P)) {
+    if (tile > 0) block_sync();         // every wave is done with the stream buffers and the parked encoding of the last pass
+    // (the fine stage's loop: what the section addresses are built from is taken as new in every pass, or the compiler
+    //  hoists two dozen 64-bit section bases out of the loop into SGPRs that live, and spill, across the whole pass)
+    const long Ppad = FINE ? fresh_uniform(Ppad_kernel) : Ppad_kernel;
+    // (the same for the thread's LDS offsets: hoisted, every `base + k * 4096 + thread` beyond the 64 KB an LDS instruction's
+    //  offset field reaches is a register of its own for the whole pass)
+    const unsigned tid = FINE ? pinned_here(threadIdx.x) : threadIdx.x;
+    w.tid16 = tid * 16u;
+    f32x4* const park = reinterpret_cast<f32x4*>(w.lds + kStreamLds + kTableFloats * 4) + tid;
+    const long wave_tile = ((long)blockIdx.x * tiles + tile) * 4 + uniform(wave_id());      // (a scalar: what derives from it -- section bases, chunk index -- is SALU work)
     // Which sample a lane works on is needed at the start (the point), before the views layer (the direction) and at the
     // end (raw, compositing): derived afresh each time from an opaque copy of the lane number -- kept alive across the
     // trunk these 64-bit indices cost six registers of a file that is full (the coarse-stage instantiation spilled).
@@ -147,14 +211,8 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
     const bool live = L0.live;
     (void)m;
 
-    Wave w;
-    w.lds = dynamic_lds<char>();
-    w.tid16 = threadIdx.x * 16u;
     w.lane16 = (unsigned)lane * 16u;
-    float* const tables = reinterpret_cast<float*>(w.lds + kStreamLds);
-    f32x4* const park = reinterpret_cast<f32x4*>(w.lds + kStreamLds + kTableFloats * 4) + threadIdx.x;
     stream_prime(w.ws, wh3, w.lds, w.tid16);
-    for (int i = threadIdx.x; i < V::kFwdTotal - V::kFwdBias; i += kThreads) tables[i] = wpk[V::kFwdBias + i];
 
     // ---- the point, its encoding (parked in LDS for the skip layer), the first operand ----
     float px, py, pz, pw = 0.f;
@@ -174,6 +232,16 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
             cs.z[p] = z;
             cs.pts[p * 3 + 0] = px; cs.pts[p * 3 + 1] = py; cs.pts[p * 3 + 2] = pz;
         }
+    } else if constexpr (FINE) {
+        // the point of the merged depth, as the sampler wrote it to pts_f (same expression, same rounding)
+        const FwdKernelArgs mirror{pts, viewdirs, vd_stride, samples_per_ray, wpk, wh3, sc, raw, save_arg, P, cs, fs, cm};
+        const auto* late = late_args(mirror);          // (read where it is used: see the compositing tail)
+        const float* r = late->fs.rays + (long)((unsigned)pc / (unsigned)samples_per_ray) * late->fs.ray_stride;
+        // (a lane without a sample repeats the last one, as the other stages' kernels do: pc is the clamped index)
+        const float z = zbuf[(int)(pc - (long)blockIdx.x * tiles * kSamplesPerBlock)];
+        px = r[0] + r[3] * z;
+        py = r[1] + r[4] * z;
+        pz = r[2] + r[5] * z;
     } else {
         px = pts[pc * PD + 0]; py = pts[pc * PD + 1]; pz = pts[pc * PD + 2];
         if constexpr (PD == 4) pw = pts[pc * PD + (PD - 1)];
@@ -395,6 +463,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
                      __builtin_fmaf(accc[0][2] + accc[1][2], os_rgb, brgb[2]), sigma};
     const Lane LE = lane_now();
     if (LE.live && LE.h == 0) *reinterpret_cast<f32x4*>(raw + LE.p * 4) = o;
+    if constexpr (FINE) {
+        if (LE.h == 0) rawbuf[tile * kSamplesPerBlock + wave_id() * kSamplesPerWave + LE.m] = o;
+    }
     if constexpr (COARSE) {
         // the parked-encoding area of the LDS is free (last read before the skip layer)
         float* sraw = reinterpret_cast<float*>(w.lds + kStreamLds + kTableFloats * 4);      // [128 samples][4]
@@ -420,6 +491,33 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
                                cs.depth ? cs.depth + ray : nullptr, cs.weights ? cs.weights + ray * kCoarseSamples : nullptr);
         }
     }
+    }});   // (passes)
+    if constexpr (FINE) {
+        block_sync();                   // every pass has left its raw outputs in rawbuf
+        // (what only this tail needs is read from the argument block HERE: as arguments held from the kernel's start, nine
+        //  pointers' worth of SGPRs would live -- and spill -- across every pass)
+        const FwdKernelArgs mirror{pts, viewdirs, vd_stride, samples_per_ray, wpk, wh3, sc, raw, save_arg, P, cs, fs, cm};
+        const auto* late = late_args(mirror);
+        const int rays_per_block = late->fs.rays_per_block;
+        if (wave_id() < rays_per_block) {                                     // one wave per ray, 64 samples per pass
+            const int slot = wave_id(), tot = kCoarseSamples + late->fs.n_importance;
+            const int n_rays = late->fs.n_rays;
+            long ray = (long)blockIdx.x * rays_per_block + slot;
+            const bool ray_live = ray < n_rays;
+            if (!ray_live) ray = n_rays - 1;
+            const float norm = ray::ray_norm(late->fs.rays + ray * late->fs.ray_stride + 3);
+            auto fetch = [&](int i, f32x4* rw, float* zi) {
+                *rw = rawbuf[slot * tot + i];
+                *zi = zbuf[slot * tot + i];
+            };
+            const float* noise = late->fs.noise;
+            float* depth = late->fs.depth;
+            float* weights = late->fs.weights;
+            ray::composite_ray(fetch, tot, norm, noise ? noise + ray * tot : nullptr, late->fs.white_bkgd, ray_live, lane_id(),
+                               late->fs.rgb + ray * 3, late->fs.disp + ray, late->fs.acc + ray, depth ? depth + ray : nullptr,
+                               weights ? weights + ray * tot : nullptr);
+        }
+    }
 }
 
 
@@ -428,10 +526,10 @@ inline int launch_fwd_h3(const float* pts, const float* viewdirs, int vd_stride,
                          const short* wh3, const float* scales, float* raw, float* save, long long n_samples, ChunkMaxima cm,
                          hipStream_t st) {
     constexpr unsigned lds = fwd_lds_bytes<PD>();
-    SCN_LDS_OPT_IN((mlp_fwd_h3_kernel<PD, TRAIN, false>), lds);
-    hipLaunchKernelGGL((mlp_fwd_h3_kernel<PD, TRAIN, false>), dim3(scn_ceil_div(n_samples, kSamplesPerBlock)), dim3(kThreads),
+    SCN_LDS_OPT_IN((mlp_fwd_h3_kernel<PD, TRAIN, kPoints>), lds);
+    hipLaunchKernelGGL((mlp_fwd_h3_kernel<PD, TRAIN, kPoints>), dim3(scn_ceil_div(n_samples, kSamplesPerBlock)), dim3(kThreads),
                        lds, st, pts, viewdirs, vd_stride, samples_per_ray, wpacked, wh3, scales, raw, save, (long)n_samples,
-                       CoarseStage{}, cm);
+                       CoarseStage{}, FineStage{}, cm);
     return scn_launch_status();
 }
 
@@ -441,9 +539,24 @@ inline int launch_coarse_h3(const CoarseStage& cs, const float* rays, int ray_st
                             const float* scales, float* raw, float* save, ChunkMaxima cm, hipStream_t st) {
     constexpr unsigned lds = fwd_lds_bytes<3>();
     const long P = (long)cs.n_rays * kCoarseSamples;
-    SCN_LDS_OPT_IN((mlp_fwd_h3_kernel<3, TRAIN, true>), lds);
-    hipLaunchKernelGGL((mlp_fwd_h3_kernel<3, TRAIN, true>), dim3(scn_ceil_div(P, kSamplesPerBlock)), dim3(kThreads), lds, st,
-                       (const float*)nullptr, rays + 8, ray_stride, kCoarseSamples, wpacked, stream_fwd, scales, raw, save, P, cs, cm);
+    SCN_LDS_OPT_IN((mlp_fwd_h3_kernel<3, TRAIN, kCoarse>), lds);
+    hipLaunchKernelGGL((mlp_fwd_h3_kernel<3, TRAIN, kCoarse>), dim3(scn_ceil_div(P, kSamplesPerBlock)), dim3(kThreads), lds, st,
+                       (const float*)nullptr, rays + 8, ray_stride, kCoarseSamples, wpacked, stream_fwd, scales, raw, save, P, cs,
+                       FineStage{}, cm);
+    return scn_launch_status();
+}
+
+
+template <bool TRAIN>
+inline int launch_fine_h3(const FineStage& fs, const float* wpacked, const short* stream_fwd, const float* scales, float* raw,
+                          float* save, ChunkMaxima cm, hipStream_t st) {
+    constexpr unsigned lds = fwd_lds_bytes<3, kFine>();
+    const int tot = kCoarseSamples + fs.n_importance;
+    const long P = (long)fs.n_rays * tot;
+    SCN_LDS_OPT_IN((mlp_fwd_h3_kernel<3, TRAIN, kFine>), lds);
+    hipLaunchKernelGGL((mlp_fwd_h3_kernel<3, TRAIN, kFine>), dim3(scn_ceil_div(fs.n_rays, fs.rays_per_block)), dim3(kThreads), lds,
+                       st, (const float*)nullptr, fs.rays + 8, fs.ray_stride, tot, wpacked, stream_fwd, scales, raw, save, P,
+                       CoarseStage{}, fs, cm);
     return scn_launch_status();
 }
 

@@ -1,0 +1,160 @@
+// ray_sample.h -- the hierarchical (inverse-CDF) sampler's per-ray pieces, shared by the stand-alone kernels
+// (sampling.hip: sample_pdf, fine_sample) and the fused fine stage (mlp_fwd_h3_kernel.h, STAGE 2), so that the two routes
+// are the SAME instructions and give bit-identical depths and indices.
+//
+//   sample_pdf            /root/reference NeRF/render.py:417-460   (cdf :421-426, search :444, inverse cdf :446-458)
+//   the fine stage's use  /root/reference NeRF/render.py:269-277   (mid points, weights[1:-1], detach, sort of the cat)
+//
+// One 64-lane wave owns one ray; the per-ray arrays live in LDS, private to the wave.  The pieces order their LDS traffic
+// with block_sync(): EVERY wave of the workgroup must call them the same number of times.
+#pragma once
+#include <scn_wave.h>
+
+#include "aten_sum.h"
+
+namespace scn {
+namespace ray {
+
+// cdf[0..nb) from weights w_in[0..nb-1) (already offset); s_w is scratch of >= nb floats
+__device__ inline void build_cdf(const float* w_in, int nb, float* s_w, float* s_cdf, int lane) {
+    const int m = nb - 1;
+    for (int k = lane; k < m; k += kWave) s_w[k] = w_in[k] + 1e-5f;
+    block_sync();
+    if (lane == 0) {
+        const float tot = aten_rowsum(s_w, m);
+        double run = 0.0;
+        s_cdf[0] = 0.f;
+#pragma unroll 1
+        for (int k = 0; k < m; ++k) {
+            const float pdf = s_w[k] / tot;
+            run += (double)pdf;
+            s_cdf[k + 1] = (float)run;
+        }
+    }
+    block_sync();
+}
+
+// upper bound (count of cdf entries <= u) for the ns samples of this ray; inds into s_ind
+__device__ inline void search_right(const float* s_cdf, int nb, const float* s_u, int ns, int* s_ind,
+                             int lane, bool side_left) {
+    if (nb <= kWave) {
+        const float c = lane < nb ? s_cdf[lane] : 0.f;
+#pragma unroll 1      // (fully unrolled these loops cost 248 VGPRs + scratch: one wave per SIMD)
+        for (int j = 0; j < ns; ++j) {
+            const float uq = s_u[j];  // LDS broadcast
+            const bool le = side_left ? (c < uq) : (c <= uq);
+            const unsigned long long m = ballot(lane < nb && le);
+            if (lane == (j & 63)) s_ind[j] = popcount64(m);
+        }
+    } else {
+        for (int j = lane; j < ns; j += kWave) {
+            const float uq = s_u[j];
+            int lo = 0, hi = nb;  // first index with cdf[idx] > u  (>= for side_left)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const float c = s_cdf[mid];
+                const bool go_right = side_left ? (c < uq) : (c <= uq);
+                if (go_right) lo = mid + 1; else hi = mid;
+            }
+            s_ind[j] = lo;
+        }
+    }
+}
+
+__device__ __forceinline__ float invert_cdf(const float* s_cdf, const float* s_bins, int nb,
+                                            float u, int ind) {
+    const int below = max(0, ind - 1);
+    const int above = min(nb - 1, ind);
+    const float c0 = s_cdf[below], c1 = s_cdf[above];
+    const float b0 = s_bins[below], b1 = s_bins[above];
+    float denom = c1 - c0;
+    if (denom < 1e-5f) denom = 1.f;
+    const float t = (u - c0) / denom;
+    return b0 + t * (b1 - b0);
+}
+
+__device__ __forceinline__ bool total_less(float a, int ia, float b, int ib) {
+    // order used by the merge: numbers ascending, NaN last (as torch.sort), ties by position
+    const bool an = a != a, bn = b != b;
+    if (an || bn) return (!an && bn) || (an && bn && ia < ib);
+    return (a < b) || (a == b && ia < ib);
+}
+
+// LDS floats one ray of the fine sampler needs: w, cdf, bins (sc - 1 each), u, indices (sf each), the unsorted and the
+// sorted depths (sc + sf each)
+__host__ __device__ constexpr int fine_sample_lds_floats(int sc, int sf) { return 3 * (sc - 1) + 2 * sf + 2 * (sc + sf); }
+
+// The fine stage's sampling of ONE ray by one wave (NeRF/render.py:269-277): bins = mid points of the coarse depths,
+// weights[1:-1], inverse cdf at u, merged with the coarse depths by rank.  `lds`: fine_sample_lds_floats(sc, sf) floats
+// of this wave.  Writes (when `live`) z_f [sc + sf], pts_f [sc + sf][3] = o + d z, z_samples [sf], z_std [1] and, if given,
+// inds [sf], cdf_out [sc - 1] -- all pointers already at the ray's row.  -> the sorted depths in LDS (sc + sf floats; valid
+// after the call, which ends with a block_sync()).
+__device__ inline const float* fine_sample_ray(const float* __restrict__ ray_row, const float* __restrict__ zc,
+                                               const float* __restrict__ wc, const float* __restrict__ u_row, int sc, int sf,
+                                               float* lds, int lane, bool live, float* __restrict__ z_f,
+                                               float* __restrict__ pts_f, float* __restrict__ z_samples,
+                                               float* __restrict__ z_std, int64_t* __restrict__ inds,
+                                               float* __restrict__ cdf_out) {
+    const int nb = sc - 1, tot = sc + sf;
+    float* s_w = lds;
+    float* s_cdf = s_w + nb;
+    float* s_bins = s_cdf + nb;
+    float* s_u = s_bins + nb;
+    int* s_ind = reinterpret_cast<int*>(s_u + sf);
+    float* s_all = reinterpret_cast<float*>(s_ind + sf);  // [tot] unsorted: z_c then samples
+    float* s_sorted = s_all + tot;                        // [tot]
+    for (int k = lane; k < sc; k += kWave) s_all[k] = zc[k];
+    for (int j = lane; j < sf; j += kWave) s_u[j] = u_row[j];
+    block_sync();
+    for (int k = lane; k < nb; k += kWave) s_bins[k] = 0.5f * (s_all[k + 1] + s_all[k]);
+    // weights[..., 1:-1]  (NeRF/render.py:270)
+    build_cdf(wc + 1, nb, s_w, s_cdf, lane);
+    search_right(s_cdf, nb, s_u, sf, s_ind, lane, false);
+    block_sync();
+    double part = 0.0;
+    for (int j = lane; j < sf; j += kWave) {
+        const float zs = invert_cdf(s_cdf, s_bins, nb, s_u[j], s_ind[j]);
+        s_all[sc + j] = zs;
+        part += (double)zs;
+        if (live) {
+            z_samples[j] = zs;
+            if (inds) inds[j] = (int64_t)s_ind[j];
+        }
+    }
+    if (live && cdf_out)
+        for (int k = lane; k < nb; k += kWave) cdf_out[k] = s_cdf[k];
+    // population std of the new samples (two-pass, fp64)
+    for (int o = 32; o > 0; o >>= 1) part += shfl_xor(part, o);
+    const double mean = part / (double)sf;
+    double var = 0.0;
+    block_sync();
+    for (int j = lane; j < sf; j += kWave) {
+        const double dlt = (double)s_all[sc + j] - mean;
+        var += dlt * dlt;
+    }
+    for (int o = 32; o > 0; o >>= 1) var += shfl_xor(var, o);
+    if (live && lane == 0) *z_std = (float)sqrt(var / (double)sf);
+    // rank merge of the sc + sf depths (values only matter; equals torch.sort of the cat)
+    for (int e = lane; e < tot; e += kWave) {
+        const float v = s_all[e];
+        int rank = 0;
+#pragma unroll 4
+        for (int j = 0; j < tot; ++j) rank += total_less(s_all[j], j, v, e) ? 1 : 0;
+        s_sorted[rank] = v;
+    }
+    block_sync();
+    if (live) {
+        const float ox = ray_row[0], oy = ray_row[1], oz = ray_row[2], dx = ray_row[3], dy = ray_row[4], dz = ray_row[5];
+        for (int e = lane; e < tot; e += kWave) {
+            const float z = s_sorted[e];
+            z_f[e] = z;
+            pts_f[e * 3 + 0] = ox + dx * z;
+            pts_f[e * 3 + 1] = oy + dy * z;
+            pts_f[e * 3 + 2] = oz + dz * z;
+        }
+    }
+    return s_sorted;
+}
+
+}  // namespace ray
+}  // namespace scn

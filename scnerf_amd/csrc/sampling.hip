@@ -11,6 +11,7 @@
 
 #include "aten_sum.h"
 #include "launch.h"
+#include "ray_sample.h"
 #include "ray_stage.h"
 #include "scnerf_hip.h"
 
@@ -20,65 +21,7 @@ using namespace scn;
 
 constexpr int kRaysPerBlock = 4;  // 4 waves / 256 threads
 
-// ---- per-wave pieces (lds arrays are private to the wave; block_sync() orders them) ----
-
-// cdf[0..nb) from weights w_in[0..nb-1) (already offset); s_w is scratch of >= nb floats
-__device__ void build_cdf(const float* w_in, int nb, float* s_w, float* s_cdf, int lane) {
-    const int m = nb - 1;
-    for (int k = lane; k < m; k += kWave) s_w[k] = w_in[k] + 1e-5f;
-    block_sync();
-    if (lane == 0) {
-        const float tot = aten_rowsum(s_w, m);
-        double run = 0.0;
-        s_cdf[0] = 0.f;
-#pragma unroll 1
-        for (int k = 0; k < m; ++k) {
-            const float pdf = s_w[k] / tot;
-            run += (double)pdf;
-            s_cdf[k + 1] = (float)run;
-        }
-    }
-    block_sync();
-}
-
-// upper bound (count of cdf entries <= u) for the ns samples of this ray; inds into s_ind
-__device__ void search_right(const float* s_cdf, int nb, const float* s_u, int ns, int* s_ind,
-                             int lane, bool side_left) {
-    if (nb <= kWave) {
-        const float c = lane < nb ? s_cdf[lane] : 0.f;
-#pragma unroll 1      // (fully unrolled these loops cost 248 VGPRs + scratch: one wave per SIMD)
-        for (int j = 0; j < ns; ++j) {
-            const float uq = s_u[j];  // LDS broadcast
-            const bool le = side_left ? (c < uq) : (c <= uq);
-            const unsigned long long m = ballot(lane < nb && le);
-            if (lane == (j & 63)) s_ind[j] = popcount64(m);
-        }
-    } else {
-        for (int j = lane; j < ns; j += kWave) {
-            const float uq = s_u[j];
-            int lo = 0, hi = nb;  // first index with cdf[idx] > u  (>= for side_left)
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                const float c = s_cdf[mid];
-                const bool go_right = side_left ? (c < uq) : (c <= uq);
-                if (go_right) lo = mid + 1; else hi = mid;
-            }
-            s_ind[j] = lo;
-        }
-    }
-}
-
-__device__ __forceinline__ float invert_cdf(const float* s_cdf, const float* s_bins, int nb,
-                                            float u, int ind) {
-    const int below = max(0, ind - 1);
-    const int above = min(nb - 1, ind);
-    const float c0 = s_cdf[below], c1 = s_cdf[above];
-    const float b0 = s_bins[below], b1 = s_bins[above];
-    float denom = c1 - c0;
-    if (denom < 1e-5f) denom = 1.f;
-    const float t = (u - c0) / denom;
-    return b0 + t * (b1 - b0);
-}
+using namespace scn::ray;
 
 // ------------------------------------------------------------------- kernels ----------
 __global__ __launch_bounds__(256) void searchsorted_kernel(
@@ -149,85 +92,21 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(
     p[2] = r[2] + r[5] * z;
 }
 
-__device__ __forceinline__ bool total_less(float a, int ia, float b, int ib) {
-    // order used by the merge: numbers ascending, NaN last (as torch.sort), ties by position
-    const bool an = a != a, bn = b != b;
-    if (an || bn) return (!an && bn) || (an && bn && ia < ib);
-    return (a < b) || (a == b && ia < ib);
-}
-
 __global__ __launch_bounds__(256) void fine_sample_kernel(
     const float* __restrict__ rays, int ray_stride, const float* __restrict__ z_c,
     const float* __restrict__ w_c, const float* __restrict__ u, int u_row_stride,
     float* __restrict__ z_f, float* __restrict__ pts_f, float* __restrict__ z_samples,
     float* __restrict__ z_std, int64_t* __restrict__ inds, float* __restrict__ cdf_out, int n,
     int sc, int sf, int lds_per_wave) {
-    const int nb = sc - 1, tot = sc + sf;
+    const int tot = sc + sf;
     float* lds = dynamic_lds<float>() + (size_t)wave_id() * lds_per_wave;
-    float* s_w = lds;
-    float* s_cdf = s_w + nb;
-    float* s_bins = s_cdf + nb;
-    float* s_u = s_bins + nb;
-    int* s_ind = reinterpret_cast<int*>(s_u + sf);
-    float* s_all = reinterpret_cast<float*>(s_ind + sf);  // [tot] unsorted: z_c then samples
-    float* s_sorted = s_all + tot;                        // [tot]
-    const int lane = lane_id();
     int ray = blockIdx.x * kRaysPerBlock + wave_id();
     const bool live = ray < n;
     if (!live) ray = n - 1;
-    const float* zc = z_c + (size_t)ray * sc;
-    for (int k = lane; k < sc; k += kWave) s_all[k] = zc[k];
-    for (int j = lane; j < sf; j += kWave) s_u[j] = u[(size_t)ray * u_row_stride + j];
-    block_sync();
-    for (int k = lane; k < nb; k += kWave) s_bins[k] = 0.5f * (s_all[k + 1] + s_all[k]);
-    // weights[..., 1:-1]  (NeRF/render.py:270)
-    build_cdf(w_c + (size_t)ray * sc + 1, nb, s_w, s_cdf, lane);
-    search_right(s_cdf, nb, s_u, sf, s_ind, lane, false);
-    block_sync();
-    double part = 0.0;
-    for (int j = lane; j < sf; j += kWave) {
-        const float zs = invert_cdf(s_cdf, s_bins, nb, s_u[j], s_ind[j]);
-        s_all[sc + j] = zs;
-        part += (double)zs;
-        if (live) {
-            z_samples[(size_t)ray * sf + j] = zs;
-            if (inds) inds[(size_t)ray * sf + j] = (int64_t)s_ind[j];
-        }
-    }
-    if (live && cdf_out)
-        for (int k = lane; k < nb; k += kWave) cdf_out[(size_t)ray * nb + k] = s_cdf[k];
-    // population std of the new samples (two-pass, fp64)
-    for (int o = 32; o > 0; o >>= 1) part += shfl_xor(part, o);
-    const double mean = part / (double)sf;
-    double var = 0.0;
-    block_sync();
-    for (int j = lane; j < sf; j += kWave) {
-        const double dlt = (double)s_all[sc + j] - mean;
-        var += dlt * dlt;
-    }
-    for (int o = 32; o > 0; o >>= 1) var += shfl_xor(var, o);
-    if (live && lane == 0) z_std[ray] = (float)sqrt(var / (double)sf);
-    // rank merge of the sc + sf depths (values only matter; equals torch.sort of the cat)
-    for (int e = lane; e < tot; e += kWave) {
-        const float v = s_all[e];
-        int rank = 0;
-#pragma unroll 4
-        for (int j = 0; j < tot; ++j) rank += total_less(s_all[j], j, v, e) ? 1 : 0;
-        s_sorted[rank] = v;
-    }
-    block_sync();
-    if (live) {
-        const float* r = rays + (size_t)ray * ray_stride;
-        const float ox = r[0], oy = r[1], oz = r[2], dx = r[3], dy = r[4], dz = r[5];
-        for (int e = lane; e < tot; e += kWave) {
-            const float z = s_sorted[e];
-            const size_t o = (size_t)ray * tot + e;
-            z_f[o] = z;
-            pts_f[o * 3 + 0] = ox + dx * z;
-            pts_f[o * 3 + 1] = oy + dy * z;
-            pts_f[o * 3 + 2] = oz + dz * z;
-        }
-    }
+    ray::fine_sample_ray(rays + (size_t)ray * ray_stride, z_c + (size_t)ray * sc, w_c + (size_t)ray * sc,
+                         u + (size_t)ray * u_row_stride, sc, sf, lds, lane_id(), live, z_f + (size_t)ray * tot,
+                         pts_f + (size_t)ray * tot * 3, z_samples + (size_t)ray * sf, z_std + ray,
+                         inds ? inds + (size_t)ray * sf : nullptr, cdf_out ? cdf_out + (size_t)ray * (sc - 1) : nullptr);
 }
 
 }  // namespace
@@ -284,7 +163,7 @@ extern "C" int scnerf_fine_sample(const float* rays, int ray_stride, const float
     SCN_RETURN_IF(n < 0 || sc < 3 || sf < 1 || ray_stride < 8, SCN_EINVAL);
     SCN_RETURN_IF(u_row_stride != 0 && u_row_stride != sf, SCN_EINVAL);
     if (n == 0) return 0;
-    const int per_wave = 3 * (sc - 1) + 2 * sf + 2 * (sc + sf);
+    const int per_wave = ray::fine_sample_lds_floats(sc, sf);
     const size_t lds = (size_t)per_wave * 4 * kRaysPerBlock;
     SCN_RETURN_IF(lds > 160 * 1024, SCN_ENOSUP);
     hipLaunchKernelGGL(fine_sample_kernel, dim3(scn_ceil_div(n, kRaysPerBlock)), dim3(256), lds,

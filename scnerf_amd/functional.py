@@ -104,7 +104,6 @@ class RenderRaysFunction(torch.autograd.Function):
 
         fine_net = net_f if net_f is not None else net_c
         u_dev = _c(u) if u is not None else host_linspace(sf, dev)
-        z_f, pts_f, z_s, z_std, _, _ = ops.fine_sample(rays, z_c, w_c, u_dev)
         tot = sc + sf
         fine_net.require_standard()
         flat_f = fine_net.flat_parameters()
@@ -112,9 +111,15 @@ class RenderRaysFunction(torch.autograd.Function):
         save_f = ops.save_workspace(n * tot, dev) if train else None
         pl_f = pl_c if fine_net is net_c else (ops.pack_for_arithmetic(flat_f, train) if n > 0 else None)
         mx_f = ops.ChunkMaxima(n * tot, dev) if (train and resident) else None
-        raw_f = ops.mlp_fwd(pts_f, viewdirs, tot, wf_f, save_f, planes=pl_f, maxima=mx_f).view(n, tot, 4)
-        rgb_f, disp_f, acc_f, _, depth_f = ops.composite_fwd(raw_f, z_f, rays, _c(noise_f), cfg.white_bkgd,
-                                                             want_weights=False)
+        if resident and sc == ops.COARSE_STAGE_SAMPLES and sf in ops.FINE_STAGE_IMPORTANCE and n > 0:
+            # the whole fine stage -- inverse-cdf sampler, merge, network, compositing -- is one launch
+            z_f, pts_f, z_s, z_std, _, _, raw_f, rgb_f, disp_f, acc_f, depth_f, _ = ops.fine_stage_fwd(
+                rays, z_c, w_c, u_dev, wf_f, save_f, _c(noise_f), cfg.white_bkgd, pl_f, maxima=mx_f)
+        else:
+            z_f, pts_f, z_s, z_std, _, _ = ops.fine_sample(rays, z_c, w_c, u_dev)
+            raw_f = ops.mlp_fwd(pts_f, viewdirs, tot, wf_f, save_f, planes=pl_f, maxima=mx_f).view(n, tot, 4)
+            rgb_f, disp_f, acc_f, _, depth_f = ops.composite_fwd(raw_f, z_f, rays, _c(noise_f), cfg.white_bkgd,
+                                                                 want_weights=False)
         ctx.fine = (z_f, pts_f, raw_f, _c(noise_f), save_f, mx_f)
         ctx.pl_f = pl_f
         ctx.wb_f = (ctx.wb_c if fine_net is net_c else ops.pack_weights(flat_f, "bwd")) if train else None

@@ -422,6 +422,58 @@ def coarse_stage_fwd(rays: Tensor, t_vals: Tensor, t_rand: Optional[Tensor], lin
     return z, pts, raw, rgb, disp, acc, w, depth
 
 
+FINE_STAGE_IMPORTANCE = (64, 128, 192)       # the fused fine stage exists for 64 + N_importance = 128, 192, 256 samples per ray
+
+
+def fine_stage_fwd(rays: Tensor, z_c: Tensor, w_c: Tensor, u: Tensor, wpacked: Tensor, save: Optional[Tensor],
+                   noise: Optional[Tensor], white_bkgd: bool, planes: "ResidentWeights", maxima: Optional["ChunkMaxima"] = None,
+                   want_inds=False, want_cdf=False, want_weights=False):
+    """fine_sample + mlp_fwd + composite_fwd of the fine stage as ONE launch (resident arithmetic; 64 coarse samples and
+    N_importance in FINE_STAGE_IMPORTANCE): -> (z_f [n,tot], pts_f [n,tot,3], z_samples [n,sf], z_std [n], inds, cdf,
+    raw [n,tot,4], rgb [n,3], disp [n], acc [n], depth [n], weights)."""
+    _f(rays, "rays"), _f(z_c, "z_c"), _f(w_c, "w_c"), _f(u, "u"), _f(wpacked, "wpacked")
+    for name, t_ in (("noise", noise), ("save", save)):
+        if t_ is not None:
+            _f(t_, name)
+    if not isinstance(planes, ResidentWeights) or planes.pd != 3:
+        raise TypeError("the fused fine stage runs on the resident arithmetic (3-D points)")
+    n, sc = z_c.shape
+    sf = u.shape[-1]
+    if sc != COARSE_STAGE_SAMPLES or sf not in FINE_STAGE_IMPORTANCE or rays.shape[1] < 11:
+        raise ValueError("the fused fine stage takes 64 coarse samples, N_importance in %s and an 11-column ray batch" % (FINE_STAGE_IMPORTANCE,))
+    tot = sc + sf
+    stride = sf if u.dim() == 2 else 0
+    lay = ML.layout(3)
+    if wpacked.numel() != lay.fwd_total:
+        raise ValueError("wpacked has the wrong size")
+    if save is not None and save.numel() < lay.save_floats(n * tot):
+        raise ValueError("activation workspace too small")
+    dev = rays.device
+    z_f = torch.empty((n, tot), dtype=torch.float32, device=dev)
+    pts_f = torch.empty((n, tot, 3), dtype=torch.float32, device=dev)
+    z_s = torch.empty((n, sf), dtype=torch.float32, device=dev)
+    z_std = torch.empty((n,), dtype=torch.float32, device=dev)
+    inds = torch.empty((n, sf), dtype=torch.int64, device=dev) if want_inds else None
+    cdf = torch.empty((n, sc - 1), dtype=torch.float32, device=dev) if want_cdf else None
+    raw = torch.empty((n, tot, 4), dtype=torch.float32, device=dev)
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    disp = torch.empty((n,), dtype=torch.float32, device=dev)
+    acc = torch.empty((n,), dtype=torch.float32, device=dev)
+    depth = torch.empty((n,), dtype=torch.float32, device=dev)
+    w = torch.empty((n, tot), dtype=torch.float32, device=dev) if want_weights else None
+    P = n * tot
+    mx = maxima if save is not None else None
+    with PROFILE.region("mlp_fwd_h3_kernel<fine stage>/P=%d/%s" % (P, "train" if save is not None else "infer"),
+                        2 * _MAC_PER_SAMPLE[3] * P):
+        st = _capi.load().scnerf_fine_stage_fwd_h3(
+            _p(rays), rays.shape[1], _p(z_c), _p(w_c), _p(u), stride, _p(wpacked), _p(planes.fwd), _p(planes.scales), _p(save),
+            _p(noise), int(bool(white_bkgd)), _p(z_f), _p(pts_f), _p(z_s), _p(z_std), _p(inds), _p(cdf), _p(raw), _p(rgb),
+            _p(disp), _p(acc), _p(depth), _p(w), n, sc, sf, _p(mx.x) if mx else None, mx.chunks if mx else 0,
+            mx.chunk_samples if mx else 0, _stream())
+    _capi.check(st, "scnerf_fine_stage_fwd_h3")
+    return z_f, pts_f, z_s, z_std, inds, cdf, raw, rgb, disp, acc, depth, w
+
+
 def save_workspace(P: int, device, pd: int = 3) -> Tensor:
     return torch.empty(ML.layout(pd).save_floats(P), dtype=torch.float32, device=device)
 

@@ -41,3 +41,8 @@ def f32(a):
 def call(name, *args):
     st = getattr(lib(), name)(*[ptr(a) if isinstance(a, np.ndarray) or a is None else a for a in args])
     assert st == 0, "%s returned %d" % (name, st)
+
+
+def lib_call_status(name, *args):
+    """as call(), returning the status instead of asserting it"""
+    return getattr(lib(), name)(*[ptr(a) if isinstance(a, np.ndarray) or a is None else a for a in args])

@@ -128,6 +128,9 @@ typedef const char* global_bytes;
 inline global_bytes uniform_global(const void* p) { return static_cast<const char*>(p); }
 inline global_bytes uniform_global(global_bytes p) { return p; }
 inline unsigned pinned_here(unsigned x) { return x; }
+template <class Args> inline const Args* late_args(const Args& mirror) { return &mirror; }
+inline long fresh_uniform(long v) { return v; }
+inline int fresh_uniform(int v) { return v; }
 inline unsigned long long shader_cycles() { return 0; }
 inline unsigned long long reference_ticks() { return 0; }
 typedef char* global_bytes_rw;

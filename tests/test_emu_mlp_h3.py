@@ -256,3 +256,56 @@ def test_a_parameter_that_is_not_finite_shows_in_the_colours(where, value):
     raw_ok = np.zeros((P, 4), np.float32)
     H.call("scnerf_mlp_fwd_h3", 3, pts.numpy(), vd.numpy(), 3, 32, wpk, fwd, sc, raw_ok, None, P, None, 0, 0, None)
     assert np.isfinite(raw_ok).all()
+
+
+@pytest.mark.parametrize("n,sf,train,det", [(3, 128, True, False), (2, 64, False, False), (1, 192, True, True)])
+def test_fused_fine_stage_equals_the_three_launches(n, sf, train, det):
+    """scnerf_fine_stage_fwd_h3 (sampler + merge in front of the resident network, compositing behind, whole rays through
+    passes of 128 samples; NeRF/render.py:269-285) against scnerf_fine_sample -> scnerf_mlp_fwd_h3 -> scnerf_composite_fwd on
+    the same inputs: the same device code on the same numbers -- every output BIT-identical, including the search indices,
+    the activation workspace and (odd ray counts) the last workgroup's half-empty pass."""
+    from scnerf_amd import synthetic as synth
+    sc, tot = 64, 64 + sf
+    p = network_params(1)
+    wpk = pack_forward(p, 3)
+    fwd, _, scales = pack_h3(p, 3, directions=("fwd",))
+    rays = synth.ray_batch(n, seed=4).numpy()
+    g = torch.Generator().manual_seed(9)
+    z_c = torch.sort(torch.rand(n, sc, generator=g), -1)[0].numpy()
+    w_c = (torch.rand(n, sc, generator=g) ** 4).numpy()
+    w_c[0, 10:50] = 0.0                                            # empty bins: the `denom < 1e-5` branch
+    u = torch.linspace(0, 1, sf).numpy() if det else torch.rand(n, sf, generator=g).numpy()
+    noise = (torch.randn(n, tot, generator=g) * 0.5).numpy()
+    lay = ML.layout(3)
+    P = n * tot
+
+    def outputs():
+        return dict(z_f=np.full((n, tot), np.nan, np.float32), pts=np.full((n, tot, 3), np.nan, np.float32),
+                    z_s=np.full((n, sf), np.nan, np.float32), z_std=np.full(n, np.nan, np.float32),
+                    inds=np.full((n, sf), -1, np.int64), cdf=np.full((n, sc - 1), np.nan, np.float32),
+                    raw=np.full((n, tot, 4), np.nan, np.float32), rgb=np.full((n, 3), np.nan, np.float32),
+                    disp=np.full(n, np.nan, np.float32), acc=np.full(n, np.nan, np.float32), depth=np.full(n, np.nan, np.float32),
+                    w=np.full((n, tot), np.nan, np.float32), save=np.full(lay.save_floats(P), np.nan, np.float32) if train else None)
+    a, b = outputs(), outputs()
+    stride = 0 if det else sf
+    H.call("scnerf_fine_sample", rays, 11, z_c, w_c, u, stride, a["z_f"], a["pts"], a["z_s"], a["z_std"], a["inds"], a["cdf"], n, sc, sf, None)
+    vd = np.ascontiguousarray(rays[:, 8:11])
+    H.call("scnerf_mlp_fwd_h3", 3, a["pts"], vd, 3, tot, wpk, fwd, scales, a["raw"], a["save"], P, None, 0, 0, None)
+    H.call("scnerf_composite_fwd", a["raw"], a["z_f"], rays, 11, noise, 1, a["rgb"], a["disp"], a["acc"], a["depth"], a["w"], n, tot, None)
+    H.call("scnerf_fine_stage_fwd_h3", rays, 11, z_c, w_c, u, stride, wpk, fwd, scales, b["save"], noise, 1, b["z_f"], b["pts"],
+           b["z_s"], b["z_std"], b["inds"], b["cdf"], b["raw"], b["rgb"], b["disp"], b["acc"], b["depth"], b["w"], n, sc, sf,
+           None, 0, 0, None)
+    for k in a:
+        if a[k] is None:
+            continue
+        x, y = a[k], b[k]
+        if k == "save":                                             # (padding slots of the last wave tile are never written)
+            ok = ~np.isnan(x)
+            assert np.array_equal(np.isnan(x), np.isnan(y)), k
+            x, y = x[ok], y[ok]
+        assert not np.isnan(y).any(), k
+        np.testing.assert_array_equal(x.view(np.int32) if x.dtype == np.float32 else x, y.view(np.int32) if y.dtype == np.float32 else y, err_msg=k)
+    # shapes the fused stage does not cover are refused, not approximated
+    assert H.lib_call_status("scnerf_fine_stage_fwd_h3", rays, 11, z_c, w_c, u, stride, wpk, fwd, scales, None, noise, 1, b["z_f"], b["pts"],
+                             b["z_s"], b["z_std"], None, None, b["raw"], b["rgb"], b["disp"], b["acc"], None, None, n, sc, 100,
+                             None, 0, 0, None) != 0

@@ -495,3 +495,41 @@ def test_resident_data_gradients_follow_the_fused_chain_row_by_row(ops):
         size = a.double().abs().max(1)[0]
         err = (a.double() - b.double()).abs().max(1)[0]
         assert bool((err <= 1e-4 * size + 1e-45).all()), (what, float((err / size.clamp_min(1e-300)).max()))
+
+
+@pytest.mark.parametrize("n,sf,train", [(4096, 128, True), (1025, 128, False), (777, 64, True), (300, 192, True)])
+def test_fused_fine_stage_equals_the_three_launches(ops, n, sf, train):
+    """scnerf_fine_stage_fwd_h3 -- the fine stage of render_rays (NeRF/render.py:269-285) as ONE launch: inverse-cdf sampler
+    and merge in front of the resident network, compositing behind, whole rays through passes of 128 samples -- against
+    fine_sample -> mlp_fwd (resident) -> composite_fwd: the same device code on the same numbers, so every output is
+    bit-identical: depths, search indices, cdf, points, raw, maps, weights, the activation workspace and the chunk maxima."""
+    from tests.emu_mlp_util import network_params
+    sc, tot = 64, 64 + sf
+    flat = dev(_flat(network_params(4, 3), 3))
+    wf, rw = ops.pack_weights(flat, "fwd"), ops.pack_resident(flat)
+    rays = synth.ray_batch(n, seed=4).cuda()
+    g = torch.Generator().manual_seed(9)
+    z_c = torch.sort(torch.rand(n, sc, generator=g), -1)[0].cuda()
+    w_c = (torch.rand(n, sc, generator=g) ** 4)
+    w_c[::7, 10:50] = 0.0                                          # empty bins: the `denom < 1e-5` branch
+    w_c = w_c.cuda()
+    u = torch.rand(n, sf, generator=g).cuda()
+    noise = (torch.randn(n, tot, generator=g) * 0.5).cuda()
+    P = n * tot
+    save_a = ops.save_workspace(P, "cuda").fill_(float("nan")) if train else None
+    save_b = ops.save_workspace(P, "cuda").fill_(float("nan")) if train else None
+    mx_a, mx_b = (ops.ChunkMaxima(P, "cuda"), ops.ChunkMaxima(P, "cuda")) if train else (None, None)
+    z_f, pts_f, z_s, z_std, inds, cdf = ops.fine_sample(rays, z_c, w_c, u, True, True)
+    raw = ops.mlp_fwd(pts_f, rays[:, 8:11], tot, wf, save_a, planes=rw, maxima=mx_a).view(n, tot, 4)
+    rgb, disp, acc, w, depth = ops.composite_fwd(raw, z_f, rays, noise, True)
+    got = ops.fine_stage_fwd(rays, z_c, w_c, u, wf, save_b, noise, True, rw, maxima=mx_b, want_inds=True, want_cdf=True,
+                             want_weights=True)
+    want = (z_f, pts_f, z_s, z_std, inds, cdf, raw, rgb, disp, acc, depth, w)
+    names = ("z_f", "pts_f", "z_samples", "z_std", "inds", "cdf", "raw", "rgb", "disp", "acc", "depth", "weights")
+    for name, a, b in zip(names, want, got):
+        assert torch.equal(a, b), (name, n, sf)
+    if train:
+        wrote = ~torch.isnan(save_a)
+        assert torch.equal(wrote, ~torch.isnan(save_b))
+        assert torch.equal(save_a[wrote].view(torch.int32), save_b[wrote].view(torch.int32))
+        assert torch.equal(mx_a.x, mx_b.x)

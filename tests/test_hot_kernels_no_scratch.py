@@ -51,8 +51,8 @@ def test_hot_kernels_have_no_scratch(tmp_path):
             if nm and pv and any(h in nm.group(1) for h in HOT):
                 assert int(pv.group(1)) == 0, (nm.group(1), "private segment", pv.group(1))
     # every variant of the resident kernels and of the big weight-gradient GEMM is there and clean
-    for want in ("mlp_fwd_h3_kernelILi3ELb1ELb0", "mlp_fwd_h3_kernelILi3ELb1ELb1", "mlp_fwd_h3_kernelILi3ELb0ELb0",
-                 "mlp_fwd_h3_kernelILi4ELb1ELb0", "mlp_bwd_h3_kernelILi3E", "mlp_bwd_h3_kernelILi4E", "wgrad256_half_kernel"):
+    for want in ("mlp_fwd_h3_kernelILi3ELb1ELi0E", "mlp_fwd_h3_kernelILi3ELb1ELi1E", "mlp_fwd_h3_kernelILi3ELb0ELi0E", "mlp_fwd_h3_kernelILi3ELb1ELi2E", "mlp_fwd_h3_kernelILi3ELb0ELi2E",
+                 "mlp_fwd_h3_kernelILi4ELb1ELi0E", "mlp_bwd_h3_kernelILi3E", "mlp_bwd_h3_kernelILi4E", "wgrad256_half_kernel"):
         assert any(want in k for k in seen), (want, sorted(seen))
     dirty = {k: v for k, v in seen.items() if v}
     assert not dirty, dirty

@@ -14,8 +14,10 @@ KEEP = ("mlp_fwd_kernel", "mlp_bwd_kernel", "mlp_fwd_h3_kernel", "mlp_bwd_h3_ker
         "wgrad_tiles_kernel", "wgrad_reduce_multi_kernel", "wgrad_kernel", "vecmat_kernel", "elementwise_kernel")
 
 # bench.py's region names of the kernels whose HBM traffic goes into profiles/pmc_traffic_r<NN>.json (P = 786432)
-REGIONS = {"mlp_fwd_h3_kernel<3, true, false>": "mlp_fwd_h3_kernel/P=786432/train",
-           "mlp_fwd_h3_kernel<3, false, false>": "mlp_fwd_h3_kernel/P=786432/infer",
+REGIONS = {"mlp_fwd_h3_kernel<3, true, 0>": "mlp_fwd_h3_kernel/P=786432/train",
+           "mlp_fwd_h3_kernel<3, false, 0>": "mlp_fwd_h3_kernel/P=786432/infer",
+           "mlp_fwd_h3_kernel<3, true, 2>": "mlp_fwd_h3_kernel<fine stage>/P=786432/train",
+           "mlp_fwd_h3_kernel<3, false, 2>": "mlp_fwd_h3_kernel<fine stage>/P=786432/infer",
            "mlp_bwd_h3_kernel<3>": "mlp_bwd_h3_kernel/P=786432",
            "wgrad256_half_kernel<0>": "wgrad256_kernel<8 GEMMs, half>/P=786432"}
 

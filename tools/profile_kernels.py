@@ -32,6 +32,15 @@ def main():
     mx = ops.ChunkMaxima(P, "cuda")
     for _ in range(reps):
         ops.mlp_fwd(pts, vd, 192, wf, save, planes=rw, maxima=mx)
+    # the fused fine stage (what the default step launches): sampler + network + compositing of 4096 rays x (64 + 128)
+    rays = synth.ray_batch(4096, seed=1).cuda()
+    z_c = torch.sort(torch.rand(4096, 64, device="cuda"), -1)[0]
+    w_c = torch.rand(4096, 64, device="cuda") ** 4
+    u = torch.rand(4096, 128, device="cuda")
+    for _ in range(reps):
+        ops.fine_stage_fwd(rays, z_c, w_c, u, wf, None, None, False, rw)
+    for _ in range(reps):
+        ops.fine_stage_fwd(rays, z_c, w_c, u, wf, save, None, False, rw, maxima=mx)
     for _ in range(reps):
         grads, d_pts, d_views = ops.mlp_bwd(d_raw, pts, vd, 192, wb, save, planes=rw, maxima=mx)
     for _ in range(reps):
