@@ -111,8 +111,9 @@ class RenderRaysFunction(torch.autograd.Function):
         save_f = ops.save_workspace(n * tot, dev) if train else None
         pl_f = pl_c if fine_net is net_c else (ops.pack_for_arithmetic(flat_f, train) if n > 0 else None)
         mx_f = ops.ChunkMaxima(n * tot, dev) if (train and resident) else None
-        if resident and sc == ops.COARSE_STAGE_SAMPLES and sf in ops.FINE_STAGE_IMPORTANCE and n > 0:
-            # the whole fine stage -- inverse-cdf sampler, merge, network, compositing -- is one launch
+        if ops.fused_fine_stage() and resident and sc == ops.COARSE_STAGE_SAMPLES and sf in ops.FINE_STAGE_IMPORTANCE and n > 0:
+            # the whole fine stage -- inverse-cdf sampler, merge, network, compositing -- as one launch (opt-in: measured
+            # slower than the three launches below, ops.fused_fine_stage)
             z_f, pts_f, z_s, z_std, _, _, raw_f, rgb_f, disp_f, acc_f, depth_f, _ = ops.fine_stage_fwd(
                 rays, z_c, w_c, u_dev, wf_f, save_f, _c(noise_f), cfg.white_bkgd, pl_f, maxima=mx_f)
         else:
