@@ -437,3 +437,29 @@ def test_headline_size_invariants(R):
     g_all, g_a, g_b = grads(0, n), grads(0, n // 2), grads(n // 2, n)
     scale = float(g_all.abs().max())
     assert float((g_all - (g_a + g_b)).abs().max()) <= 2e-5 * scale
+
+
+def test_render_rays_with_the_fused_fine_stage_is_bit_identical(R):
+    """ops.fused_fine_stage(True): render_rays takes the fine stage as one launch (scnerf_fine_stage_fwd_h3) instead of
+    three -- the same device code on the same numbers: every output and every gradient bit for bit (odd ray count: the last
+    workgroup's second ray is empty)."""
+    n, sc, sf = 1025, 64, 128
+    rays = synth.ray_batch(n, seed=1).cuda()
+    rnd = {k: v.cuda() for k, v in synth.render_randoms(n, sc, sf, seed=3).items()}
+    target = synth.target_rgb(n, seed=2).cuda()
+    results = []
+    saved = R["ops"].fused_fine_stage()
+    try:
+        for fused in (False, True):
+            R["ops"].fused_fine_stage(fused)
+            net_c, net_f = make_net(R, 0), make_net(R, 1)
+            rd = rays.clone().requires_grad_(True)
+            ret = R["render"].render_rays(rd, net_c, make_query(R), sc, retraw=True, perturb=1.0, N_importance=sf,
+                                          network_fine=net_f, raw_noise_std=1.0, _randoms=rnd)
+            (torch.mean((ret["rgb_map"] - target) ** 2) + torch.mean((ret["rgb0"] - target) ** 2)).backward()
+            results.append(([ret[k].detach() for k in ("rgb_map", "disp_map", "acc_map", "raw", "rgb0", "z_std")],
+                            [p.grad.clone() for p in list(net_c.parameters()) + list(net_f.parameters())] + [rd.grad.clone()]))
+    finally:
+        R["ops"].fused_fine_stage(saved)
+    for a, b in zip(results[0][0] + results[0][1], results[1][0] + results[1][1]):
+        assert torch.equal(a, b)
