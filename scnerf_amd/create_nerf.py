@@ -35,16 +35,20 @@ class _QueryFunction(torch.autograd.Function):
         train = any(ctx.needs_input_grad)
         flat = net.flat_parameters()
         save = ops.save_workspace(p.shape[0], p.device) if train else None
-        raw = ops.mlp_fwd(p, v, spr, ops.pack_weights(flat, "fwd"), save)
-        ctx.state = (p, v, spr, save, ops.pack_weights(flat, "bwd") if train else None, shape, viewdirs.shape)
+        # the arithmetic in force (ops.mlp_arithmetic), as in render_rays: the resident kernels' streams + the chunk maxima
+        # their weight-gradient GEMMs scale by, or the fused fp32-MFMA kernels
+        planes = ops.pack_for_arithmetic(flat, train) if p.shape[0] > 0 else None
+        maxima = ops.ChunkMaxima(p.shape[0], p.device) if (train and isinstance(planes, ops.ResidentWeights)) else None
+        raw = ops.mlp_fwd(p, v, spr, ops.pack_weights(flat, "fwd"), save, planes=planes, maxima=maxima)
+        ctx.state = (p, v, spr, save, ops.pack_weights(flat, "bwd") if train else None, shape, viewdirs.shape, planes, maxima)
         return raw.view(*shape[:-1], 4)
 
     @staticmethod
     def backward(ctx, g_raw):
-        p, v, spr, save, wbk, shape, vshape = ctx.state
+        p, v, spr, save, wbk, shape, vshape, planes, maxima = ctx.state
         d_raw = g_raw.reshape(-1, 4).contiguous().float()
-        grads, d_pts, d_views = ops.mlp_bwd(d_raw, p, v, spr, wbk, save)
-        flat_grad = ops.nerf_wgrad(save, grads, d_raw, p.shape[0])
+        grads, d_pts, d_views = ops.mlp_bwd(d_raw, p, v, spr, wbk, save, planes=planes, maxima=maxima)
+        flat_grad = ops.nerf_wgrad(save, grads, d_raw, p.shape[0], maxima=maxima)
         d_v = d_views.view(-1, spr, 3).sum(1).view(vshape)
         gs = [flat_grad[ML.PARAM_OFFSETS[n]: ML.PARAM_OFFSETS[n] + int(torch.Size(s).numel())].view(s)
               for n, s in ML.PARAM_SHAPES]
