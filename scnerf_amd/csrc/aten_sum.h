@@ -82,4 +82,20 @@ __device__ inline float aten_rowsum(const float* w, int m) {
     return acc;
 }
 
+// aten_rowsum by a whole wave: the eight vector lanes' sums are formed by eight GPU lanes side by side -- each with ATen's
+// own sequence of additions -- and then added in order by every lane alike: bit-identical to aten_rowsum at about an
+// eighth of its latency (the serial version is one lane walking the row through LDS, a round trip per element).  Every
+// lane of the wave must call it; the result is the same in every lane.
+__device__ inline float aten_rowsum_wave(const float* w, int m, int lane) {
+    if (m < 8) return aten_lane_sum(w, 1, m);
+    const int nv = m >> 3;
+    float acc = 0.f;
+#pragma unroll 1
+    for (int k = nv * 8; k < m; ++k) acc += w[k];
+    const float mine = aten_lane_sum(w + (lane & 7), 8, nv);       // lanes 0 .. 7: the eight vector lanes (the others repeat them)
+#pragma unroll
+    for (int v = 0; v < 8; ++v) acc += read_lane(mine, v);
+    return acc;
+}
+
 }  // namespace scn

@@ -183,6 +183,17 @@ __device__ __forceinline__ int shfl(int v, int src_lane) { return __shfl(v, src_
 __device__ __forceinline__ int shfl_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ int shfl_up(int v, int delta) { return __shfl_up(v, delta, 64); }
 
+// the value lane `k` holds, k the same in every lane (a wave-uniform index: v_readlane_b32, no LDS crossbar, no latency
+// to speak of -- what the samplers' serial sections are built on)
+__device__ __forceinline__ float read_lane(float v, int k) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k));
+}
+__device__ __forceinline__ double read_lane(double v, int k) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, k);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), k);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ int popcount64(unsigned long long m) { return __popcll(m); }
 

@@ -15,12 +15,27 @@
 namespace scn {
 namespace ray {
 
-// cdf[0..nb) from weights w_in[0..nb-1) (already offset); s_w is scratch of >= nb floats
+// cdf[0..nb) from weights w_in[0..nb-1) (already offset); s_w is scratch of >= nb floats.
+// Up to 64 knots (the render path's 63) the wave works side by side: ATen's row sum with its eight vector lanes on eight GPU
+// lanes (aten_rowsum_wave), one division per lane, and the fp64 running sum -- sequential, as torch.cumsum's -- fed from the
+// lanes' registers (read_lane) instead of one lane walking the row through LDS with a round trip per element.  Same
+// operations in the same order on the same numbers: bit-identical to the one-lane form, which larger rows keep.
 __device__ inline void build_cdf(const float* w_in, int nb, float* s_w, float* s_cdf, int lane) {
     const int m = nb - 1;
     for (int k = lane; k < m; k += kWave) s_w[k] = w_in[k] + 1e-5f;
     block_sync();
-    if (lane == 0) {
+    if (nb <= kWave) {
+        const float tot = aten_rowsum_wave(s_w, m, lane);
+        const double pd = lane < m ? (double)(s_w[lane] / tot) : 0.0;
+        double run = 0.0;
+        float mine = 0.f;                                   // lane k ends up with cdf[k]; cdf[0] = 0
+#pragma unroll 4
+        for (int k = 0; k < m; ++k) {
+            run += read_lane(pd, k);
+            if (lane == k + 1) mine = (float)run;
+        }
+        if (lane < nb) s_cdf[lane] = mine;
+    } else if (lane == 0) {
         const float tot = aten_rowsum(s_w, m);
         double run = 0.0;
         s_cdf[0] = 0.f;
@@ -34,17 +49,25 @@ __device__ inline void build_cdf(const float* w_in, int nb, float* s_w, float* s
     block_sync();
 }
 
-// upper bound (count of cdf entries <= u) for the ns samples of this ray; inds into s_ind
+// upper bound (count of cdf entries <= u) for the ns samples of this ray; inds into s_ind.  Up to 64 knots: a knot per
+// lane, one v_cmp + ballot + s_bcnt1 per sample, the sample's u broadcast from the registers of the lane that holds it.
 __device__ inline void search_right(const float* s_cdf, int nb, const float* s_u, int ns, int* s_ind,
-                             int lane, bool side_left) {
+                                    int lane, bool side_left) {
     if (nb <= kWave) {
         const float c = lane < nb ? s_cdf[lane] : 0.f;
-#pragma unroll 1      // (fully unrolled these loops cost 248 VGPRs + scratch: one wave per SIMD)
-        for (int j = 0; j < ns; ++j) {
-            const float uq = s_u[j];  // LDS broadcast
-            const bool le = side_left ? (c < uq) : (c <= uq);
-            const unsigned long long m = ballot(lane < nb && le);
-            if (lane == (j & 63)) s_ind[j] = popcount64(m);
+#pragma unroll 1
+        for (int j0 = 0; j0 < ns; j0 += kWave) {
+            const int nj = min(kWave, ns - j0);
+            const float ub = lane < nj ? s_u[j0 + lane] : 0.f;
+            int mine = 0;
+#pragma unroll 4
+            for (int jj = 0; jj < nj; ++jj) {
+                const float uq = read_lane(ub, jj);
+                const bool le = side_left ? (c < uq) : (c <= uq);
+                const int cnt = popcount64(ballot(lane < nb && le));
+                if (lane == jj) mine = cnt;
+            }
+            if (lane < nj) s_ind[j0 + lane] = mine;
         }
     } else {
         for (int j = lane; j < ns; j += kWave) {
@@ -78,6 +101,60 @@ __device__ __forceinline__ bool total_less(float a, int ia, float b, int ib) {
     const bool an = a != a, bn = b != b;
     if (an || bn) return (!an && bn) || (an && bn && ia < ib);
     return (a < b) || (a == b && ia < ib);
+}
+
+// s_sorted[rank(e)] = s_all[e] for the tot values of a ray, rank by total_less (numbers ascending, NaN last, ties by
+// position: torch.sort of the concatenation).  Up to 256 values the wave holds them in registers (lane l: values l, l + 64,
+// ...), walks e, and COUNTS the values that sort before value e with ballots -- v_cmp + s_bcnt1 per 64 values -- instead of
+// every lane walking all values through LDS (192 x 192 LDS round trips and ~8 VALU per pair: the former 11 us of a ray).
+__device__ inline void rank_merge(const float* s_all, int tot, float* s_sorted, int lane) {
+    constexpr int NB = 4;
+    if (tot > NB * kWave) {
+        for (int e = lane; e < tot; e += kWave) {
+            const float v = s_all[e];
+            int rank = 0;
+#pragma unroll 4
+            for (int j = 0; j < tot; ++j) rank += total_less(s_all[j], j, v, e) ? 1 : 0;
+            s_sorted[rank] = v;
+        }
+        return;
+    }
+    // (slots behind the last value hold +inf: never below anything, and behind every real value in position)
+    float v[NB];
+    unsigned long long nan_at[NB], real_at[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const bool has = b * kWave + lane < tot;
+        v[b] = has ? s_all[b * kWave + lane] : __builtin_huge_valf();
+        real_at[b] = ballot(has);
+        nan_at[b] = ballot(has && v[b] != v[b]);
+    }
+#pragma unroll
+    for (int eb = 0; eb < NB; ++eb) {
+        const int ne = min(kWave, tot - eb * kWave);
+#pragma unroll 2
+        for (int el = 0; el < ne; ++el) {
+            const float ve = read_lane(v[eb], el);
+            const unsigned long long before = (1ull << el) - 1ull;      // lanes of block eb in front of value e
+            int rank = 0;
+            if (ve == ve) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    if (b * kWave >= tot) break;
+                    rank += popcount64(ballot(v[b] < ve));
+                    const unsigned long long eq = ballot(v[b] == ve);
+                    rank += b < eb ? popcount64(eq) : b == eb ? popcount64(eq & before) : 0;
+                }
+            } else {                                                    // a NaN: behind every number, among NaNs by position
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    rank += popcount64(real_at[b] & ~nan_at[b]);
+                    rank += b < eb ? popcount64(nan_at[b]) : b == eb ? popcount64(nan_at[b] & before) : 0;
+                }
+            }
+            if (lane == 0) s_sorted[rank] = ve;
+        }
+    }
 }
 
 // LDS floats one ray of the fine sampler needs: w, cdf, bins (sc - 1 each), u, indices (sf each), the unsorted and the
@@ -135,13 +212,7 @@ __device__ inline const float* fine_sample_ray(const float* __restrict__ ray_row
     for (int o = 32; o > 0; o >>= 1) var += shfl_xor(var, o);
     if (live && lane == 0) *z_std = (float)sqrt(var / (double)sf);
     // rank merge of the sc + sf depths (values only matter; equals torch.sort of the cat)
-    for (int e = lane; e < tot; e += kWave) {
-        const float v = s_all[e];
-        int rank = 0;
-#pragma unroll 4
-        for (int j = 0; j < tot; ++j) rank += total_less(s_all[j], j, v, e) ? 1 : 0;
-        s_sorted[rank] = v;
-    }
+    rank_merge(s_all, tot, s_sorted, lane);
     block_sync();
     if (live) {
         const float ox = ray_row[0], oy = ray_row[1], oz = ray_row[2], dx = ray_row[3], dy = ray_row[4], dz = ray_row[5];

@@ -182,6 +182,8 @@ inline double shfl_xor(double v, int m) { return shfl_xor_t(v, m); }
 inline double shfl_up(double v, int d) { return shfl_up_t(v, d); }
 inline double shfl_down(double v, int d) { return shfl_down_t(v, d); }
 inline int shfl(int v, int s) { return shfl_t(v, s); }
+inline float read_lane(float v, int k) { return shfl_t(v, k); }
+inline double read_lane(double v, int k) { return shfl_t(v, k); }
 inline int shfl_xor(int v, int m) { return shfl_xor_t(v, m); }
 inline int shfl_up(int v, int d) { return shfl_up_t(v, d); }
 

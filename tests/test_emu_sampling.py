@@ -99,7 +99,7 @@ def test_coarse_sample_bit_exact(lindisp, perturb):
     np.testing.assert_array_equal(pts, po.numpy())
 
 
-@pytest.mark.parametrize("sc,sf,det", [(64, 128, False), (64, 64, False), (64, 128, True), (16, 24, False)])
+@pytest.mark.parametrize("sc,sf,det", [(64, 128, False), (64, 64, False), (64, 128, True), (16, 24, False), (64, 200, False), (64, 192, False)])
 def test_fine_sample_bit_exact(sc, sf, det):
     n = 10
     g = torch.Generator().manual_seed(sc + sf)
@@ -129,3 +129,32 @@ def test_fine_sample_bit_exact(sc, sf, det):
     np.testing.assert_array_equal(z_f, zf_o.numpy())
     np.testing.assert_array_equal(pts_f, pts_o.numpy())
     np.testing.assert_allclose(z_std, torch.std(so, dim=-1, unbiased=False).numpy(), rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("sc,sf", [(64, 128), (40, 33), (64, 200)])
+def test_fine_sample_merge_is_torch_sort_with_ties_and_nans(sc, sf):
+    """The rank merge of the fine sampler (ballot counts over register-held values up to 256 depths, the pairwise walk beyond)
+    against torch.sort of the concatenation [z_c | new samples] on rows with repeated depths, +-0, infinities and NaNs
+    (NaN last, ties by position): the merged row bit for bit, the new samples taken from the kernel's own output."""
+    n = 6
+    g = torch.Generator().manual_seed(sc * 7 + sf)
+    rays = synth.ray_batch(n, seed=3)
+    z_c = torch.sort(torch.rand(n, sc, generator=g), -1)[0]
+    z_c[0, 5:9] = z_c[0, 5]                         # repeated coarse depths
+    z_c[1, 0] = 0.0
+    z_c[1, 1] = -0.0                                # equal in value, different in bits
+    z_c[2, -1] = float("inf")
+    z_c[3, 10] = float("nan")                       # (its bins are NaN too: NaN samples, several of them)
+    z_c[4] = 0.25                                   # every depth the same
+    w_c = torch.rand(n, sc, generator=g) ** 3
+    w_c[5, 2:-2] = 0.0                              # flat cdf: many samples on one spot
+    u = torch.rand(n, sf, generator=g)
+    u[5, : sf // 2] = 0.5
+    tot = sc + sf
+    z_f = np.zeros((n, tot), np.float32)
+    pts_f = np.zeros((n, tot, 3), np.float32)
+    z_s = np.zeros((n, sf), np.float32)
+    z_std = np.zeros((n,), np.float32)
+    H.call("scnerf_fine_sample", rays.numpy(), 11, z_c.numpy(), w_c.numpy(), u.numpy(), sf, z_f, pts_f, z_s, z_std, None, None, n, sc, sf, None)
+    want = torch.sort(torch.cat([z_c, torch.from_numpy(z_s)], -1), dim=-1, stable=True)[0].numpy()
+    np.testing.assert_array_equal(z_f.view(np.int32), want.view(np.int32))
