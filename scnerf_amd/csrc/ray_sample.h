@@ -103,13 +103,64 @@ __device__ __forceinline__ bool total_less(float a, int ia, float b, int ib) {
     return (a < b) || (a == b && ia < ib);
 }
 
-// s_sorted[rank(e)] = s_all[e] for the tot values of a ray, rank by total_less (numbers ascending, NaN last, ties by
-// position: torch.sort of the concatenation).  Up to 256 values the wave holds them in registers (lane l: values l, l + 64,
-// ...), walks e, and COUNTS the values that sort before value e with ballots -- v_cmp + s_bcnt1 per 64 values -- instead of
-// every lane walking all values through LDS (192 x 192 LDS round trips and ~8 VALU per pair: the former 11 us of a ray).
+// ---- the merge: s_sorted = torch.sort of the tot values in s_all (numbers ascending, -0 and +0 equal, NaN last, ties by
+// position: total_less).  Up to 256 values: a bitonic network over (key, position) pairs held four per lane -- 36 stages of
+// compare-exchange, the strides 1 and 2 inside a lane, the larger ones through shfl_xor -- ~650 instructions where counting
+// ranks pair by pair took 6 500 (ballot counts) or 4 600 plus 37 000 LDS round trips (every lane walking every value).
+// The key orders like the float (sign-flipped bits, both zeros on one key, NaN above +inf); the position breaks ties and
+// finds the value again, so the merged row carries the original bit patterns.
+__device__ __forceinline__ unsigned long long merge_key(float v, int pos) {
+    unsigned k;
+    if (v != v) {
+        k = 0xffffffffu;
+    } else {
+        const unsigned b = v == 0.f ? 0u : __float_as_uint(v);
+        k = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    }
+    return ((unsigned long long)k << 32) | (unsigned)pos;
+}
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
+    const unsigned lo = (unsigned)shfl_xor((int)(unsigned)v, mask), hi = (unsigned)shfl_xor((int)(unsigned)(v >> 32), mask);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int K, int J>
+__device__ __forceinline__ void bitonic_stage(unsigned long long (&key)[4], int lane) {
+    if constexpr (J >= 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned long long other = shfl_xor_u64(key[r], J >> 2);
+            const int i = lane * 4 + r;
+            const bool keep_min = ((i & J) == 0) == ((i & K) == 0);
+            const bool other_less = other < key[r];
+            key[r] = (keep_min == other_less) ? other : key[r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if ((r & J) != 0) continue;
+            const int i = lane * 4 + r;
+            const bool asc = (i & K) == 0;
+            const unsigned long long a = key[r], b = key[r | J];
+            const bool swap = (b < a) == asc;
+            key[r] = swap ? b : a;
+            key[r | J] = swap ? a : b;
+        }
+    }
+}
+template <int K, int J>
+__device__ __forceinline__ void bitonic_phase(unsigned long long (&key)[4], int lane) {
+    bitonic_stage<K, J>(key, lane);
+    if constexpr (J > 1) bitonic_phase<K, J / 2>(key, lane);
+}
+template <int K>
+__device__ __forceinline__ void bitonic_sort256(unsigned long long (&key)[4], int lane) {
+    bitonic_phase<K, K / 2>(key, lane);
+    if constexpr (K < 256) bitonic_sort256<K * 2>(key, lane);
+}
+
 __device__ inline void rank_merge(const float* s_all, int tot, float* s_sorted, int lane) {
-    constexpr int NB = 4;
-    if (tot > NB * kWave) {
+    if (tot > 4 * kWave) {
         for (int e = lane; e < tot; e += kWave) {
             const float v = s_all[e];
             int rank = 0;
@@ -119,41 +170,17 @@ __device__ inline void rank_merge(const float* s_all, int tot, float* s_sorted, 
         }
         return;
     }
-    // (slots behind the last value hold +inf: never below anything, and behind every real value in position)
-    float v[NB];
-    unsigned long long nan_at[NB], real_at[NB];
+    unsigned long long key[4];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const bool has = b * kWave + lane < tot;
-        v[b] = has ? s_all[b * kWave + lane] : __builtin_huge_valf();
-        real_at[b] = ballot(has);
-        nan_at[b] = ballot(has && v[b] != v[b]);
+    for (int r = 0; r < 4; ++r) {
+        const int i = lane * 4 + r;          // (slots behind the last value: the NaN key at a later position -- they sort last)
+        key[r] = i < tot ? merge_key(s_all[i], i) : ((0xffffffffull << 32) | (unsigned)i);
     }
+    bitonic_sort256<2>(key, lane);
 #pragma unroll
-    for (int eb = 0; eb < NB; ++eb) {
-        const int ne = min(kWave, tot - eb * kWave);
-#pragma unroll 2
-        for (int el = 0; el < ne; ++el) {
-            const float ve = read_lane(v[eb], el);
-            const unsigned long long before = (1ull << el) - 1ull;      // lanes of block eb in front of value e
-            int rank = 0;
-            if (ve == ve) {
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    if (b * kWave >= tot) break;
-                    rank += popcount64(ballot(v[b] < ve));
-                    const unsigned long long eq = ballot(v[b] == ve);
-                    rank += b < eb ? popcount64(eq) : b == eb ? popcount64(eq & before) : 0;
-                }
-            } else {                                                    // a NaN: behind every number, among NaNs by position
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    rank += popcount64(real_at[b] & ~nan_at[b]);
-                    rank += b < eb ? popcount64(nan_at[b]) : b == eb ? popcount64(nan_at[b] & before) : 0;
-                }
-            }
-            if (lane == 0) s_sorted[rank] = ve;
-        }
+    for (int r = 0; r < 4; ++r) {
+        const int i = lane * 4 + r;
+        if (i < tot) s_sorted[i] = s_all[(int)(unsigned)key[r]];
     }
 }
 
