@@ -425,10 +425,11 @@ def coarse_stage_fwd(rays: Tensor, t_vals: Tensor, t_rand: Optional[Tensor], lin
 FINE_STAGE_IMPORTANCE = (64, 128, 192)       # the fused fine stage exists for 64 + N_importance = 128, 192, 256 samples per ray
 # Whether render_rays takes the fine stage as ONE launch (fine_stage_fwd) or as three (fine_sample, mlp_fwd, composite_fwd).
 # Both routes are the same device code on the same numbers (bit-identical outputs: tests).  Measured on the MI355X at
-# 4096 x (64 + 128) (profiles/r04_fused_fine_stage.txt): one launch 3.45 ms, three launches 3.10 + 0.085 + 0.013 = 3.20 ms.
-# The sampler is serial, latency-bound work of one wave per ray (~30 us); as a kernel of its own a CU overlaps a dozen
-# rays' worth of it, in front of the resident network -- one wave per SIMD, nothing else resident -- every microsecond of it
-# is exposed, eight workgroups in a row per CU.  Off by default for that reason; SCNERF_FUSED_FINE_STAGE=1 switches it on.
+# 4096 x (64 + 128) (profiles/r04_fused_fine_stage.txt): one launch 3.14 ms, the three launches back to back 3.07 ms
+# (3.45 against 3.20 ms before the samplers' serial sections were rewritten).  The sampler is ~8 us of one wave's work per
+# workgroup; as a kernel of its own a CU overlaps sixteen rays of it (43 us for the batch), in front of the resident
+# network -- one wave per SIMD, nothing else resident -- every microsecond of it is exposed, eight workgroups in a row per
+# CU.  Off by default for that reason; SCNERF_FUSED_FINE_STAGE=1 switches it on.
 _FUSED_FINE_STAGE = [os.environ.get("SCNERF_FUSED_FINE_STAGE", "0") not in ("", "0")]
 
 
