@@ -4,6 +4,7 @@ set -eu
 TAG=${1:-r04}
 cd "$(dirname "$0")/.."
 O=gpurun_out/$TAG
+cp gpurun_out/parity_$TAG.json profiles/parity_$TAG.json 2> /dev/null || true
 for f in gpu_tests.txt bench_n1.json bench_detail_n1.json bench_n2_gloo_one_device.json bench_n1_fp32.json kernel_trace_bench.txt pmc_kernels.txt; do
   [ -f $O/$f ] && cp $O/$f profiles/${TAG}_$f
 done
