@@ -9,11 +9,14 @@ BASELINE.json's configs[1] exactly (precomputed rays of a fixed camera).  At N >
 of each step come from the learnable camera model (get_rays_kps_use_camera + NDC through the model: the ray
 source of configs[2..3]) and ONE RCCL all-reduce per step sums the flat fp32 gradient buffer that holds both
 networks AND the camera parameters -- the north star's collective; the extra work per step is two small
-kernels, so per-N values stay comparable (N = 1 with the camera is reported under extras).  Rank 0 prints one
-JSON line; at N = 1 `extras` adds short timings of the other configurations (camera curriculum states, PRD
-loss, full-image inference, NeRF++).  `roofline` is measured live with HIP events around the dominant kernel's launches on
-the stream they run on; `cpu_baseline` times the CPU oracle (a torch-CPU restatement of the
-reference path, kind "port") on a bounded sample of the same workload on the box's host cores.
+kernels, so per-N values stay comparable (N = 1 with the camera is reported under extras).  Rank 0 prints ONE compact JSON
+line (< 4 KB: the contract's keys, `roofline`, `cpu_baseline`, the all-fp32-MFMA step; tests/test_bench_line.py) and writes
+the full record -- per-kernel tables, and at N = 1 short timings of the other configurations (camera curriculum states, PRD
+loss, full-image inference, NeRF++) -- to profiles/bench_detail_n<N>.json, named in the line.  `--gpus N` without a launcher
+starts its own N ranks.  `roofline` is measured live with HIP events around the dominant kernel's launches on the stream they
+run on, its `traffic` comes from the newest PMC summary whose source hash matches the kernels (tools/round_evidence.sh);
+`cpu_baseline` times the UNMODIFIED reference render_rays at 4096 rays x (64 + 128) on the box's host cores where its tree or
+the shipped archive is present (kind "reference"; oracle/ref_ship.py), else the CPU oracle on a bounded sample (kind "port").
 """
 import argparse
 import json
