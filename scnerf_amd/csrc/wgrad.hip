@@ -475,11 +475,17 @@ int launch_wgrad_tiles(const wgt::Args& a, int G, hipStream_t stream) {
 
 // the same shapes on three fp16 products (wgrad_half_narrow.h)
 template <int NA, int NB, bool B_ROWMAJOR>
-int launch_wgrad_half_narrow(const wgnh::Args& a, int G, hipStream_t stream) {
+int launch_wgrad_half_narrow(const wgnh::Args& a, int G, hipStream_t stream, int jobs = 1) {
     SCN_LDS_OPT_IN((wgnh::wgrad_half_narrow_kernel<NA, NB, B_ROWMAJOR>), wgnh::kLdsBytes);
-    hipLaunchKernelGGL((wgnh::wgrad_half_narrow_kernel<NA, NB, B_ROWMAJOR>), dim3(G), dim3(wgnh::kThreads), wgnh::kLdsBytes, stream, a);
+    hipLaunchKernelGGL((wgnh::wgrad_half_narrow_kernel<NA, NB, B_ROWMAJOR>), dim3(G, jobs), dim3(wgnh::kThreads), wgnh::kLdsBytes, stream, a);
     return scn_launch_status();
 }
+
+// two narrow GEMMs of one shape on the same X, queued by wgrad_gemm and launched together (grid (G, 2))
+struct NarrowPair {
+    wgnh::Args first;
+    int n, k_load, G;
+};
 
 // where a narrow GEMM finds its operands' maxima (nullptr rows: stay on the fp32 MFMA)
 struct NarrowScales {
@@ -512,7 +518,7 @@ namespace {
 int wgrad_gemm(const float* dz, int lda, int n_load, int n_out, int dz_tiled, const float* x, int ldb, int k_load,
                int k_out, int x_tiled, long long n_samples, int n_chunks, float* workspace, float* dW, int ldo,
                int col0, float* db, hipStream_t st, ReduceJob* job, long long* used, wg256::Args* batch = nullptr,
-               const NarrowScales* narrow = nullptr) {
+               const NarrowScales* narrow = nullptr, NarrowPair* pair = nullptr) {
     SCN_RETURN_IF(!dz || !x || !workspace || !dW || n_samples < 0 || n_chunks < 1, SCN_EINVAL);
     SCN_RETURN_IF(lda % 4 || ldb % 4 || n_load % 4 || k_load % 4 || n_out > n_load || k_out > k_load, SCN_EINVAL);
     SCN_RETURN_IF(((uintptr_t)dz | (uintptr_t)x | (uintptr_t)workspace) & 15, SCN_EINVAL);
@@ -548,8 +554,18 @@ int wgrad_gemm(const float* dz, int lda, int n_load, int n_out, int dz_tiled, co
                ((n_load == 256 && !x_tiled && (k_load == 64 || k_load == 128)) || (n_load == 128 && x_tiled && k_load == 256))) {
         if (narrow && narrow->a.amax && narrow->b.amax) {
             wgnh::Args t{dz, x, a.part_w, db ? a.part_b : nullptr, a.P, a.Ppad, a.chunk, narrow->a, narrow->b,
-                         narrow->n_coarse, narrow->coarse_chunk, nullptr, nullptr, wgnh::Bound{nullptr, nullptr, nullptr}};
-            if (n_load == 128) rc = launch_wgrad_half_narrow<128, 256, false>(t, G, st);
+                         narrow->n_coarse, narrow->coarse_chunk, nullptr, nullptr, wgnh::Bound{nullptr, nullptr, nullptr},
+                         nullptr, nullptr, nullptr, wgnh::Bound{nullptr, nullptr, nullptr}};
+            if (pair && n_load == 256 && pair->n == 0) {
+                pair->first = t; pair->n = 1; pair->k_load = k_load; pair->G = G;        // launched with its partner
+                rc = 0;
+            } else if (pair && n_load == 256 && pair->n == 1 && pair->k_load == k_load && pair->G == G && pair->first.B == x) {
+                wgnh::Args both = pair->first;
+                both.A_y1 = t.A; both.part_w_y1 = t.part_w; both.part_b_y1 = t.part_b; both.a_y1 = t.a;
+                pair->n = 2;
+                rc = k_load == 64 ? launch_wgrad_half_narrow<256, 64, true>(both, G, st, 2)
+                                  : launch_wgrad_half_narrow<256, 128, true>(both, G, st, 2);
+            } else if (n_load == 128) rc = launch_wgrad_half_narrow<128, 256, false>(t, G, st);
             else if (k_load == 64) rc = launch_wgrad_half_narrow<256, 64, true>(t, G, st);
             else rc = launch_wgrad_half_narrow<256, 128, true>(t, G, st);
         } else {
@@ -660,10 +676,12 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
                                             scales ? scales + scn::h3::kLayerFeat * scn::h3::kScaleStride + scn::h3::kBoundB : nullptr},
                                 nb, coarse_chunk};
     const NarrowScales* narrow = nullptr;
+    NarrowPair pair;                 // layer 0 and the skip columns of layer 5: same shape, same X -- one launch
+    pair.n = 0;
 #define SCN_WG(...)                                                                            \
     {                                                                                          \
         long long used__ = 0;                                                                  \
-        rc = wgrad_gemm(__VA_ARGS__, st, &jobs.j[jobs.n], &used__, &big, narrow);              \
+        rc = wgrad_gemm(__VA_ARGS__, st, &jobs.j[jobs.n], &used__, &big, narrow, &pair);       \
         if (rc != 0) return rc;                                                                \
         ws += used__;                                                                          \
         ++jobs.n;                                                                              \
@@ -682,6 +700,11 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
         } else {
             SCN_WG(dz(l), 256, 256, 256, 1, act(l - 1), 256, 256, 256, 1, P, nb, ws, g + V::trunk_w(l), 256, 0, g + V::trunk_b(l))
         }
+    }
+    if (pair.n == 1) {               // (a lone narrow GEMM of the pair's shape: never with this network, launched for safety)
+        rc = pair.k_load == 64 ? launch_wgrad_half_narrow<256, 64, true>(pair.first, pair.G, st)
+                               : launch_wgrad_half_narrow<256, 128, true>(pair.first, pair.G, st);
+        if (rc != 0) return rc;
     }
     // feature_linear; alpha_linear (one output row) = d sigma^T . act7 with d sigma = d_raw[:, 3]
     SCN_WG(G(kGradDfeat), 256, 256, 256, 1, act(7), 256, 256, 256, 1, P, nb, ws, g + V::kWF, 256, 0, g + V::kBF)

@@ -46,7 +46,12 @@ using wg256h::kRowEl;
 using wg256h::kSlabEl;
 using wg256h::kThreads;
 using wg256h::u32x2;
-constexpr unsigned kLdsBytes = wg256h::kLdsBytes;
+// Two slab images: slab s + 1 is cut into the image slab s - 1 was read from, which every wave has left behind the
+// barrier that ended iteration s - 1 (wgrad256_half.h keeps three because its cut runs two slabs ahead).  66 KB instead of
+// 99: with at most 256 registers per wave TWO workgroups fit a CU, and one's dependent chain of a slab -- LDS reads, cut,
+// MFMAs, barrier -- runs under the other's.
+constexpr int kImages = 2;
+constexpr unsigned kLdsBytes = (unsigned)kImages * kSlabEl * 2u;
 constexpr int kSets = 4;                       // staging register sets = slabs the loads run ahead
 
 struct Bound {
@@ -70,6 +75,12 @@ struct Args {
     const float* B2;
     float* part_w2;
     Bound b2;
+    // a second GEMM of the same shape on the same X (blockIdx.y == 1; grid (G, 2)): layer 0 and the skip columns of layer 5
+    // both multiply the encoded point -- launched together their workgroups pair up on a CU and read X once from HBM
+    const float* A_y1;
+    float* part_w_y1;
+    float* part_b_y1;
+    Bound a_y1;
 };
 
 // where the 4-feature group fg of an operand sits in its 256-position region of an LDS row (wgrad256_half.h's image)
@@ -78,7 +89,8 @@ __device__ __forceinline__ int region_pos(int fg) {
 }
 
 template <int WA, int WB, bool B_ROWMAJOR, int WB2 = 0>
-__global__ __launch_bounds__(kThreads, 1) void wgrad_half_narrow_kernel(Args a) {
+__global__ __launch_bounds__(kThreads, (WA == 256 && WB == 64 && WB2 == 0) ? 2 : 1) void wgrad_half_narrow_kernel(Args a) {
+    if (blockIdx.y == 1) { a.A = a.A_y1; a.part_w = a.part_w_y1; a.part_b = a.part_b_y1; a.a = a.a_y1; }
     constexpr int TA = WA / 64, TB = WB / 64;             // accumulator tiles per wave
     constexpr int PA = WA / 64, PB = WB / 64;             // 16-byte pieces per thread and slab
     constexpr int P2 = WB2 ? 1 : 0;                       // the second X operand's piece (waves 0 and 1 only)
@@ -285,7 +297,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_half_narrow_kernel(Args a) 
     using S1 = std::integral_constant<int, 1>;
     using S2 = std::integral_constant<int, 2>;
     using S3 = std::integral_constant<int, 3>;
-    // slab k waits in set k mod 4; slab s is cut into image s mod 3 during iteration s - 1 and read during iteration s
+    // slab k waits in set k mod 4; slab s is cut into image s mod kImages during iteration s - 1 and read during iteration s
     load_slab(S0{}, 0);
     load_slab(S1{}, 1);
     load_slab(S2{}, 2);
@@ -298,7 +310,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_half_narrow_kernel(Args a) 
         step_body(next_set_tag, s, cur, nxt);
         block_sync();
         cur = nxt;
-        nxt = nxt == 2 ? 0 : nxt + 1;
+        nxt = nxt == kImages - 1 ? 0 : nxt + 1;
     };
     for (int s = 0; s < n_slab; s += 4) {
         step(S1{}, s);
