@@ -51,29 +51,39 @@ def positional_encoding(x: Tensor, n_freqs: int) -> Tensor:
 
 # -------------------------------------------------------------------------- MLP
 def mlp_forward(p: Dict[str, Tensor], embedded: Tensor, input_ch: int,
-                input_ch_views: int, skips=(4,), use_viewdirs=True) -> Tensor:
+                input_ch_views: int, skips=(4,), use_viewdirs=True, gates=None, record=None) -> Tensor:
     """NeRF.forward (NeRF/run_nerf_helpers.py:105-128): ReLU trunk with the encoded
     points re-concatenated *in front of* h after layer index in `skips`; density
-    head from the trunk; colour head from [feature, encoded view dir]."""
+    head from the trunk; colour head from [feature, encoded view dir].
+    `gates` (tests only): depth + 1 boolean [P, width] tensors that REPLACE the ReLUs' own decisions (z * gate
+    instead of relu(z)) -- a pre-activation within rounding of zero lands on either side in two fp32
+    evaluations, and a comparison of gradients wants both sides on the same one.  `record`: a list that receives this
+    evaluation's own decisions (z > 0), layer by layer."""
     x_pts, x_views = torch.split(embedded, [input_ch, input_ch_views], dim=-1)
     depth = len([k for k in p if k.startswith("pts_linears.") and k.endswith(".weight")])
     h = x_pts
     for i in range(depth):
-        h = F.relu(F.linear(h, p["pts_linears.%d.weight" % i], p["pts_linears.%d.bias" % i]))
+        z = F.linear(h, p["pts_linears.%d.weight" % i], p["pts_linears.%d.bias" % i])
+        if record is not None:
+            record.append((z > 0).detach())
+        h = F.relu(z) if gates is None else z * gates[i].to(z.dtype)
         if i in skips:
             h = torch.cat([x_pts, h], dim=-1)
     if use_viewdirs:
         sigma = F.linear(h, p["alpha_linear.weight"], p["alpha_linear.bias"])
         feat = F.linear(h, p["feature_linear.weight"], p["feature_linear.bias"])
         hv = torch.cat([feat, x_views], dim=-1)
-        hv = F.relu(F.linear(hv, p["views_linears.0.weight"], p["views_linears.0.bias"]))
+        zv = F.linear(hv, p["views_linears.0.weight"], p["views_linears.0.bias"])
+        if record is not None:
+            record.append((zv > 0).detach())
+        hv = F.relu(zv) if gates is None else zv * gates[depth].to(zv.dtype)
         rgb = F.linear(hv, p["rgb_linear.weight"], p["rgb_linear.bias"])
         return torch.cat([rgb, sigma], dim=-1)
     return F.linear(h, p["output_linear.weight"], p["output_linear.bias"])
 
 
 def query_network(p, pts: Tensor, viewdirs: Optional[Tensor], multires=10,
-                  multires_views=4, skips=(4,)) -> Tensor:
+                  multires_views=4, skips=(4,), gates=None, record=None) -> Tensor:
     """run_network (NeRF/create_nerf.py:18-32): encode points, broadcast + encode
     the per-ray view direction over the samples, concatenate, evaluate."""
     flat = pts.reshape(-1, pts.shape[-1])
@@ -85,7 +95,7 @@ def query_network(p, pts: Tensor, viewdirs: Optional[Tensor], multires=10,
         emb_d = positional_encoding(dirs, multires_views)
         input_ch_views = emb_d.shape[-1]
         emb = torch.cat([emb, emb_d], dim=-1)
-    out = mlp_forward(p, emb, input_ch, input_ch_views, skips, viewdirs is not None)
+    out = mlp_forward(p, emb, input_ch, input_ch_views, skips, viewdirs is not None, gates, record)
     return out.reshape(list(pts.shape[:-1]) + [out.shape[-1]])
 
 
@@ -214,13 +224,16 @@ def stratified_z(near: Tensor, far: Tensor, n_samples: int, lindisp=False,
 def render_rays(ray_batch: Tensor, coarse, fine, n_samples: int, n_importance: int,
                 t_rand=None, u=None, noise_c=None, noise_f=None, lindisp=False,
                 white_bkgd=False, multires=10, multires_views=4, rowsum="torch",
-                retraw=True, skips=(4,)):
+                retraw=True, skips=(4,), z_samples=None, gates_coarse=None, gates_fine=None, record_gates=None):
     """render_rays (NeRF/render.py:186-300) with injected randomness.
 
     ray_batch [N, 8 or 11] = [o(3), d(3), near, far, (viewdirs(3))].  `fine` may be
     None (then the coarse net is re-used: :279).  When n_importance > 0 and `u` is
     None the deterministic linspace is used (perturb == 0).  Extra keys beyond the
     reference's dict (depth maps, z values, indices) are returned for the tests.
+    `z_samples` [N, n_importance]: use THESE new depths instead of the sampler's own (they are detached anyway, :274) --
+    for tests that compare what lies behind the sampler on identical samples; `gates_coarse` / `gates_fine`: mlp_forward's
+    `gates` for the two network evaluations; `record_gates`: a dict that receives their own decisions ("coarse" / "fine").
     """
     n = ray_batch.shape[0]
     rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]
@@ -228,7 +241,9 @@ def render_rays(ray_batch: Tensor, coarse, fine, n_samples: int, n_importance: i
     near, far = ray_batch[:, 6:7], ray_batch[:, 7:8]
     z_c = stratified_z(near, far, n_samples, lindisp, t_rand)
     pts = rays_o[:, None, :] + rays_d[:, None, :] * z_c[:, :, None]
-    raw_c = query_network(coarse, pts, viewdirs, multires, multires_views, skips)
+    rec_c = record_gates.setdefault("coarse", []) if record_gates is not None else None
+    rec_f = record_gates.setdefault("fine", []) if record_gates is not None else None
+    raw_c = query_network(coarse, pts, viewdirs, multires, multires_views, skips, gates_coarse, rec_c)
     rgb, disp, acc, w, depth = composite(raw_c, z_c, rays_d, noise_c, white_bkgd)
     out = {"z_coarse": z_c, "weights_coarse": w}
     raw = raw_c
@@ -239,10 +254,12 @@ def render_rays(ray_batch: Tensor, coarse, fine, n_samples: int, n_importance: i
             u = deterministic_u(n, n_importance, z_c.dtype)
         z_s, inds, cdf = sample_pdf(z_mid, w[..., 1:-1], u, rowsum)
         z_s = z_s.detach()                                              # :274
+        if z_samples is not None:
+            z_s = z_samples.to(z_c.dtype)
         z_f, _ = torch.sort(torch.cat([z_c, z_s], dim=-1), dim=-1)
         pts = rays_o[:, None, :] + rays_d[:, None, :] * z_f[:, :, None]
         raw = query_network(coarse if fine is None else fine, pts, viewdirs,
-                            multires, multires_views, skips)
+                            multires, multires_views, skips, gates_fine, rec_f)
         rgb, disp, acc, w, depth = composite(raw, z_f, rays_d, noise_f, white_bkgd)
         out.update(z_samples=z_s, inds=inds, cdf=cdf, z_fine=z_f, weights_fine=w,
                    z_std=torch.std(z_s, dim=-1, unbiased=False))         # :294
