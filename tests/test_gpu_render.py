@@ -212,12 +212,12 @@ def _render_node(tensor):
     raise AssertionError("no RenderRaysFunction node behind this tensor")
 
 
-def _kernel_gates(save, P):
+def _kernel_gates(save, P, pd=3):
     """the ReLU decisions the training forward took, from the bit masks behind its activation workspace:
     -> 8 x bool [P, 256] (trunk) + bool [P, 128] (views layer)"""
     from scnerf_amd import mlp_layout as ML
     from tests.test_gpu_kernels import _gates_from_masks
-    lay = ML.layout(3)
+    lay = ML.layout(pd)
     _, total = ML.section_offsets(lay.save_sections, P)
     masks = save[total:].cpu().numpy().view(np.uint32).reshape(9, ML.padded_samples(P) // 32, 64, 4)
     return [torch.from_numpy(_gates_from_masks(masks[l], P, 8 if l < 8 else 4)) for l in range(9)]
