@@ -25,6 +25,12 @@ def _unpack_shipped_reference():
 
 _unpack_shipped_reference()
 
+if torch.cuda.is_available():
+    # The GPU suite runs serially and most of its wall time is the CPU oracle (torch-CPU at up to 4096 rays): on the GPU box's
+    # 256 hardware threads torch's default intra-op pool oversubscribes the memory system -- 32 threads are the fastest
+    # (bench.py's probe of the reference's CPU step finds the same): 150 -> 91 s for the suite.
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
