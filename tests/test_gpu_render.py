@@ -288,6 +288,35 @@ def test_training_gradients_with_both_discontinuities_aligned(R):
     assert ge.max() <= 1e-4, float(ge.max())
 
 
+def test_training_step_is_bit_reproducible(R, arithmetic):
+    """The same 4096-ray training step five times: every output, the ray gradients and every parameter gradient of both
+    networks bit for bit the same.  All sums of the path run in a fixed order (per-GEMM partial slabs reduced by index,
+    fp64 prefix products, maxima through integer atomicMax), so anything else is a race -- and the LDS schedules of the
+    resident kernels and the weight-gradient GEMMs (two slab images, one barrier per slab; chunk rings behind one
+    barrier per chunk) are exactly what the sequentially consistent CPU interpreter cannot check."""
+    n, sc, sf = 4096, 64, 128
+    net_c, net_f = make_net(R, 0), make_net(R, 1)
+    rays = synth.ray_batch(n, seed=21).cuda()
+    rnd = {k: v.cuda() for k, v in synth.render_randoms(n, sc, sf, seed=22).items()}
+    target = torch.rand(n, 3, generator=torch.Generator().manual_seed(23)).cuda()
+    params = list(net_c.parameters()) + list(net_f.parameters())
+
+    def once():
+        r = rays.clone().requires_grad_(True)
+        ret = R["render"].render_rays(r, net_c, make_query(R), sc, retraw=True, perturb=1.0, N_importance=sf,
+                                      network_fine=net_f, raw_noise_std=1.0, _randoms=rnd)
+        loss = torch.mean((ret["rgb_map"] - target) ** 2) + torch.mean((ret["rgb0"] - target) ** 2)
+        grads = torch.autograd.grad(loss, [r] + params)
+        keys = ("rgb_map", "disp_map", "acc_map", "raw", "rgb0", "disp0", "acc0", "z_std")
+        return [ret[k].detach().clone() for k in keys] + [g.detach().clone() for g in grads]
+
+    first = once()
+    for rep in range(4):
+        again = once()
+        for i, (a, b) in enumerate(zip(first, again)):
+            assert torch.equal(a, b), ("run %d differs from run 0 in item %d" % (rep + 1, i), float((a - b).abs().max()))
+
+
 def test_batchify_clamp_zeroes_gradient(R):
     """rgb >= 1 is overwritten with 1 in place and its gradient vanishes (reference render.py:404-406)."""
     net = make_net(R, 0)
