@@ -189,6 +189,37 @@ def test_nerfnet_gradients_with_the_relu_decisions_aligned():
         assert v <= 1e-4, (name, v)
 
 
+def test_nerfnet_step_is_bit_reproducible():
+    """1024 rays x (64 + 64) through both networks, forward + backward, four times: outputs, ray gradients and every
+    parameter gradient bit for bit the same (fixed-order sums everywhere; anything else would be a race in the
+    4-D-point kernels or the 256 x 128 weight-gradient shape only this path uses)."""
+    from scnerf_amd.nerfplusplus import ddp_train_nerf as TR
+    net = make_net(778)
+    g = torch.Generator().manual_seed(5)
+    n, s = 1024, 64
+    o = (torch.randn(n, 3, generator=g) * 0.25).cuda()
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).cuda() * 1.3
+    frac = torch.sort(torch.rand(n, s, generator=g), -1)[0].cuda()
+    bg_z = torch.sort(torch.rand(n, s, generator=g), -1)[0].cuda()
+    target = torch.rand(n, 3, generator=g).cuda()
+    params = list(net.parameters())
+
+    def once():
+        oo, dd = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
+        far = TR.intersect_sphere(oo, dd)
+        fg_z = 1e-4 + frac * (far - 1e-4)[:, None]
+        ret = net(oo, dd, far, fg_z, bg_z)
+        loss = ((ret["rgb"] - target) ** 2).mean() + 0.1 * ret["fg_depth"].mean() + 0.1 * ret["bg_depth"].mean()
+        grads = torch.autograd.grad(loss, [oo, dd] + params)
+        return [ret[k].detach().clone() for k in ret] + [x.detach().clone() for x in grads]
+
+    first = once()
+    assert all(bool(torch.isfinite(x).all()) for x in first)
+    for rep in range(3):
+        for i, (a, b) in enumerate(zip(first, once())):
+            assert torch.equal(a, b), ("run %d differs from run 0 in item %d" % (rep + 1, i), float((a - b).abs().max()))
+
+
 def _cascade_inputs():
     from scnerf_amd.nerfplusplus import ddp_train_nerf as TR
     n, s0, s1 = 32, 64, 128
