@@ -112,6 +112,12 @@ __device__ __forceinline__ void stream_prime(Stream& ws, const void* stream, cha
     for (int i = 0; i < 8; ++i) ws.stage[i] = load_f32x4(ws.g + i * 4096, tid16);
     ws.g = uniform_global(ws.g + kChunkBytes);
     ws.cur = 0u;
+    if constexpr (lab::kNoStream) {        // (timing experiments: the stream is off, every buffer holds real fragments)
+#pragma unroll
+        for (int b = 1; b < 3; ++b)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(lds + b * kChunkBytes + i * 4096 + tid16) = ws.stage[i];
+    }
 }
 
 // what the stream does in slot KAPPA (0 .. 47) of a chunk: piece i of the NEXT chunk goes from its staging register to
