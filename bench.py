@@ -4,12 +4,13 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--rays 4096] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU; every rank renders its own 4096 synthetic rays (weak scaling).  At N = 1 the step is
-BASELINE.json's configs[1] exactly (precomputed rays of a fixed camera).  At N > 1 (or with --camera) the rays
-of each step come from the learnable camera model (get_rays_kps_use_camera + NDC through the model: the ray
-source of configs[2..3]) and ONE RCCL all-reduce per step sums the flat fp32 gradient buffer that holds both
-networks AND the camera parameters -- the north star's collective; the extra work per step is two small
-kernels, so per-N values stay comparable (N = 1 with the camera is reported under extras).  Rank 0 prints ONE compact JSON
+One process per GPU; every rank renders its own 4096 synthetic rays (weak scaling).  The workload is the same at every N
+(`--config`, default 1): 1 = BASELINE.json's configs[1] (precomputed rays of a fixed camera; the all-reduce carries both
+networks' gradients), 2 = configs[2] (rays from the learnable camera model, NDC through its intrinsics; the all-reduce
+carries networks AND camera parameters), 3 = configs[3] (the same + the projected-ray-distance term of one image pair in
+every step, NeRF/run_nerf.py:508-598), 4 = configs[4] (NeRF++: two cascade levels, foreground + background networks,
+nerfplusplus/ddp_train_nerf.py:491-550).  At N > 1 ONE all-reduce per step (RCCL) sums the flat fp32 gradient buffer; at
+N = 1 there is no collective.  Rank 0 prints ONE compact JSON
 line (< 4 KB: the contract's keys, `roofline`, `cpu_baseline`, the all-fp32-MFMA step; tests/test_bench_line.py) and writes
 the full record -- per-kernel tables, and at N = 1 short timings of the other configurations (camera curriculum states, PRD
 loss, full-image inference, NeRF++) -- to profiles/bench_detail_n<N>.json, named in the line.  `--gpus N` without a launcher
@@ -297,7 +298,11 @@ def build_world(dev, rank, n):
     g = torch.Generator().manual_seed(100 + rank)
     kps = torch.stack([torch.randint(0, IMG_W, (n,), generator=g), torch.randint(0, IMG_H, (n,), generator=g)], -1)
     idx = torch.randint(0, N_CAMS, (n,), generator=g)
-    return dict(net_c=make(0), net_f=make(1), cam=cam.to(dev),
+    # configs[3]: matched key points of this rank's image pair (1024 matches, a quarter of them outliers)
+    i0, i1 = rank % N_CAMS, (rank + 1) % N_CAMS
+    E, K = cam.get_extrinsic().detach().cpu(), cam.get_intrinsic().detach().cpu()
+    k0, k1 = synth.matched_keypoints(IMG_H, IMG_W, K, E[i0], E[i1], 1024, seed=8 + rank)
+    return dict(net_c=make(0), net_f=make(1), cam=cam.to(dev), matches=(k0.to(dev), k1.to(dev), i0, i1),
                 query=FusedNetworkQuery(get_embedder(10, 0)[0], get_embedder(4, 0)[0]),
                 rays=synth.ray_batch(n, seed=1 + rank).to(dev), target=synth.target_rgb(n, seed=2 + rank).to(dev),
                 kps=kps.to(dev), idx=idx.to(dev), n=n)
@@ -320,14 +325,24 @@ def fixed_camera_step(w, reducer):
     return step
 
 
-def learnable_camera_step(w, reducer):
-    """configs[2..3] ray source: key-point rays through the learnable camera model, NDC through its intrinsics,
-    render fwd + bwd down to the camera parameters (+ the all-reduce over networks AND camera)"""
+PRD_WEIGHT = 1e-4          # args.ray_dist_loss_weight of the reference's demo configuration
+
+
+def learnable_camera_step(w, reducer, prd=False):
+    """configs[2] (and with `prd` configs[3]): key-point rays through the learnable camera model, NDC through its
+    intrinsics, render fwd + bwd down to the camera parameters, + the projected-ray-distance term of one image pair
+    (+ the all-reduce over networks AND camera)"""
+    import types
     from scnerf_amd.get_rays import get_rays_kps_use_camera
+    from scnerf_amd.ray_dist_loss import proj_ray_dist_loss_single
     from scnerf_amd.render import render
     inv = 1.0 / (3 * w["n"])
     kw = dict(network_fn=w["net_c"], network_fine=w["net_f"], network_query_fn=w["query"], N_samples=S_C,
               N_importance=S_F, perturb=1.0, raw_noise_std=1.0, use_viewdirs=True, white_bkgd=False, near=0., far=1.)
+
+    prd_args = types.SimpleNamespace(proj_ray_dist_threshold=5.0)
+    i_map = torch.arange(N_CAMS).numpy()
+    one = torch.ones((), device=w["target"].device)
 
     def step():
         reducer.zero()
@@ -337,7 +352,18 @@ def learnable_camera_step(w, reducer):
                                    camera_model=w["cam"], mode="train", **kw)
         g1 = (rgb.detach() - w["target"]) * (2 * inv)
         g0 = (extras["rgb0"].detach() - w["target"]) * (2 * inv)
-        torch.autograd.backward([rgb, extras["rgb0"]], [g1, g0])
+        outs, grads = [rgb, extras["rgb0"]], [g1, g0]
+        if prd:
+            # configs[3]: + ray_dist_loss_weight x the projected-ray-distance loss of one image pair (run_nerf.py:533-596)
+            k0, k1, i0, i1 = w["matches"]
+            r0 = get_rays_kps_use_camera(H=IMG_H, W=IMG_W, camera_model=w["cam"], idx_in_camera_param=i0, kps_list=k0)
+            r1 = get_rays_kps_use_camera(H=IMG_H, W=IMG_W, camera_model=w["cam"], idx_in_camera_param=i1, kps_list=k1)
+            loss, _ = proj_ray_dist_loss_single(kps0_list=k0, kps1_list=k1, img_idx0=i0, img_idx1=i1, rays0=r0, rays1=r1,
+                                                mode="train", device=k0.device, H=IMG_H, W=IMG_W, args=prd_args,
+                                                camera_model=w["cam"], method="NeRF", i_map=i_map)
+            outs.append(loss)
+            grads.append(one * PRD_WEIGHT)
+        torch.autograd.backward(outs, grads)
         reducer.all_reduce()
     return step
 
@@ -480,6 +506,73 @@ def self_launch(n, json_out):
     return r.returncode if r.returncode else (0 if lines else 1)
 
 
+class Telemetry:
+    """Socket power and shader clock of this rank's GPU while the step loops, from the amdgpu hwmon files of its PCI device
+    (power1_input in microwatts, freq1_input = sclk in Hz, power1_cap): the resident kernels run AT the socket's power cap,
+    well below 2.4 GHz (profiles/r05_lab_residency.txt), and the record should say so.  A thread samples every 25 ms; nothing
+    here is inside the timed region.  Every failure (no sysfs, other driver layout) yields None."""
+
+    def __init__(self, dev):
+        import glob
+        self.dir = None
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            hits = glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bdf)
+            if hits and os.path.isfile(os.path.join(hits[0], "power1_input")):
+                self.dir = hits[0]
+        except Exception:
+            self.dir = None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as fh:
+                return float(fh.read().strip())
+        except Exception:
+            return None
+
+    def sample_while(self, fn, seconds):
+        """runs fn() repeatedly for `seconds`, sampling beside it -> dict or None"""
+        if self.dir is None:
+            return None
+        import threading
+        stop, power, clock = threading.Event(), [], []
+
+        def sampler():
+            while not stop.is_set():
+                pw, ck = self._read("power1_input"), self._read("freq1_input")
+                if pw is not None:
+                    power.append(pw * 1e-6)
+                if ck is not None:
+                    clock.append(ck * 1e-9)
+                time.sleep(0.025)
+        t_end = time.perf_counter() + seconds
+        for _ in range(10):                       # (the first samples would still see the idle clock)
+            fn()
+        torch.cuda.synchronize()
+        th = threading.Thread(target=sampler, daemon=True)
+        th.start()
+        steps = 0
+        t0 = time.perf_counter()
+        while time.perf_counter() < t_end:
+            fn()
+            steps += 1
+            if steps % 8 == 0:
+                torch.cuda.synchronize()          # (keeps the launch queue short, so the loop ends on time)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        stop.set()
+        th.join()
+        if not power or not clock:
+            return None
+        power.sort(), clock.sort()
+        cap = self._read("power1_cap")
+        return {"socket_power_w": power[len(power) // 2], "clock_ghz": clock[len(clock) // 2],
+                "power_cap_w": cap * 1e-6 if cap else None, "samples": len(power), "ms_per_step_during": dt / max(steps, 1) * 1e3,
+                "source": "amdgpu hwmon power1_input / freq1_input (sclk), median of samples taken every 25 ms over %.1f s of "
+                          "back-to-back steps after the timed region" % seconds}
+
+
 COMPACT_LIMIT = 4096        # bytes: the driver parses the LAST line of a bounded stdout tail
 
 
@@ -497,11 +590,12 @@ def compact_record(full, detail_path):
         return None if d is None else {k: r4(v) for k, v in d.items()}
     line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                  "scaling", "vs_baseline", "dtype", "data") if k in full}
-    line["config"] = pick(full.get("config"), ("workload", "rays_per_gpu", "parallelism"))
+    line["config"] = pick(full.get("config"), ("workload", "baseline_config", "rays_per_gpu", "parallelism"))
     line["roofline"] = rounded(pick(full.get("roofline"), (
         "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic",
         "traffic_over_survey_algorithmic", "avg_launch_ms", "frac_mfma", "frac_hbm", "algorithmic_bytes_per_launch",
-        "survey_algorithmic_bytes_per_launch", "flop_per_launch", "step_traffic_bytes", "step_traffic_over_survey_algorithmic")))
+        "survey_algorithmic_bytes_per_launch", "flop_per_launch", "step_traffic_bytes", "step_traffic_over_survey_algorithmic",
+        "clock_ghz", "socket_power_w", "power_cap_w", "mfma_busy", "clock_ghz_under_counters", "frac_at_measured_clock")))
     line["cpu_baseline"] = rounded(pick(full.get("cpu_baseline"), (
         "value", "unit", "cores", "kind", "sample", "best_ms", "median_ms", "value_median", "os_cpu_count",
         "rays_per_s_1024_rays_anomaly_on_as_shipped")))
@@ -557,7 +651,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=4096, help="rays of the CPU reference leg (BASELINE.md section 2: 4096)")
     ap.add_argument("--detail", default=None, help="where the full record goes (default profiles/bench_detail_n<N>.json)")
-    ap.add_argument("--camera", action="store_true", help="rays from the learnable camera model also at N = 1")
+    ap.add_argument("--config", type=int, choices=(1, 2, 3, 4), default=1,
+                    help="BASELINE.json's configs[k], the SAME at every --gpus N: 1 fixed camera (default, the headline); "
+                         "2 learnable camera model; 3 camera model + projected-ray-distance term every step; 4 NeRF++")
+    ap.add_argument("--camera", action="store_true", help="(= --config 2)")
     ap.add_argument("--mlp-arithmetic", choices=("resident", "fp32"), default=None,
                     help="forward and data-gradient chain: 'resident' (default): the whole network as one launch each on "
                          "three fp16 products with register-resident activations; 'fp32': the fused fp32-MFMA kernels "
@@ -568,6 +665,8 @@ def main():
     ap.add_argument("--backend", default=os.environ.get("SCNERF_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend (nccl = RCCL; gloo for a functional check of N ranks on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0 (functional check, with --backend gloo)")
+    ap.add_argument("--telemetry-seconds", type=float, default=1.5,
+                    help="N = 1: socket power and shader clock sampled over this many seconds of steps after the timed region (0: off)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -598,14 +697,28 @@ def main():
     if a.mlp_arithmetic:
         ops.mlp_arithmetic(a.mlp_arithmetic)
     n = a.rays
-    w = build_world(dev, rank, n)
-    with_camera = a.camera or world > 1
-    if with_camera:
-        reducer = FlatGradAllReduce([w["net_c"], w["net_f"], w["cam"]], world)
-        step = learnable_camera_step(w, reducer)
+    cfg = 2 if (a.camera and a.config == 1) else a.config
+    step_flop = 3 * FLOP_PER_SAMPLE_FWD * (S_C + S_C + S_F) * n
+    if cfg == 4:
+        from tools import bench_nerfpp
+        if a.rays == 4096:
+            n = 2048                                       # the NeRF++ step's batch (two levels x two networks)
+        npp_step, nets, step_flop = bench_nerfpp.build(n, seed_offset=rank, device=dev)
+        reducer = FlatGradAllReduce(nets, world)
+        w = None
+
+        def step():
+            reducer.zero()
+            npp_step(zero=False)
+            reducer.all_reduce()
     else:
-        reducer = FlatGradAllReduce([w["net_c"], w["net_f"]], world)
-        step = fixed_camera_step(w, reducer)
+        w = build_world(dev, rank, n)
+        if cfg == 1:
+            reducer = FlatGradAllReduce([w["net_c"], w["net_f"]], world)
+            step = fixed_camera_step(w, reducer)
+        else:
+            reducer = FlatGradAllReduce([w["net_c"], w["net_f"], w["cam"]], world)
+            step = learnable_camera_step(w, reducer, prd=(cfg == 3))
 
     def sync():
         if world > 1:
@@ -642,6 +755,7 @@ def main():
         step()
     sync()
     ms_off = (time.perf_counter() - t0) / a.steps * 1e3
+    telemetry = Telemetry(dev).sample_while(step, a.telemetry_seconds) if (rank == 0 and world == 1 and a.telemetry_seconds > 0) else None
 
     if rank == 0:
         kern = ops.PROFILE.summary()
@@ -691,9 +805,29 @@ def main():
                     roof["step_traffic_over_survey_algorithmic"] = rec["bytes_per_step"] / (5000.0 * n)
             else:
                 roof["traffic_source"] = stale or "no profiles/pmc_traffic_r*.json"
-        source = ("rays from the learnable camera model (%d views, %dx%d; configs[2..3] ray source), camera parameters "
-                  "in the all-reduced flat buffer" % (N_CAMS, IMG_H, IMG_W)) if with_camera else \
-            "precomputed rays of a fixed camera"
+            # the power-capped ceiling: the chip's 16-bit MFMA peak is quoted at 2.4 GHz; under these kernels the socket sits at
+            # its power cap and clocks lower, so the same kernel is also priced against the peak AT THE CLOCK IT RAN AT
+            if rec and rec.get("mfma_busy", {}).get(dom) is not None:
+                roof["mfma_busy"] = rec["mfma_busy"][dom]
+                roof["clock_ghz_under_counters"] = rec.get("clock_ghz", {}).get(dom)
+            if telemetry:
+                roof["clock_ghz"] = telemetry["clock_ghz"]
+                roof["socket_power_w"] = telemetry["socket_power_w"]
+                roof["power_cap_w"] = telemetry["power_cap_w"]
+                roof["frac_at_measured_clock"] = roof["frac_mfma"] * 2.4 / telemetry["clock_ghz"] if not hbm else None
+                roof["telemetry"] = telemetry
+        workload = {
+            1: "configs[1]: %d rays x (64 coarse + 128 fine), coarse+fine NeRF (D=8, W=256), fwd+bwd of render_rays per GPU, "
+               "perturb=1, raw_noise_std=1; precomputed rays of a fixed camera" % n,
+            2: "configs[2]: %d rays x (64 + 128) per GPU, coarse+fine NeRF, rays from the learnable camera model (%d views, "
+               "%dx%d: intrinsics, extrinsics, ray-o / ray-d noise), fwd+bwd down to the camera parameters" % (n, N_CAMS, IMG_H, IMG_W),
+            3: "configs[3]: %d rays x (64 + 128) per GPU, coarse+fine NeRF, rays from the learnable camera model (%d views, "
+               "%dx%d) + the projected-ray-distance loss of one image pair (1024 matches) in every step, fwd+bwd down to the "
+               "camera parameters" % (n, N_CAMS, IMG_H, IMG_W),
+            4: "configs[4]: NeRF++ step, %d rays per GPU, two cascade levels (64, then 64+128 samples) x (foreground + "
+               "background network), fwd+bwd" % n}[cfg]
+        collective = ("no collective at N = 1" if world == 1 else
+                      "1 %s all-reduce/step of %d floats" % ("RCCL" if a.backend == "nccl" else a.backend, int(reducer.flat.numel())))
         out = {
             "metric": "rays/sec (64+128 samples/ray) train-step", "value": n * world / (ms * 1e-3),
             "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
@@ -724,20 +858,18 @@ def main():
                              "two HIP events on the launch stream (no piecewise re-issue); ms_per_step_events_off is the same "
                              "loop without the events"),
             "data": "synthetic",
-            "config": {"workload": "configs[1]: %d rays x (64 coarse + 128 fine), coarse+fine NeRF (D=8, W=256), "
-                                   "fwd+bwd of render_rays per GPU, perturb=1, raw_noise_std=1; %s" % (n, source),
-                       "rays_per_gpu": n,
-                       "parallelism": "ray-parallel x%d, 1 %s all-reduce/step of %d floats" % (
-                           world, "RCCL" if a.backend == "nccl" else a.backend, int(reducer.flat.numel()))},
+            "config": {"workload": workload, "baseline_config": cfg, "rays_per_gpu": n,
+                       "parallelism": "ray-parallel x%d, %s" % (world, collective),
+                       "flat_gradient_floats": int(reducer.flat.numel())},
             "roofline": roof,
             "kernels": table,
-            "step_flop_algorithmic": 3 * FLOP_PER_SAMPLE_FWD * (S_C + S_C + S_F) * n,
-            "step_tflops": 3 * FLOP_PER_SAMPLE_FWD * (S_C + S_C + S_F) * n / (ms * 1e-3) / 1e12,
+            "step_flop_algorithmic": step_flop,
+            "step_tflops": step_flop / (ms * 1e-3) / 1e12,
         }
         if per_rank_ms is not None:
             out["per_rank_ms_per_step"] = per_rank_ms
             out["all_reduce_alone"] = allreduce_info
-        if world == 1 and not a.no_extras:
+        if world == 1 and not a.no_extras and cfg == 1:
             out["extras"] = extras_single_gpu(w, dev, sync)
             if a.backend == "nccl":
                 out["extras"]["rccl_allreduce_single_rank"] = rccl_allreduce_probe(dev, 1202945)

@@ -107,6 +107,40 @@ def test_gpu_bench_starts_its_own_ranks(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("config,floats", [(1, 2 * 595844), (3, None), (4, None)])
+def test_gpu_bench_runs_the_named_configs_on_two_ranks(tmp_path, config, floats):
+    """`--config k --gpus 2`: BASELINE.json's configs[1], [3] (learnable camera + projected-ray-distance term every step) and
+    [4] (NeRF++) with two ranks on one device over gloo -- the workload is named in the line, the per-rank times and the
+    collective on its own are there, and the flat gradient buffer has the size the configuration implies."""
+    detail = str(tmp_path / "detail.json")
+    line = _run_bench(["--gpus", "2", "--config", str(config), "--backend", "gloo", "--one-device", "--steps", "2", "--warmup", "1",
+                       "--no-cpu", "--rays", "256", "--detail", detail])
+    assert line["n_gpus"] == 2 and line["config"]["baseline_config"] == config
+    assert line["config"]["workload"].startswith("configs[%d]" % config)
+    assert "all-reduce/step" in line["config"]["parallelism"]
+    assert len(line["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in line["per_rank_ms_per_step"])
+    assert "all_reduce_alone" in line
+    full = json.load(open(detail))
+    n = full["config"]["flat_gradient_floats"]
+    if floats is not None:
+        assert n == floats
+    elif config == 3:
+        assert n > 2 * 595844                       # both networks AND the learnable camera tensors
+    else:
+        assert n == 2 * (595844 + 606596)           # two NerfNet levels x (foreground + background network)
+
+
+@pytest.mark.gpu
+def test_gpu_bench_says_no_collective_on_one_rank(tmp_path):
+    line = _run_bench(["--steps", "2", "--warmup", "1", "--no-cpu", "--no-extras", "--rays", "256", "--config", "3",
+                       "--telemetry-seconds", "0.3", "--detail", str(tmp_path / "d.json")])
+    assert "no collective at N = 1" in line["config"]["parallelism"] and line["config"]["baseline_config"] == 3
+    roof = line["roofline"]
+    if "clock_ghz" in roof:                         # (hwmon files present: they are on the pool's boxes)
+        assert 0.3 < roof["clock_ghz"] < 2.6 and 100 < roof["socket_power_w"] < 1600
+
+
+@pytest.mark.gpu
 def test_gpu_bench_single_line(tmp_path):
     detail = str(tmp_path / "detail.json")
     line = _run_bench(["--steps", "2", "--warmup", "1", "--no-cpu", "--no-extras", "--rays", "1024", "--detail", detail])

@@ -35,7 +35,7 @@ def step_traffic(d, steps):
     return int((tot["WRITE_SIZE"] * 1024 + 2 * tot["FETCH_SIZE"] * 1024) / steps)
 
 
-def traffic_json(agg, out_path, source, bytes_per_step=None):
+def traffic_json(agg, out_path, source, bytes_per_step=None, durations=None):
     """bytes per launch = WRITE_SIZE KB x 1024 + 2 x FETCH_SIZE KB x 1024 (gfx950 tallies wide coalesced reads at half
     their size: MI355X_MICROARCH.md, HBM section), with the calibration copy of known size beside it"""
     import hashlib
@@ -60,7 +60,19 @@ def traffic_json(agg, out_path, source, bytes_per_step=None):
     # the calibration copy: the LARGEST dispatch of the runtime's blit kernel (small copies share its name)
     cal = [{"fetch_kb_raw": max(agg[k]["FETCH_SIZE"]), "write_kb": max(agg[k]["WRITE_SIZE"])} for k in agg
            if "copyBuffer" in k and agg[k].get("FETCH_SIZE") and agg[k].get("WRITE_SIZE")]
-    rec = {"_csrc_sha16": bench.csrc_sha16(), "_source": source, "bytes_per_launch": by_region, "per_kernel": per}
+    # matrix-pipe utilisation and shader clock per region: MFMA busy cycles / (cycles per XCD x 1024 SIMDs); cycles per XCD / duration
+    busy, clock = {}, {}
+    for k in agg:
+        a = agg[k]
+        if a.get("GRBM_GUI_ACTIVE") and a.get("SQ_VALU_MFMA_BUSY_CYCLES") and durations and durations.get(k):
+            gui = mean(k, "GRBM_GUI_ACTIVE") / 8.0
+            short = k.replace("void ", "").replace("scn::wg256h::", "").replace("scn::wgnh::", "")
+            for pat, region in REGIONS.items():
+                if pat in short:
+                    busy[region] = mean(k, "SQ_VALU_MFMA_BUSY_CYCLES") / (gui * 1024.0)
+                    clock[region] = gui / (sum(durations[k]) / len(durations[k])) / 1e3
+    rec = {"_csrc_sha16": bench.csrc_sha16(), "_source": source, "bytes_per_launch": by_region, "per_kernel": per,
+           "mfma_busy": busy, "clock_ghz": clock}
     if bytes_per_step:
         rec["bytes_per_step"] = bytes_per_step
         rec["_bytes_per_step_source"] = ("the same two counters summed over every dispatch of `tools/profile_steps.py pmc` "
@@ -94,7 +106,7 @@ def main():
             bps = step_traffic(sys.argv[sys.argv.index("--steps-dir") + 1], int(sys.argv[sys.argv.index("--steps") + 1]))
         traffic_json(agg, sys.argv[sys.argv.index("--json") + 1],
                      "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, one counter each, --kernel-trace only) of "
-                     "tools/profile_kernels.py at P = 786432 (tools/collect_profiles.sh)", bps)
+                     "tools/profile_kernels.py at P = 786432 (tools/collect_profiles.sh)", bps, dur)
     print("# rocprofv3 --pmc summary of %s (values are per-dispatch means; counters from separate passes)" % d)
     print("# gfx950 notes (MI355X_MICROARCH.md): SQ_* cycle counters are quad-cycles summed over waves; "
           "FETCH_SIZE / WRITE_SIZE are KB; FETCH_SIZE under-reports wide coalesced reads by 2x;")
