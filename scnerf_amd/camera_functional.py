@@ -53,10 +53,14 @@ class CameraMatricesFunction(torch.autograd.Function):
     """apply(intr_init, intr_noise, intr_scale, multiplicative, extr_init, extr_noise, extr_scale, memo) -> K [4,4],
     E [C,4,4]: CameraModel.get_intrinsic() and get_extrinsic() (model/camera_model.py:160-192) as one launch each way,
     differentiable in the two noise tensors.  The four tensors are kept with save_for_backward, so an in-place update
-    between forward and backward (an optimizer step) is caught by autograd's version check instead of silently
-    recomputing the Gram-Schmidt step from the new values.  `memo`: the caller's one-entry cache of this node's outputs
-    (a MatricesMemo, or None; held weakly -- the cached outputs own this node); it is emptied when the node's backward
-    runs: the graph behind the cached outputs is gone then."""
+    between forward and backward is caught by autograd's version check instead of silently recomputing the Gram-Schmidt
+    step from the new values -- torch's own optimizers bump the version with their in-place ops, this package's FusedAdam
+    writes through raw pointers and bumps it explicitly (optim.py, end of step()).  `memo`: the caller's one-entry cache of
+    this node's outputs (a MatricesMemo, or None; held weakly -- the cached outputs own this node); it is emptied when the
+    node's backward runs: the graph behind the cached outputs is gone then.
+    K and E of one parameter version are the two outputs of ONE node: backpropagating a loss through K and, separately, a
+    second loss through E of the same call pair needs `retain_graph=True` on the first backward (in the reference the two
+    getters build independent graphs); summing the losses, as run_nerf.py does, needs nothing."""
 
     @staticmethod
     def forward(ctx, intr_init, intr_noise, intr_scale, multiplicative, extr_init, extr_noise, extr_scale, memo=None):

@@ -106,7 +106,7 @@ class FusedNetworkQuery:
 
 def batchify(fn, chunk):
     """Kept for API parity (reference :187-196); the fused kernel needs no chunking."""
-    if chunk is None:
+    if chunk is None or chunk <= 0:           # (0: `netchunk_per_gpu` absent from args -- no chunking, not range(0, N, 0))
         return fn
 
     def ret(inputs):

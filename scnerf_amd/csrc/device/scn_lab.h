@@ -12,5 +12,10 @@ constexpr bool kNoPe = false;            // no sines / cosines
 constexpr bool kNoStream = false;        // no weight stream (LDS keeps its first chunks)
 constexpr bool kNoBarrier = false;       // no chunk barrier (racy)
 constexpr bool kLateLoads = false;       // the stream's global loads in slots 24 .. 47 instead of 0 .. 23
+// the fp32-MFMA yardstick kernels (mlp_common.h)
+constexpr bool kPlainStore = false;      // workspace stores with the default cache policy instead of non-temporal
+constexpr bool kBurst = false;           // round 1's burst schedule of a chunk's memory instructions instead of the spread one
+constexpr bool kGroupHints = false;      // explicit MFMA / VALU interleave hints in the last chunk
+constexpr bool kNoChain = false;         // no accumulator chaining between chunks
 }  // namespace lab
 }  // namespace scn

@@ -13,6 +13,7 @@
 #pragma once
 #include <type_traits>
 
+#include <scn_lab.h>
 #include <scn_wave.h>
 
 namespace scn {
@@ -69,6 +70,7 @@ static_assert(Var<4>::kNParams == 606596, "NeRF++ background network");
 constexpr int kMaxChunkFwd = 8192;      // floats: 32 KB, x3 buffers = 96 KB LDS
 constexpr int kMaxChunkBwd = 8192;      // floats: 32 KB, x3 buffers = 96 KB LDS
 constexpr int kStreamBufs = 3;
+constexpr int kInterleave = 2;          // accumulator tiles interleaved in the fp32 kernels' MFMA order (4-way measured: forward -0.3 %, dgrad +1.8 %; 2 kept)
 static_assert(kMaxChunkFwd == 8192 && kMaxChunkBwd == 8192, "WStream::buf stride");
 
 // Activation / gradient workspaces.  Offsets are in floats per (padded) sample: a section starts at
@@ -181,11 +183,8 @@ struct WStream {
 // launch -- non-temporal, so the stream does not displace the packed weights every workgroup re-reads from L2
 // (dgrad -0.8 %, forward unchanged)
 __device__ __forceinline__ void store_ws(f32x4* p, f32x4 v) {
-#ifdef SCN_PLAIN_STORE              // (timing experiment)
-    *p = v;
-#else
-    __builtin_nontemporal_store(v, p);
-#endif
+    if constexpr (lab::kPlainStore) *p = v;           // (timing experiment: default cache policy)
+    else __builtin_nontemporal_store(v, p);
 }
 
 // All counts are compile-time so the staging registers stay registers.
@@ -219,12 +218,7 @@ __device__ __forceinline__ void stream_commit(WStream& ws, const f32x4 (&stage)[
 // Chunks with fewer than 8 bundles keep the burst form.
 template <int NB, int N>
 struct Spread {
-    static constexpr bool kOn =
-#ifdef SCN_BURST                    // (timing experiments only: the round-1 schedule)
-        false;
-#else
-        NB >= 8 && N > 0;
-#endif
+    static constexpr bool kOn = !lab::kBurst && NB >= 8 && N > 0;       // (lab::kBurst: the round-1 burst schedule)
     static constexpr int kQ = NB / 4;
     static constexpr int load_at(int i) { return (i * kQ) / (N > 0 ? N : 1); }
     static constexpr int commit_at(int i) { return kQ + (i * 2 * kQ) / (N > 0 ? N : 1); }
@@ -317,20 +311,12 @@ __device__ __forceinline__ void mfma_chunk(const float (&b)[NSTEP], f32x16 (&acc
         // IW tiles are interleaved so that consecutive MFMAs never target the same accumulator: a dependent
         // chain on one accumulator issues slower than 64 cycles (tools/ubench/mfma_dep.hip: 145 / 148 / 151 /
         // 154 TFLOP/s with 1 / 2 / 4 / 8 independent chains).
-#ifndef SCN_IW
-#define SCN_IW 2      // (4-way measured: forward -0.3 %, dgrad +1.8 % -- no gain next to the LDS traffic; 2 kept)
-#endif
-        constexpr int IW = (NT % 4 == 0) ? SCN_IW : 2;
+        constexpr int IW = (NT % 4 == 0) ? kInterleave : 2;
         constexpr int NB = NF / IW;            // fragment bundles (tiles t .. t+IW-1 of the same 4 steps)
         static_assert(NB % 2 == 0 || !(CONT_IN || CONT_OUT), "ring parity across chunks");
-#ifndef SCN_COMMIT_NUM
-#define SCN_COMMIT_NUM 2
-#define SCN_COMMIT_DEN 4
-#define SCN_SYNC_NUM 3
-#define SCN_SYNC_DEN 4
-#endif
-        constexpr int COMMIT_AT = (NB * SCN_COMMIT_NUM) / SCN_COMMIT_DEN;
-        constexpr int SYNC_AT = (NB * SCN_SYNC_NUM) / SCN_SYNC_DEN >= NB ? NB - 1 : (NB * SCN_SYNC_NUM) / SCN_SYNC_DEN;
+        // the next chunk's LDS writes half-way through the chunk, the barrier at three quarters
+        constexpr int COMMIT_AT = (NB * 2) / 4;
+        constexpr int SYNC_AT = (NB * 3) / 4 >= NB ? NB - 1 : (NB * 3) / 4;
         const f32x4* An = reinterpret_cast<const f32x4*>(WStream::buf(ws.next())) + lane;
         constexpr bool SPREAD = Spread<NB, N_F4>::kOn;
         static_assert(!SPREAD || (SYNC_AT == 3 * (NB / 4) && Spread<NB, N_F4>::commit_at(N_F4 - 1) < SYNC_AT),
@@ -451,13 +437,13 @@ struct LastChunk {
             epi.template slice<P - 1, g, 1>();
             epi.template slice<P - 1, g, 2>();
             epi.template slice<P - 1, g, 3>();
-#ifdef SCN_GROUP_HINTS         // (experiment: explicit MFMA/VALU interleave hints were slower than the default schedule)
+            if constexpr (lab::kGroupHints) {     // (experiment: explicit MFMA/VALU interleave hints were slower than the default schedule)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                sched_group_mfma<1>();
-                sched_group_valu<EPI::kValuPerMfma>();
+                for (int k = 0; k < 8; ++k) {
+                    sched_group_mfma<1>();
+                    sched_group_valu<EPI::kValuPerMfma>();
+                }
             }
-#endif
         }
         if constexpr (Q + 1 < NQ) {
             LastChunk<NSTEP, NT, CS, B0, N_F4, CONT_IN, EPI, Q + 1, T0, T1>::run(b, acc, ws, stage, ring, A, epi, save_tile);
@@ -494,11 +480,7 @@ struct PartLoop {
     static constexpr int NC = NSTEP / CS;
     static constexpr int CHUNK_F4 = NT * CS * 64 / 4 / kThreads;
     static constexpr int N_F4 = (C + 1 < NC) ? CHUNK_F4 : NEXT_F4;
-#ifdef SCN_NO_CHAIN
-    static constexpr bool CHAIN = false;
-#else
-    static constexpr bool CHAIN = (NT % 2 == 0) && (((CS / 4) * NT / ((NT % 4 == 0) ? SCN_IW : 2)) % 2 == 0);
-#endif
+    static constexpr bool CHAIN = !lab::kNoChain && (NT % 2 == 0) && (((CS / 4) * NT / ((NT % 4 == 0) ? kInterleave : 2)) % 2 == 0);
     static __device__ __forceinline__ void run(const float (&b)[NSTEP], f32x16 (&acc)[NT], WStream& ws,
                                                f32x4 (&ring)[8], int lane, float* save_tile, EPI& epi) {
         f32x4 stage[N_F4 > 0 ? N_F4 : 1];

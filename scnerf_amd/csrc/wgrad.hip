@@ -705,6 +705,7 @@ int nerf_wgrad(const float* save, const float* grads, const float* d_raw, long l
         rc = pair.k_load == 64 ? launch_wgrad_half_narrow<256, 64, true>(pair.first, pair.G, st)
                                : launch_wgrad_half_narrow<256, 128, true>(pair.first, pair.G, st);
         if (rc != 0) return rc;
+        pair.n = 0;                  // (flushed: a later GEMM of the pair's shape starts a new pair instead of re-launching this one)
     }
     // feature_linear; alpha_linear (one output row) = d sigma^T . act7 with d sigma = d_raw[:, 3]
     SCN_WG(G(kGradDfeat), 256, 256, 256, 1, act(7), 256, 256, 256, 1, P, nb, ws, g + V::kWF, 256, 0, g + V::kBF)

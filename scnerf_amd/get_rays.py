@@ -36,15 +36,22 @@ class _DeferredKeypointCheck:
     def __init__(self):
         import os
         self.pending = []          # (event, pinned flag, message)
+        self.carried = None        # a failure found at a checkpoint boundary, raised by the NEXT poll (see carry())
         self.calls = 0
         self.synchronous = os.environ.get("SCNERF_SYNC_KEYPOINT_CHECK", "0") not in ("", "0")
 
     def _raise_if_set(self, flag, message):
         assert not bool(flag.item()), message
 
+    def carry(self, message):
+        """A failure the caller could not raise where it found it (FusedAdam.state_dict: the checkpoint is written first):
+        it stays pending and the next poll -- the next ray-generation call, render_path, interpreter exit -- raises it."""
+        if self.carried is None:
+            self.carried = message
+
     def poll(self, block=False):
         waiting, self.pending = self.pending, []
-        failed = None
+        failed, self.carried = self.carried, None
         for ev, flag, message in waiting:
             if block:
                 ev.synchronize()

@@ -206,15 +206,19 @@ class FusedAdam(torch.optim.Optimizer):
                              "exp_avg": m.reshape(p.shape).clone(), "exp_avg_sq": v.reshape(p.shape).clone()}
         sd = super().state_dict()
         self.state.clear()
-        # a checkpoint boundary: report any out-of-range key-point batch of the steps so far -- AFTER the state has been
-        # assembled and as a warning: one bad batch (which the reference would have refused when it was drawn) must not
-        # cost the run its checkpoint
+        # a checkpoint boundary: look at the key-point batches of the steps so far -- AFTER the state has been assembled, so
+        # one bad batch (which the reference would have refused when it was drawn) does not cost the run its checkpoint.
+        # The failure is not swallowed: a warning here, and it stays pending -- the next ray-generation call, render_path
+        # or interpreter exit raises the reference's AssertionError (SCNERF_SYNC_KEYPOINT_CHECK=1 is the strict mode that
+        # raises at the faulty call itself).
         from .get_rays import KEYPOINT_CHECK
         try:
             KEYPOINT_CHECK.flush()
         except AssertionError as e:
             import warnings
-            warnings.warn("scnerf_amd.get_rays: %s (found while writing a checkpoint)" % e, RuntimeWarning)
+            warnings.warn("scnerf_amd.get_rays: %s (found while writing a checkpoint; the checkpoint is written, the "
+                          "assertion is raised by the next ray-generation call)" % e, RuntimeWarning)
+            KEYPOINT_CHECK.carry(str(e))
         return sd
 
     def load_state_dict(self, state_dict):
@@ -270,6 +274,9 @@ class FusedAdam(torch.optim.Optimizer):
                                             s.exp_avg_sq.data_ptr(), s.n, float(g["lr"]), float(beta1), float(beta2),
                                             float(g["eps"]), float(g["weight_decay"]), lo, hi, s.step, stream)
             _capi.check(st, "scnerf_adam_step_range")
+        # the kernel wrote the parameters through raw pointers: tell autograd (what an in-place tensor op does), so that a
+        # graph holding an old value refuses a late backward and memos keyed on `_version` (CameraModel._matrices) see the step
+        torch.autograd.graph.increment_version([p for p in g["params"] if p.grad is not None])
         return loss
 
 

@@ -60,22 +60,22 @@ class FlatGradAllReduce:
     def attach(self):
         if self.optimizer is not None:
             return self.optimizer.flat_gradient()
-        o = 0
+        o, self._views = 0, []
         for p in self.params:
-            p.grad = self._own[o:o + p.numel()].view(p.shape)
+            v = self._own[o:o + p.numel()].view(p.shape)
+            p.grad = v
+            self._views.append(v)
             o += p.numel()
 
     def zero(self):
         if self.optimizer is not None:
             return self.optimizer.zero_grad()
         self._own.zero_()
-        # autograd may have replaced a .grad (e.g. after set_to_none): re-point cheaply
-        o = 0
-        for p in self.params:
-            g = p.grad
-            if g is None or g.data_ptr() != self._own.data_ptr() + 4 * o:
-                p.grad = self._own[o:o + p.numel()].view(p.shape)
-            o += p.numel()
+        # autograd may have replaced a .grad (set_to_none, a first accumulation into a fresh tensor): compare by identity
+        # with the view this object attached -- 52 pointer comparisons, no tensor call per parameter per step
+        for p, v in zip(self.params, self._views):
+            if p.grad is not v:
+                p.grad = v
 
     def all_reduce(self, local_rays=None, total_rays=None):
         flat = self.flat

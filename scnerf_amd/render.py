@@ -47,8 +47,10 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     """Volumetric rendering of a ray batch; see the reference docstring (:199-231) for the
     arguments and the returned dict (rgb_map, disp_map, acc_map[, raw][, rgb0, disp0, acc0, z_std]).
 
-    `network_query_fn` must be the FusedNetworkQuery made by scnerf_amd.create_nerf (it carries the
-    embedder configuration the fused kernels were built for).  `_randoms` (tests only) injects
+    `network_query_fn`: the FusedNetworkQuery made by scnerf_amd.create_nerf (it carries the embedder configuration the
+    fused kernels were built for) takes the fused path when the networks have the standard shape and the batch has view
+    directions; any other callable -- or network shape -- is called as the reference calls it, between the same HIP
+    samplers and compositing kernels (`_render_rays_opaque`).  `_randoms` (tests only) injects
     dict(t_rand=, u=, noise_c=, noise_f=) instead of drawing them."""
     net_c = _unwrap(network_fn)
     net_f = _unwrap(network_fine) if network_fine is not None else None

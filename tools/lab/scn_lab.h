@@ -38,5 +38,25 @@ constexpr bool kLateLoads = true;
 #else
 constexpr bool kLateLoads = false;
 #endif
+#ifdef SCN_PLAIN_STORE
+constexpr bool kPlainStore = true;
+#else
+constexpr bool kPlainStore = false;
+#endif
+#ifdef SCN_BURST
+constexpr bool kBurst = true;
+#else
+constexpr bool kBurst = false;
+#endif
+#ifdef SCN_GROUP_HINTS
+constexpr bool kGroupHints = true;
+#else
+constexpr bool kGroupHints = false;
+#endif
+#ifdef SCN_NO_CHAIN
+constexpr bool kNoChain = true;
+#else
+constexpr bool kNoChain = false;
+#endif
 }  // namespace lab
 }  // namespace scn
