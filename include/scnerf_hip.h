@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SCNERF_ABI_VERSION 3
+#define SCNERF_ABI_VERSION 4
 
 int scnerf_abi_version(void);
 
@@ -43,6 +43,15 @@ int scnerf_searchsorted(const float* a, const float* v, int64_t* out, int nrow, 
 int scnerf_sample_pdf(const float* bins, const float* weights, const float* u, int u_row_stride,
                       float* samples, int64_t* inds, float* cdf, int n, int nb, int ns,
                       void* stream);
+
+/* The random numbers of one render_rays call in ONE launch: the stratified jitter t_rand [n_t_rand] in [0, 1)
+ * (NeRF/render.py:252-257), the inverse-cdf variates u [n_u] in [0, 1) (:425-429) and the density noise of the coarse and
+ * the fine stage, standard normal x raw_noise_std (:329-330, called at :262 and :285).  Any pointer may be NULL (that draw
+ * is skipped); non-NULL pointers are 16-byte aligned.  Philox4x32-10 keyed by `seed`, counter = (element / 4, stream, call):
+ * a pure function of its arguments, replacing four torch.rand / torch.randn launches and their scaling passes. */
+int scnerf_render_randoms(unsigned long long seed, unsigned long long call, float* t_rand, long long n_t_rand,
+                          float* u, long long n_u, float* noise_c, long long n_noise_c, float* noise_f,
+                          long long n_noise_f, float raw_noise_std, void* stream);
 
 /* Stratified coarse samples + points, NeRF/render.py:235-259.
  * rays [n, ray_stride] = [o(3) d(3) near far ...]; t_vals [s] = linspace(0,1,s) (host made);

@@ -354,6 +354,25 @@ def camera_extrinsics(cam: Dict[str, Tensor]):
     return ortho6d_to_rotation(e[:, :6]), e[:, 6:]
 
 
+def camera_K(cam: Dict[str, Tensor]) -> Tensor:
+    """CameraModel.get_intrinsic(): the 4 x 4 matrix with fx, fy on the diagonal and cx, cy in column 2
+    (model/camera_utils.py:191-195 on the parameters of model/camera_model.py:166-177)."""
+    fx, fy, cx, cy = camera_intrinsic_params(cam)
+    one, zero = torch.ones_like(fx), torch.zeros_like(fx)
+    return torch.stack([torch.stack([fx, zero, cx, zero]), torch.stack([zero, fy, cy, zero]),
+                        torch.stack([zero, zero, one, zero]), torch.stack([zero, zero, zero, one])])
+
+
+def camera_E(cam: Dict[str, Tensor]) -> Tensor:
+    """CameraModel.get_extrinsic(): [C, 4, 4] camera-to-world matrices, rotation from the 6-D parameters, translation in
+    column 3 (model/camera_model.py:179-192, camera_utils.py:184-188)."""
+    rot, trans = camera_extrinsics(cam)
+    top = torch.cat([rot, trans[:, :, None]], -1)
+    bottom = torch.zeros_like(top[:, :1, :])
+    bottom = torch.cat([bottom[:, :, :3], torch.ones_like(bottom[:, :, :1])], -1)
+    return torch.cat([top, bottom], 1)
+
+
 def upsample_noise_grid(grid: Tensor, H: int, W: int, scale: float) -> Tensor:
     """CameraModel.get_ray_{o,d}_noise (camera_model.py:24-46): bilinear
     (align_corners=False) upsampling of the [H/g, W/g, 3] grid to [H*W, 3]."""

@@ -24,6 +24,7 @@ PROTOTYPES = {
     "scnerf_abi_version": [],
     "scnerf_searchsorted": [P, P, P, I, I, I, I, I, I, P],
     "scnerf_sample_pdf": [P, P, P, I, P, P, P, I, I, I, P],
+    "scnerf_render_randoms": [ctypes.c_ulonglong, ctypes.c_ulonglong, P, LL, P, LL, P, LL, P, LL, F, P],
     "scnerf_coarse_sample": [P, I, P, P, P, P, I, I, I, P],
     "scnerf_fine_sample": [P, I, P, P, P, I, P, P, P, P, P, P, I, I, I, P],
     "scnerf_camera_rays_fwd": [P, P, I, P, I, P, P, F, I, P, P, F, I, P, F, P, F, I, I, I, I, P, P, I, P],
@@ -121,7 +122,7 @@ def load() -> ctypes.CDLL:
                 "libscnerf_hip.so is not built (%s). Run `python -m scnerf_amd.csrc.build` "
                 "(or __graft_entry__.build()); scnerf_amd has no CPU fallback." % LIB_PATH)
         _lib = bind(ctypes.CDLL(LIB_PATH))
-        if _lib.scnerf_abi_version() != 3:
+        if _lib.scnerf_abi_version() != 4:
             raise ScnerfLibraryError("ABI version mismatch")
     return _lib
 

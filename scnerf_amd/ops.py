@@ -117,6 +117,32 @@ def sample_pdf(bins: Tensor, weights: Tensor, u: Tensor, want_inds=False, want_c
     return samples, inds, cdf
 
 
+_random_calls = [0]
+
+
+def render_randoms(n: int, n_samples: int, n_importance: int, raw_noise_std: float, device, want_t_rand=True, want_u=True):
+    """The draws of one render_rays call in ONE launch (csrc/randoms.hip; reference NeRF/render.py:252-257, :329-330,
+    :425-429): -> (t_rand [n, S] | None, u [n, N_importance] | None, noise_c [n, S] | None, noise_f [n, S + N_importance] |
+    None), the noises already multiplied by raw_noise_std.  Philox4x32-10 keyed by torch.initial_seed(), counter = (element,
+    stream, a per-process call counter): reproducible from torch.manual_seed for a given sequence of calls."""
+    S, F = int(n_samples), int(n_importance)
+    sizes = [n * S if want_t_rand else 0, n * F if (want_u and F > 0) else 0,
+             n * S if raw_noise_std > 0 else 0, n * (S + F) if (raw_noise_std > 0 and F > 0) else 0]
+    padded = [(z + 3) // 4 * 4 for z in sizes]
+    buf = torch.empty(sum(padded), dtype=torch.float32, device=device)
+    outs, o = [], 0
+    for z, pz in zip(sizes, padded):
+        outs.append(buf[o:o + z] if z else None)
+        o += pz
+    _random_calls[0] += 1
+    st = _capi.load().scnerf_render_randoms(torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, _random_calls[0],
+                                            _p(outs[0]), sizes[0], _p(outs[1]), sizes[1], _p(outs[2]), sizes[2],
+                                            _p(outs[3]), sizes[3], float(max(raw_noise_std, 0.0)), _stream())
+    _capi.check(st, "scnerf_render_randoms")
+    shapes = [(n, S), (n, F), (n, S), (n, S + F)]
+    return tuple(None if t is None else t.view(sh) for t, sh in zip(outs, shapes))
+
+
 def coarse_sample(rays: Tensor, t_vals: Tensor, t_rand: Optional[Tensor], lindisp: bool):
     _f(rays, "rays"), _f(t_vals, "t_vals")
     n, s = rays.shape[0], t_vals.shape[0]

@@ -41,28 +41,9 @@ def _device_rand(shape, device, pytest):
     return torch.rand(shape, device=device)
 
 
-def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False,
-                perturb=0., N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0.,
-                verbose=False, pytest=False, _randoms=None):
-    """Volumetric rendering of a ray batch; see the reference docstring (:199-231) for the
-    arguments and the returned dict (rgb_map, disp_map, acc_map[, raw][, rgb0, disp0, acc0, z_std]).
-
-    `network_query_fn`: the FusedNetworkQuery made by scnerf_amd.create_nerf (it carries the embedder configuration the
-    fused kernels were built for) takes the fused path when the networks have the standard shape and the batch has view
-    directions; any other callable -- or network shape -- is called as the reference calls it, between the same HIP
-    samplers and compositing kernels (`_render_rays_opaque`).  `_randoms` (tests only) injects
-    dict(t_rand=, u=, noise_c=, noise_f=) instead of drawing them."""
-    net_c = _unwrap(network_fn)
-    net_f = _unwrap(network_fine) if network_fine is not None else None
-    if not ops._capi.on_device(ray_batch):
-        raise RuntimeError("ray_batch must be on the GPU: scnerf_amd has no CPU path")
-    # the fused path: the standard network(s) behind a query object that carries the standard encodings, view directions in
-    # the batch.  Anything else at this boundary is an opaque callable, as in the reference (:186-300): called as it is.
-    fused_for = getattr(network_query_fn, "fused_for", None)
-    fused = (fused_for is not None and fused_for(net_c) and (net_f is None or fused_for(net_f)) and ray_batch.shape[-1] > 8)
-    n = ray_batch.shape[0]
-    dev = ray_batch.device
-    r = _randoms or {}
+def _host_side_draws(r, n, N_samples, N_importance, perturb, raw_noise_std, dev, pytest):
+    """the draws of one render_rays call as the reference makes them, one tensor at a time (:252-257, :329-336, :425-440):
+    injected values (`_randoms`, tests), the fixed numpy stream of `pytest` mode, else torch's device generator"""
     t_rand = u = noise_c = noise_f = None
     if perturb > 0.:
         t_rand = r["t_rand"] if "t_rand" in r else _device_rand((n, N_samples), dev, pytest)
@@ -86,6 +67,39 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
                 noise_f = torch.Tensor(np.random.rand(n, tot) * raw_noise_std).to(dev)
             else:
                 noise_f = torch.randn((n, tot), device=dev) * raw_noise_std
+    return t_rand, u, noise_c, noise_f
+
+
+def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False,
+                perturb=0., N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0.,
+                verbose=False, pytest=False, _randoms=None):
+    """Volumetric rendering of a ray batch; see the reference docstring (:199-231) for the
+    arguments and the returned dict (rgb_map, disp_map, acc_map[, raw][, rgb0, disp0, acc0, z_std]).
+
+    `network_query_fn`: the FusedNetworkQuery made by scnerf_amd.create_nerf (it carries the embedder configuration the
+    fused kernels were built for) takes the fused path when the networks have the standard shape and the batch has view
+    directions; any other callable -- or network shape -- is called as the reference calls it, between the same HIP
+    samplers and compositing kernels (`_render_rays_opaque`).  `_randoms` (tests only) injects
+    dict(t_rand=, u=, noise_c=, noise_f=) instead of drawing them."""
+    net_c = _unwrap(network_fn)
+    net_f = _unwrap(network_fine) if network_fine is not None else None
+    if not ops._capi.on_device(ray_batch):
+        raise RuntimeError("ray_batch must be on the GPU: scnerf_amd has no CPU path")
+    # the fused path: the standard network(s) behind a query object that carries the standard encodings, view directions in
+    # the batch.  Anything else at this boundary is an opaque callable, as in the reference (:186-300): called as it is.
+    fused_for = getattr(network_query_fn, "fused_for", None)
+    fused = (fused_for is not None and fused_for(net_c) and (net_f is None or fused_for(net_f)) and ray_batch.shape[-1] > 8)
+    n = ray_batch.shape[0]
+    dev = ray_batch.device
+    r = _randoms or {}
+    t_rand = u = noise_c = noise_f = None
+    if not r and not pytest and (perturb > 0. or raw_noise_std > 0.):
+        # the throughput path: every draw of this call from ONE launch (csrc/randoms.hip) instead of four generator launches
+        # and their scaling passes; the `pytest` mode and injected draws take the branches below, as the reference's
+        t_rand, u, noise_c, noise_f = ops.render_randoms(n, N_samples, N_importance, raw_noise_std, dev,
+                                                         want_t_rand=perturb > 0., want_u=perturb > 0.)
+    elif perturb > 0. or raw_noise_std > 0.:
+        t_rand, u, noise_c, noise_f = _host_side_draws(r, n, N_samples, N_importance, perturb, raw_noise_std, dev, pytest)
     if not fused:
         return _render_rays_opaque(ray_batch, network_fn, network_query_fn, int(N_samples), retraw, bool(lindisp),
                                    int(N_importance), network_fine, bool(white_bkgd), t_rand, u, noise_c, noise_f,

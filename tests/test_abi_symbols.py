@@ -31,7 +31,7 @@ def test_product_library_exports_every_symbol():
     lib = ctypes.CDLL(_capi.LIB_PATH)
     for name in declared():
         assert hasattr(lib, name), name
-    assert lib.scnerf_abi_version() == 3
+    assert lib.scnerf_abi_version() == 4
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

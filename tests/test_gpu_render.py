@@ -224,7 +224,8 @@ def _kernel_gates(save, P, pd=3):
     return [torch.from_numpy(_gates_from_masks(masks[l], P, 8 if l < 8 else 4)) for l in range(9)]
 
 
-def test_training_gradients_with_both_discontinuities_aligned(R):
+@pytest.mark.parametrize("n", [256, 4096], ids=["256rays", "4096rays"])
+def test_training_gradients_with_both_discontinuities_aligned(R, n):
     """The golden cases bound the gradients behind the hierarchical sampler only loosely: one sample the reference
     algorithm places discontinuously (render.py:444, :455-456) or one ReLU whose pre-activation is a rounding from
     zero shifts every entry of a weight gradient a little at 24 rays.  Here both discontinuities are taken out of the
@@ -235,7 +236,7 @@ def test_training_gradients_with_both_discontinuities_aligned(R):
     (tests/test_gpu_kernels.py::test_relu_gate_flips_are_attributed).  How many decisions differ from the oracle's
     own goes to the report."""
     from scnerf_amd.functional import host_linspace
-    n, sc, sf = 256, 64, 128
+    sc, sf = 64, 128                       # (4096 rays: the headline batch -- 8.6e8 ReLU decisions taken from the bit masks)
     net_c, net_f = make_net(R, 0), make_net(R, 1)
     rays = synth.ray_batch(n, seed=11)
     rnd = synth.render_randoms(n, sc, sf, seed=12)
@@ -279,7 +280,7 @@ def test_training_gradients_with_both_discontinuities_aligned(R):
     cols = [0, 1, 2, 3, 4, 5, 8, 9, 10]
     ge = np.abs(rays_d.grad[:, cols].cpu().numpy() - rays_o.grad[:, cols].numpy()).max(1) / np.abs(rays_o.grad.numpy()).max()
     worst = max(rep, key=lambda k_: rep[k_][1])
-    REPORT["training_gradients_discontinuities_aligned_256x(64+128)"] = dict(
+    REPORT["training_gradients_discontinuities_aligned_%dx(64+128)" % n] = dict(
         relu_decisions=n_gates, relu_decisions_differing_from_the_oracles_own=flips,
         worst_q999=max(v[0] for v in rep.values()), worst_max=rep[worst][1], worst_parameter=worst,
         d_ray_batch_worst_ray=float(ge.max()))

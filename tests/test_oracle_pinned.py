@@ -204,3 +204,33 @@ def test_rotation_to_ortho6d_is_the_references():
     if ref_import.reference_available():
         ns = ref_import.load_reference()
         assert torch.equal(p6, ns.camera_utils.rotation2orth(R))
+
+
+def test_camera_K_and_E_are_the_references():
+    """oracle.camera_K / camera_E (what the combined configs[3] gradient test feeds the oracle's projected-ray-distance
+    loss) against the reference's own get_intrinsic() / get_extrinsic() (model/camera_model.py:160-192) where the tree is
+    present; everywhere: K's layout (camera_utils.py:191-195) and E's rigid structure."""
+    spec = synth.camera_spec(378, 504, n_cams=6, seed=21, multiplicative=True)
+    cam = O.camera_state(spec)
+    K, E = O.camera_K(cam), O.camera_E(cam)
+    fx, fy, cx, cy = O.camera_intrinsic_params(cam)
+    want = torch.eye(4)
+    want[0, 0], want[1, 1], want[0, 2], want[1, 2] = fx, fy, cx, cy
+    assert torch.equal(K, want)
+    rot, trans = O.camera_extrinsics(cam)
+    assert torch.equal(E[:, :3, :3], rot) and torch.equal(E[:, :3, 3], trans)
+    assert torch.equal(E[:, 3], torch.tensor([0., 0., 0., 1.]).expand(6, 4))
+    from oracle import ref_import
+    if ref_import.reference_available():
+        import types
+        ns = ref_import.load_reference()
+        args = types.SimpleNamespace(camera_model="pinhole_rot_noise_10k_rayo_rayd", grid_size=10,
+                                     ray_o_noise_scale=spec["ray_o_noise_scale"], ray_d_noise_scale=spec["ray_d_noise_scale"],
+                                     extrinsics_noise_scale=spec["extrinsics_noise_scale"],
+                                     intrinsics_noise_scale=spec["intrinsics_noise_scale"], multiplicative_noise=True)
+        ref = ns.camera_model.PinholeModelRotNoiseLearning10kRayoRayd(spec["K_init"], list(spec["poses"].numpy()), args, 378, 504)
+        with torch.no_grad():
+            ref.intrinsics_noise.copy_(spec["intrinsics_noise"])
+            ref.extrinsics_noise.copy_(spec["extrinsics_noise"])
+        close(K, ref.get_intrinsic().detach().numpy(), atol=0)
+        close(E, ref.get_extrinsic().detach().numpy(), atol=1e-6)
