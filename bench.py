@@ -840,13 +840,13 @@ def main():
                                 "two (per sample from the row / column 1-norm bound x the measured input maximum; per layer for "
                                 "the weights) and cut into 2 fp16 numbers, 3 partial products on v_mfma_f32_32x32x16_f16, fp32 "
                                 "accumulate; activations register-resident from layer to layer; per-layer error vs fp64 = the "
-                                "fp32 MFMA's (profiles/parity_r04.json resident_layer_arithmetic_*)",
+                                "fp32 MFMA's (profiles/parity_r05.json resident_layer_arithmetic_*)",
                     "fp32": "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32 (fused kernels)"}[ops.mlp_arithmetic()],
                 "256x256 weight gradients": {
                     "half": "fp32 operands scaled by one power of two per operand and workgroup chunk (the chunk maxima come "
                             "from the resident kernels) and cut into 2 fp16 numbers, 3 partial products on "
                             "v_mfma_f32_32x32x16_f16, fp32 accumulate (csrc/wgrad256_half.h); error vs fp64 = the fp32 MFMA "
-                            "kernel's (profiles/parity_r04.json wgrad256_arithmetic_*)",
+                            "kernel's (profiles/parity_r05.json wgrad256_arithmetic_*)",
                     "fp32": "fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32"}[
                         "half" if (ops.wgrad_arithmetic() == "half" and ops.mlp_arithmetic() == "resident") else "fp32"],
                 "narrow weight gradients": (

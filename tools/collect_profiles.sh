@@ -4,7 +4,7 @@
 # 1. kernel trace of the default bench workload (per-kernel durations; --kernel-trace only)
 # 2. counters, ONE per pass (--pmc with --kernel-trace only, as the pool requires), of tools/profile_kernels.py
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
