@@ -38,13 +38,6 @@ __device__ __forceinline__ f32x16 mfma_32x32x16_f16(s16x8 a, s16x8 b, f32x16 c) 
     typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
-// v_mfma_f32_16x16x32_f16: D[16x16] += A[16x32] * B[32x16], 16 cycles/SIMD (half the MACs of the 32x32x16 form per 1 KB
-// operand).  Lane l supplies A[i = l&15][k = 8 (l>>4) .. +7] and B[k = 8 (l>>4) .. +7][j = l&15]; it receives column
-// j = l&15 of D, rows 4 (l>>4) + r for r = 0..3.
-__device__ __forceinline__ f32x4 mfma_16x16x32_f16(s16x8 a, s16x8 b, f32x4 c) {
-    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
 // fp32 -> fp16 (round to nearest even) as a bit pattern in the low half of a word, and back
 __device__ __forceinline__ unsigned f16_bits(float x) { return __builtin_bit_cast(unsigned short, (_Float16)x); }
 __device__ __forceinline__ float f16_value(unsigned bits) { return (float)__builtin_bit_cast(_Float16, (unsigned short)bits); }

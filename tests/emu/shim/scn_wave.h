@@ -111,30 +111,6 @@ inline f32x16 mfma_32x32x16_f16(s16x8 a, s16x8 b, f32x16 c) {
     }
     return c;
 }
-// v_mfma_f32_16x16x32_f16: lane l gives A[l&15][8 (l>>4) .. +7], B[8 (l>>4) .. +7][l&15]; receives column l&15, rows 4 (l>>4) + r
-inline f32x4 mfma_16x16x32_f16(s16x8 a, s16x8 b, f32x4 c) {
-    uint64_t mine[4];
-    std::memcpy(&mine[0], &a, 16);
-    std::memcpy(&mine[2], &b, 16);
-    uint64_t all[4][64];
-    for (int w = 0; w < 4; ++w) {
-        const uint64_t* x = simt::wave_exchange(mine[w]);
-        std::memcpy(all[w], x, sizeof(all[w]));
-    }
-    auto elem = [&](int word0, int lane, int k) {
-        const uint64_t u = all[word0 + (k >> 2)][lane];
-        return f16_value((unsigned)(uint16_t)(u >> (16 * (k & 3))));
-    };
-    const int l = simt::cur_lane();
-    const int j = l & 15, g = l >> 4;
-    for (int r = 0; r < 4; ++r) {
-        const int i = 4 * g + r;
-        double sum = 0.0;
-        for (int k = 0; k < 32; ++k) sum += (double)elem(0, i + 16 * (k >> 3), k & 7) * (double)elem(2, j + 16 * (k >> 3), k & 7);
-        c[r] = (float)((double)c[r] + sum);
-    }
-    return c;
-}
 // ds_read_b64_tr_b16: lane c of a 16-lane group names row c >> 2, columns 4 (c & 3) .. +3 of the group's
 // [4][16] block and receives column c
 inline s16x4 lds_read_tr16(const short* p) {

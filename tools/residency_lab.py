@@ -143,12 +143,14 @@ def build_emu():
     csrc = os.path.join(ROOT, "scnerf_amd", "csrc")
     srcs = [os.path.join(ROOT, "tools", "ubench", f) for f in ("residency_lab.hip", "residency_lds_lab.hip")]
     srcs = [s for s in srcs if os.path.isfile(s)] + [os.path.join(shim, "simt_emu.cpp")]
-    deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")] + [os.path.join(shim, "scn_wave.h")]
+    deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")] + [os.path.join(shim, "scn_wave.h"),
+                                                                                         os.path.join(ROOT, "tools", "ubench", "mlp_h3p.h")]
     if os.path.isfile(out) and all(os.path.getmtime(out) > os.path.getmtime(d) for d in deps):
         return out
     cxx = "/opt/rocm/lib/llvm/bin/clang++"
     flags = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-DSCNERF_SIMT_EMU_BUILD=1",
-             "-I", shim, "-I", csrc, "-I", os.path.join(ROOT, "include"), "-idirafter", os.path.join(csrc, "device"),
+             "-I", shim, "-I", os.path.join(ROOT, "tools", "ubench"), "-I", csrc, "-I", os.path.join(ROOT, "include"),
+             "-idirafter", os.path.join(csrc, "device"), "-Wno-psabi",
              "-Wno-unknown-pragmas", "-Wno-unused-variable"]
     objs = []
     for s in srcs:

@@ -12,7 +12,7 @@ build() {
   for f in residency_lab residency_lds_lab; do
     [ -f tools/ubench/$f.hip ] || continue
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math $defs ${SAVE_TEMPS:+-save-temps=obj} \
-      -Itools/lab -Iscnerf_amd/csrc/device -Iscnerf_amd/csrc -Iinclude -Wall -Wno-unused-function \
+      -Itools/lab -Itools/ubench -Iscnerf_amd/csrc/device -Iscnerf_amd/csrc -Iinclude -Wall -Wno-unused-function \
       -c tools/ubench/$f.hip -o /tmp/${f}_${tag:-plain}.o &
     objs="$objs /tmp/${f}_${tag:-plain}.o"
   done

@@ -1,4 +1,4 @@
-// mlp_h3p.h -- the resident arithmetic of mlp_h3.h in its PAIRED residency: 16 samples per wave on
+// mlp_h3p.h -- LAB (tools/ubench/residency_lab.hip; never part of the product build): the resident arithmetic of mlp_h3.h in its PAIRED residency: 16 samples per wave on
 // v_mfma_f32_16x16x32_f16, eight waves per workgroup = TWO waves per SIMD at <= 256 registers.
 //
 // Why.  mlp_h3.h's wave owns 32 samples x 256 features: two operand buffers of 128 registers each, ~490 of the 512 a lone
@@ -15,13 +15,13 @@
 // rate.  ds_read_b128 moves 256 B per clock per CU on gfx950 (MI355X_MICROARCH.md, LDS table; round 4's arithmetic took
 // 128 and called this residency LDS-bound) -- 0.67 of the LDS array, plus the stream's writes.  Measured:
 // profiles/r05_lab_residency.txt (tools/ubench/residency_lab.hip runs a chain of eight 256 -> 256 layers in both
-// residencies from these very building blocks).
+// residencies from the product's building blocks and these).
 //
 // Shape.  Wave = 16 samples x all features.  The product is computed transposed, D[feature][sample]: lane (m = l & 15,
 // g = l >> 4) owns feature 16 T + 4 g + j of sample m in register j of output tile T (16 features).  The MFMA contracts
 // 32 k per instruction, 8 per lane group: the two accumulators (2 s, 2 s + 1) of a lane ARE its 8 elements of K slab s of
 // the next layer -- element e of lane group g is feature 32 s + 16 (e >> 2) + 4 g + (e & 3) -- once the weights are packed
-// in that order (mlp_layout.h3p_plan).  Output tiles are produced pair by pair as in mlp_h3.h: a pair = one K slab of the
+// in that order (tools/residency_lab.py: fragment_index).  Output tiles are produced pair by pair as in mlp_h3.h: a pair = one K slab of the
 // next layer, its epilogue (two pieces of four registers) dealt out under the next pair's 48 MFMA slots.
 //
 // Weight stream: mlp_h3.h's format -- 16-byte A fragments in consumption order, a unit = [Wh T0][Wh T1][Wl T0][Wl T1] of
@@ -35,6 +35,42 @@
 #include "mlp_h3.h"
 
 namespace scn {
+
+#ifndef SCNERF_SIMT_EMU_BUILD
+// v_mfma_f32_16x16x32_f16: D[16x16] += A[16x32] * B[32x16], 16 cycles/SIMD (half the MACs of the 32x32x16 form per 1 KB
+// operand).  Lane l supplies A[i = l&15][k = 8 (l>>4) .. +7] and B[k = 8 (l>>4) .. +7][j = l&15]; it receives column
+// j = l&15 of D, rows 4 (l>>4) + r for r = 0..3.
+__device__ __forceinline__ f32x4 mfma_16x16x32_f16(s16x8 a, s16x8 b, f32x4 c) {
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+#else
+// v_mfma_f32_16x16x32_f16: lane l gives A[l&15][8 (l>>4) .. +7], B[8 (l>>4) .. +7][l&15]; receives column l&15, rows 4 (l>>4) + r
+inline f32x4 mfma_16x16x32_f16(s16x8 a, s16x8 b, f32x4 c) {
+    uint64_t mine[4];
+    std::memcpy(&mine[0], &a, 16);
+    std::memcpy(&mine[2], &b, 16);
+    uint64_t all[4][64];
+    for (int w = 0; w < 4; ++w) {
+        const uint64_t* x = simt::wave_exchange(mine[w]);
+        std::memcpy(all[w], x, sizeof(all[w]));
+    }
+    auto elem = [&](int word0, int lane, int k) {
+        const uint64_t u = all[word0 + (k >> 2)][lane];
+        return f16_value((unsigned)(uint16_t)(u >> (16 * (k & 3))));
+    };
+    const int l = simt::cur_lane();
+    const int j = l & 15, g = l >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g + r;
+        double sum = 0.0;
+        for (int k = 0; k < 32; ++k) sum += (double)elem(0, i + 16 * (k >> 3), k & 7) * (double)elem(2, j + 16 * (k >> 3), k & 7);
+        c[r] = (float)((double)c[r] + sum);
+    }
+    return c;
+}
+#endif
+
 namespace h3p {
 
 using namespace scn::mlp;
