@@ -96,6 +96,52 @@ def pack_stream(wts, sc, kind_rows):
     return np.ascontiguousarray(np.concatenate([stream, pad]))
 
 
+def pack_stream_lds(wts, sc):
+    """candidate (b): per layer and K slab one 16 KB ring slot: [feature tile 8][plane 2] fragments (rows 32 T + n, today's k order)"""
+    lane = np.arange(64)
+    n, g, e = lane & 31, lane >> 5, np.arange(8)
+    out = []
+    for l in range(LAYERS):
+        ws = wts[l].astype(np.float32) * sc[l, 0]
+        hi = ws.astype(np.float16)
+        lo = (ws - hi.astype(np.float32)).astype(np.float16)
+        for sl in range(16):
+            cols = feature_of_32(sl, g[:, None], e[None, :])
+            for T in range(8):
+                rows = np.broadcast_to((32 * T + n)[:, None], (64, 8))
+                out.append(hi[rows, cols])
+                out.append(lo[rows, cols])
+    stream = np.stack(out).reshape(-1)
+    return np.ascontiguousarray(np.concatenate([stream, np.zeros(2 * 32 * 512, np.float16)]))
+
+
+def check_lds(acc, wts, sc, P):
+    """the last layer's accumulators [workgroup][wave][ft][st][r 16][lane 64] against W_7 x0 in fp64"""
+    a = acc.reshape(-1, 8, 2, 2, 16, 64)
+    wg = np.array([0, a.shape[0] - 1])
+    lane = np.arange(64)
+    m, g = lane & 31, lane >> 5
+    r = np.arange(16)
+    worst, sq, cnt = 0.0, 0.0, 0
+    s0 = float(scale_for(1.0))
+    for w in wg:
+        for wave in range(8):
+            fb, sb = wave >> 1, wave & 1
+            for ft in range(2):
+                for st in range(2):
+                    feat = 64 * fb + 32 * ft + (r[:, None] & 3) + 8 * (r[:, None] >> 2) + 4 * g[None, :]        # [16, 64]
+                    samp = w * 128 + 64 * sb + 32 * st + m                                                  # [64]
+                    x0 = lab_input(samp, np.arange(W)).astype(np.float64)                                   # [64, 256]
+                    ref = np.einsum("rlk,lk->rl", wts[LAYERS - 1].astype(np.float64)[feat], x0)
+                    mag = np.einsum("rlk,lk->rl", np.abs(wts[LAYERS - 1].astype(np.float64))[feat], np.abs(x0))
+                    got = a[w, wave, ft, st].astype(np.float64) / (float(sc[LAYERS - 1, 0]) * s0)
+                    err = np.abs(got - ref) / mag
+                    worst = max(worst, float(err.max()))
+                    sq += float((err ** 2).sum())
+                    cnt += err.size
+    return worst, (sq / cnt) ** 0.5, cnt
+
+
 def untile(block, P):
     """tile-native section [P/32][t 8][q 4][lane 64][4] -> [P, 256]"""
     b = block.reshape(-1, 8, 4, 2, 32, 4)          # tile, t, q, h, m, j
@@ -184,6 +230,10 @@ def main():
     run.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
     save_floats = SECTIONS * W * Ppad + SECTIONS * 8 * Ppad
     streams = {32: pack_stream(wts, sc, 32), 16: pack_stream(wts, sc, 16)}
+    if any(k.startswith("lds") for k in args.kinds.split(",")):
+        streams["lds"] = pack_stream_lds(wts, sc)
+        run_lds = lib.residency_lds_lab_run
+        run_lds.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
     check_rows = np.unique(np.concatenate([np.arange(0, min(P, 64)), np.arange(max(0, P - 64), P),
                                           (np.arange(16) * 7919 * 32) % max(P - 32, 1)]))
     ref, mag = (None, None) if args.no_check else reference(wts, bias, check_rows)
@@ -199,9 +249,35 @@ def main():
     for name in args.kinds.split(","):
         kind = KINDS[name]
         rows = 32 if name.startswith("h3") and not name.startswith("h3p") else 16
-        if name.startswith("lds"):
-            rows = 32
         ms = np.zeros(max(args.reps, 1), np.float32)
+        if name.startswith("lds"):
+            n_acc = Ppad // 128 * 8 * 4 * 16 * 64
+            assert n_acc <= save_floats
+            if hip:
+                st = run_lds(d_streams["lds"], d_save, P, args.reps, ms.ctypes.data_as(ctypes.c_void_p))
+                hip.sync()
+                acc = np.zeros(n_acc, np.float32)
+                if not args.no_check:
+                    hip.download(d_save, 0, acc)
+            else:
+                st = run_lds(streams["lds"].ctypes.data_as(ctypes.c_void_p), save.ctypes.data_as(ctypes.c_void_p), P, 1,
+                             ms.ctypes.data_as(ctypes.c_void_p))
+                acc = save[:n_acc]
+            assert st == 0, "residency_lds_lab_run -> %d" % st
+            rec = {"kind": name, "samples": P, "status": st, "note": "bare: MFMAs + fragment reads + ring + one barrier per K slab"}
+            if not args.no_check:
+                mx, rms, cnt = check_lds(acc, wts, sc, P)
+                rec.update(check_values=cnt, max_err_over_sum_abs=mx, rms_err_over_sum_abs=rms, ok=bool(mx < 2e-6))
+            if hip:
+                t = np.sort(ms[1:] if len(ms) > 1 else ms)
+                flop = 2.0 * LAYERS * W * W * P
+                rec.update(ms_best=float(t[0]), ms_median=float(t[len(t) // 2]), ms_per_layer=float(t[0]) / LAYERS,
+                           fp32_tflops=flop / float(t[0]) * 1e-9, issued_fp16_tflops=3 * flop / float(t[0]) * 1e-9,
+                           frac_of_2500=3 * flop / float(t[0]) * 1e-9 / 2500.0)
+            print(json.dumps(rec), flush=True)
+            if rec.get("ok") is False:
+                sys.exit(1)
+            continue
         if hip:
             assert hip.rt.hipMemset(d_save, 0, ctypes.c_size_t(SECTIONS * W * Ppad * 4)) == 0
             st = run(kind, d_streams[rows], d_bias, d_sc, d_save, d_out, P, args.reps, ms.ctypes.data_as(ctypes.c_void_p))
