@@ -117,6 +117,11 @@ class CameraModel(nn.Module):
 
 
 class _PinholeRotNoise(CameraModel):
+    # get_intrinsic() and get_extrinsic() of one parameter version share ONE autograd node (one launch each way for the
+    # pair).  A script that backpropagates a loss through K and, separately, another through E of the same getter pair
+    # either passes retain_graph=True to the first backward or sets this to False (per instance or on the class).
+    share_matrix_node = True
+
     def focal_xy(self):
         """[fx, fy] of get_intrinsic() without building the 4x4 matrix (what the NDC warp needs per step)."""
         p = self.intrinsics_initial[:2]
@@ -132,6 +137,12 @@ class _PinholeRotNoise(CameraModel):
         from . import _capi
         if not _capi.on_device(self.intrinsics_noise):
             return None
+        if not self.share_matrix_node:
+            # the reference's structure: every getter call builds a graph of its own (two separate backward passes through
+            # K and through E work without retain_graph), at one launch each way per call
+            return CameraMatricesFunction.apply(self.intrinsics_initial, self.intrinsics_noise, self.intrinsics_noise_scale,
+                                                self.multiplicative_noise, self.extrinsics_initial, self.extrinsics_noise,
+                                                self.extrinsics_noise_scale, None)
         tensors = (self.intrinsics_initial, self.intrinsics_noise, self.extrinsics_initial, self.extrinsics_noise)
         key = tuple((t.data_ptr(), t._version, bool(t.requires_grad)) for t in tensors) + (torch.is_grad_enabled(),)
         memo = self.__dict__.get("_matrices_memo")

@@ -354,6 +354,28 @@ def test_combined_config3_step_gradients_with_decisions_aligned(M):
         assert rep[name]["max"] <= 2e-3 and rep[name]["l2"] <= 1e-3, (name, rep[name])
 
 
+def test_separate_backward_passes_through_K_and_E(M):
+    """In the reference get_intrinsic() and get_extrinsic() build independent graphs: loss_K.backward(); loss_E.backward()
+    works.  Here the pair shares one node by default (the second backward needs retain_graph on the first);
+    `share_matrix_node = False` restores the reference's structure, with the same gradients."""
+    cm, _, _ = make_camera(M, "pinhole_rot_noise_10k_rayo_rayd", True)
+    K, E = cm.get_intrinsic(), cm.get_extrinsic()
+    (K.sum() * 2.0).backward(retain_graph=True)
+    (E ** 2).sum().backward()
+    want = (cm.intrinsics_noise.grad.clone(), cm.extrinsics_noise.grad.clone())
+    cm.intrinsics_noise.grad = cm.extrinsics_noise.grad = None
+    K, E = cm.get_intrinsic(), cm.get_extrinsic()
+    (K.sum() * 2.0).backward()
+    with pytest.raises(RuntimeError):
+        (E ** 2).sum().backward()                       # the shared node's buffers are gone
+    cm.intrinsics_noise.grad = cm.extrinsics_noise.grad = None
+    cm.share_matrix_node = False
+    K, E = cm.get_intrinsic(), cm.get_extrinsic()
+    (K.sum() * 2.0).backward()
+    (E ** 2).sum().backward()
+    assert torch.equal(cm.intrinsics_noise.grad, want[0]) and torch.equal(cm.extrinsics_noise.grad, want[1])
+
+
 def test_key_point_range_check_is_deferred_but_raised(M):
     """Out-of-image key points: the reference asserts at once (a host read of GPU memory per call); here the
     verdict travels to pinned memory asynchronously and the AssertionError comes with the next ray-generation

@@ -59,10 +59,21 @@ def main():
         print("%-34s %8.3f ms  %7.1f TFLOP/s (algorithmic fp32)" % (name, ms, res[name]["tflops_fp32_equiv"]), flush=True)
 
     if a.only_resident_train:
+        # (ablation builds, tools/ablate_h3_run.sh) time + the clock and socket power each kernel sustains over 1.5 s of
+        # back-to-back launches: a variant can be faster in CYCLES or in CLOCK (the socket sits at its power cap)
+        import bench
+        tel = bench.Telemetry(dev)
         d_raw = torch.randn(P, 4, generator=g).to(dev) * 1e-3
-        run("resident train", lambda: ops.mlp_fwd_resident(pts, vd, a.spr, wpk, rw, save_b))
-        run("resident dgrad", lambda: ops.mlp_bwd_resident(d_raw, pts, vd, a.spr, wbk, rw, save_b))
-        print(json.dumps({k: round(v["ms"], 3) for k, v in res.items()}))
+        rec = {}
+        for name, fn in (("resident train", lambda: ops.mlp_fwd_resident(pts, vd, a.spr, wpk, rw, save_b)),
+                         ("resident dgrad", lambda: ops.mlp_bwd_resident(d_raw, pts, vd, a.spr, wbk, rw, save_b))):
+            run(name, fn)
+            rec[name] = round(res[name]["ms"], 3)
+            t = tel.sample_while(fn, 1.5)
+            if t:
+                rec[name + " sustained"] = {"ms": round(t["ms_per_step_during"], 3), "ghz": round(t["clock_ghz"], 3),
+                                            "watt": round(t["socket_power_w"])}
+        print(json.dumps(rec))
         return
     run("fused fp32 train", lambda: ops.mlp_fwd(pts, vd, a.spr, wpk, save_a))
     run("fused fp32 infer", lambda: ops.mlp_fwd(pts, vd, a.spr, wpk, None))
