@@ -12,8 +12,6 @@ constexpr bool kNoPe = false;            // no sines / cosines
 constexpr bool kNoStream = false;        // no weight stream (LDS keeps its first chunks)
 constexpr bool kNoBarrier = false;       // no chunk barrier (racy)
 constexpr bool kLateLoads = false;       // the stream's global loads in slots 24 .. 47 instead of 0 .. 23
-constexpr bool kDmaStream = false;       // the weight stream as LDS-DMA (global_load_lds_dwordx4) instead of load + LDS write (experiment)
-constexpr bool kDrainBeforeBarrier = false;   // s_waitcnt vmcnt(0) in front of every chunk barrier (what an LDS-DMA stream would need without store counting)
 // the fp32-MFMA yardstick kernels (mlp_common.h)
 constexpr bool kPlainStore = false;      // workspace stores with the default cache policy instead of non-temporal
 constexpr bool kBurst = false;           // round 1's burst schedule of a chunk's memory instructions instead of the spread one

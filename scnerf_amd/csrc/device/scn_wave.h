@@ -148,16 +148,6 @@ __device__ __forceinline__ f32x4 load_f32x4(global_bytes base, unsigned lane_off
 __device__ __forceinline__ f32x4 load_stream_f32x4(global_bytes base, unsigned lane_off) {
     return __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(base + lane_off));
 }
-// LDS-DMA: 1 KB of global memory -> LDS without a register round trip (`global_load_lds_dwordx4`): lane i's 16 bytes at
-// base + lane_off land at byte `lds_offset + 16 i` of the workgroup's LDS (wave-uniform; the dynamic region starts at 0).
-// The request is counted by vmcnt like a load; nothing orders a later LDS read behind it but the issuing wave's own
-// `s_waitcnt vmcnt` (+ a barrier for the other waves).  Inline asm on purpose: the compiler does not know this writes LDS,
-// so it does not put a vmcnt wait in front of every LDS read that follows (what it does for the builtin) -- the CALLER waits.
-__device__ __forceinline__ void dma_to_lds_16(global_bytes base, unsigned lane_off, unsigned lds_offset) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane_off), "s"(base), "s"(lds_offset) : "memory", "m0");
-}
-// every vector-memory request of this wave (loads, stores, LDS-DMA) has completed
-__device__ __forceinline__ void drain_vector_memory() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // stores through a wave-uniform base + 32-bit lane offset (`global_store v_off, v[data], s[base]`)
 typedef __attribute__((address_space(1))) char* global_bytes_rw;
 __device__ __forceinline__ global_bytes_rw uniform_global_rw(void* p) {

@@ -97,23 +97,12 @@ struct Stream {
     unsigned cur;          // LDS byte offset of the buffer in use: 0, 32 K, 64 K
     f32x4 stage[8];
     __device__ __forceinline__ unsigned next() const { return cur == 2u * kChunkBytes ? 0u : cur + kChunkBytes; }
-    __device__ __forceinline__ unsigned prev() const { return cur == 0u ? 2u * kChunkBytes : cur - kChunkBytes; }
 };
 
 // first chunk -> buffer 0, second chunk -> staging registers (slots 0 .. 23 of chunk 0 commit it); the caller
 // synchronises the workgroup before the first fragment read
 __device__ __forceinline__ void stream_prime(Stream& ws, const void* stream, char* lds, unsigned tid16) {
     ws.g = uniform_global(stream);
-    if constexpr (lab::kDmaStream) {
-        // LDS-DMA: chunks 0 and 1 straight into buffers 0 and 1 (a wave's share of a 4 KB piece is its own 1 KB)
-        const unsigned wave_lds = (unsigned)uniform((int)(tid16 & ~1023u));
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dma_to_lds_16(ws.g, tid16 + (unsigned)(i * 4096), (unsigned)(i * 4096) + wave_lds);
-        drain_vector_memory();
-        ws.g = uniform_global(ws.g + 2 * kChunkBytes);
-        ws.cur = 0u;
-        return;
-    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) ws.stage[i] = load_f32x4(ws.g + i * 4096, tid16);
 #pragma unroll
@@ -138,29 +127,8 @@ __device__ __forceinline__ void stream_prime(Stream& ws, const void* stream, cha
 // issued 24 slots ahead the waits cost ~0.4 ms of a 3 ms launch: lab::kLateLoads is that schedule).
 template <int KAPPA>
 __device__ __forceinline__ void stream_slot(Stream& ws, char* lds, unsigned tid16) {
-    if constexpr (lab::kDmaStream) {
-        // LDS-DMA schedule: behind this chunk's barrier (slot 30) the buffer of the chunk BEFORE this one is free -- the eight
-        // pieces of the chunk after next go straight into it in slots 31, 33 .. 45; each wave makes sure of its own requests
-        // in front of the NEXT barrier (slot 29 of the next chunk), behind which the data is read from slot 42 on.
-        if constexpr (KAPPA == 29) drain_vector_memory();
-        if constexpr (!lab::kNoBarrier && KAPPA == 30) block_sync();
-        if constexpr (KAPPA >= 31 && KAPPA <= 45 && (KAPPA & 1) == 1) {
-            constexpr int piece = (KAPPA - 31) / 2;
-            // (the destination is formed where it is used, from a value the optimiser takes as new: hoisted, the 24 distinct
-            //  destinations of the three buffers live in SGPRs across the whole layer loop and spill)
-            const unsigned t16 = pinned_here(tid16);
-            const unsigned dst = (unsigned)uniform((int)((t16 & ~1023u) + ws.prev() + (unsigned)(piece * 4096)));
-            dma_to_lds_16(ws.g, t16 + (unsigned)(piece * 4096), dst);
-        }
-        if constexpr (KAPPA == 47) {
-            ws.cur = ws.next();
-            ws.g = uniform_global(ws.g + kChunkBytes);
-        }
-        return;
-    }
     if constexpr (!lab::kNoStream && KAPPA < 24 && KAPPA % 3 == 0)
         *reinterpret_cast<f32x4*>(lds + ws.next() + (KAPPA / 3) * 4096 + tid16) = ws.stage[KAPPA / 3];
-    if constexpr (lab::kDrainBeforeBarrier && KAPPA == 29) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (experiment: what a full drain per chunk costs)
     if constexpr (!lab::kNoBarrier && KAPPA == 30) block_sync();
     constexpr int LOAD_PIECE = lab::kNoStream ? -1
                                : lab::kLateLoads ? ((KAPPA >= 24 && KAPPA % 3 == 0) ? (KAPPA - 24) / 3 : -1)

@@ -134,11 +134,6 @@ inline int fresh_uniform(int v) { return v; }
 inline unsigned long long shader_cycles() { return 0; }
 inline unsigned long long reference_ticks() { return 0; }
 typedef char* global_bytes_rw;
-// LDS-DMA on the interpreter: the bytes land at once (no ordering to model)
-inline void dma_to_lds_16(global_bytes base, unsigned lane_off, unsigned lds_offset) {
-    std::memcpy(simt::block_lds() + lds_offset + 16u * (unsigned)simt::cur_lane(), base + lane_off, 16);
-}
-inline void drain_vector_memory() {}
 inline global_bytes_rw uniform_global_rw(void* p) { return static_cast<char*>(p); }
 inline global_bytes_rw uniform_global_rw(global_bytes_rw p) { return p; }
 template <typename V>

@@ -58,15 +58,5 @@ constexpr bool kNoChain = true;
 #else
 constexpr bool kNoChain = false;
 #endif
-#ifdef SCN_H3_DMA
-constexpr bool kDmaStream = true;
-#else
-constexpr bool kDmaStream = false;
-#endif
-#ifdef SCN_H3_DRAIN
-constexpr bool kDrainBeforeBarrier = true;
-#else
-constexpr bool kDrainBeforeBarrier = false;
-#endif
 }  // namespace lab
 }  // namespace scn
