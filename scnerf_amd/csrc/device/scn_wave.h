@@ -198,6 +198,9 @@ __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p
 __device__ __forceinline__ int popcount64(unsigned long long m) { return __popcll(m); }
 
 __device__ __forceinline__ void block_sync() { __syncthreads(); }
+// The lanes of ONE wave hand data to each other through LDS: a wave's LDS instructions execute in order, so nothing is
+// emitted -- the call pins the order for the compiler (and is the rendezvous of the wave's fibers on the CPU interpreter).
+__device__ __forceinline__ void wave_lds_handoff() { __builtin_amdgcn_wave_barrier(); }
 
 // Compiler-only fence: instructions are not moved across it by the machine scheduler (used to keep
 // prefetches where they were written; no instruction is emitted).

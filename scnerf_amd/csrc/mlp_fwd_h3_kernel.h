@@ -32,6 +32,45 @@ __device__ __forceinline__ void store_pe_rows(const float (&e)[NS], float* __res
         for (int c = PD + 2 * PD * L; c < ld; ++c) row[c] = 0.f;
 }
 
+// The same rows as COALESCED stores.  store_pe_rows writes one float per lane and instruction into 32 different rows -- a
+// cache line per lane: 0.46 of the fine forward's 5.8 Mcycles (tools/ablate_h3.sh nopestore, profiles/r05_ablation_h3.txt).
+// A wave tile's 32 rows of a row-major section are ONE contiguous block of 32 x LD floats, and the slots are (or can be put)
+// in LDS in slot layout -- `slots[g * kThreads + thread]` = slots 4 g .. 4 g + 3 of the thread --, so the block goes out as
+// LD / 8 instructions of 16 bytes per lane: lane l of instruction k owns columns 4 (l % (LD / 4)) .. + 3 of row
+// k * (256 / LD) + l / (LD / 4) and gathers them from the slot layout (column c = slot s_c of lane half h_c: PeInverse).
+template <int PD, int L, int NS, int LD>
+struct PeInverse {
+    unsigned off[LD];          // byte offset of column c's slot relative to its sample's lane-half-0 entry; ~0u: zero pad
+    constexpr PeInverse() : off() {
+        for (int c = 0; c < LD; ++c) off[c] = 0xffffffffu;
+        for (int s = 0; s < NS; ++s)
+            for (int h = 0; h < 2; ++h) {
+                const int c = pe_col(L, s, h, PD);
+                if (c >= 0) off[c] = (unsigned)((s / 4) * (kThreads * 16) + h * 512 + (s % 4) * 4);
+            }
+    }
+};
+template <int PD, int L, int NS, int LD>
+__device__ __forceinline__ void store_pe_tile(const char* slots, float* __restrict__ section, long wave_tile, int wave, int lane) {
+    if (lab::kNoPeStore) return;
+    wave_lds_handoff();                               // the slots are the wave's own lanes' writes
+    static constexpr PeInverse<PD, L, NS, LD> inverse{};
+    constexpr int LPR = LD / 4;                       // lanes per row
+    unsigned o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = inverse.off[4 * (lane % LPR) + i];
+    const global_bytes_rw block = uniform_global_rw(section + wave_tile * (32L * LD));
+#pragma unroll
+    for (int k = 0; k < LD / 8; ++k) {
+        const int m = k * (64 / LPR) + lane / LPR;
+        const char* row = slots + (wave * 64 + m) * 16;
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = o[i] == 0xffffffffu ? 0.f : *reinterpret_cast<const float*>(row + o[i]);
+        store_stream_at(uniform_global_rw(block + k * 1024), pinned_here((unsigned)lane * 16u), v);
+    }
+}
+
 // KIND 0: ReLU + mask bits;  1: the same + the density head's dot product (layer 7);  2: linear (feature layer)
 // members only some kinds use
 struct NoDensity {};
@@ -257,9 +296,11 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
         } else {
             pe_slots<PD, 10, ES>(px, py, pz, pw, h, e);
         }
-        if (save) store_pe_rows<PD, 10, ES>(e, save + (long)kSaveEpts * Ppad, pc, V::kEW, h, live);
 #pragma unroll
         for (int g = 0; g < ES / 4; ++g) park[g * kThreads] = f32x4{e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3]};
+        // (the saved rows from the parked copy: the wave reads back what its own lanes just wrote -- LDS is in order per wave)
+        if (save) store_pe_tile<PD, 10, ES, V::kEW>(w.lds + kStreamLds + kTableFloats * 4, save + (long)kSaveEpts * Ppad, wave_tile,
+                                                    uniform(wave_id()), lane);
         const float s_e = scale_for(m_e);
 #pragma unroll
         for (int u = 0; u < NE; ++u) cut8(e + 8 * u, s_e, eh[u], el[u]);
@@ -416,8 +457,12 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
         float ev[16];
         pe_slots<3, 4, 16>(vx, vy, vz, 0.f, h, ev);
         if (save) {
-            const Lane L = lane_now();
-            store_pe_rows<3, 4, 16>(ev, save + (long)kSaveEviews * Ppad, L.pc, 32, h, L.live);
+            // through the park area (the encoded point's last reader was the skip layer): slot layout, then coalesced rows
+            f32x4* const vpark = reinterpret_cast<f32x4*>(w.lds + kStreamLds + kTableFloats * 4) + pinned_here(threadIdx.x);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) vpark[g * kThreads] = f32x4{ev[4 * g], ev[4 * g + 1], ev[4 * g + 2], ev[4 * g + 3]};
+            store_pe_tile<3, 4, 16, 32>(w.lds + kStreamLds + kTableFloats * 4, save + (long)kSaveEviews * Ppad, wave_tile,
+                                        uniform(wave_id()), (int)pinned_here((unsigned)lane_id()));
         }
         cut8(ev, epif.s_next, vh[0], vl[0]);
         cut8(ev + 8, epif.s_next, vh[1], vl[1]);

@@ -196,6 +196,7 @@ inline unsigned long long ballot(bool p) {
 inline int popcount64(unsigned long long m) { return __builtin_popcountll(m); }
 
 inline void block_sync() { simt::block_barrier(); }
+inline void wave_lds_handoff() { (void)simt::wave_exchange(0); }       // every fiber of the wave has made its LDS writes
 inline void sched_fence() {}
 inline int uniform(int v) { return v; }
 template <typename T> inline const T* uniform_ptr(const T* p) { return p; }
