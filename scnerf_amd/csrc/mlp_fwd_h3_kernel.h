@@ -17,23 +17,10 @@ using namespace scn::mlp;
 using namespace scn::h3;
 
 
-// encodings are saved in torch column order so the wgrad GEMM writes weight columns directly (as mlp_fwd.hip)
-template <int PD, int L, int NS>
-__device__ __forceinline__ void store_pe_rows(const float (&e)[NS], float* __restrict__ base, long p, int ld, int h, bool live) {
-    if (lab::kNoPeStore || !live) return;
-    float* row = base + p * ld;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int c0 = pe_col(L, s, 0, PD), c1 = pe_col(L, s, 1, PD);
-        const int c = h ? c1 : c0;
-        if (c >= 0) row[c] = e[s];
-    }
-    if (h == 1)
-        for (int c = PD + 2 * PD * L; c < ld; ++c) row[c] = 0.f;
-}
-
-// The same rows as COALESCED stores.  store_pe_rows writes one float per lane and instruction into 32 different rows -- a
-// cache line per lane: 0.46 of the fine forward's 5.8 Mcycles (tools/ablate_h3.sh nopestore, profiles/r05_ablation_h3.txt).
+// Encodings are saved in torch column order so the wgrad GEMM writes weight columns directly (as mlp_fwd.hip), row-major
+// [P][LD] -- as COALESCED stores.  One float per lane and instruction into 32 different rows (what mlp_fwd.hip's
+// store_pe does) was a cache line per lane: 0.46 of the fine forward's 5.8 Mcycles (tools/ablate_h3.sh nopestore,
+// profiles/r05_ablation_h3.txt).
 // A wave tile's 32 rows of a row-major section are ONE contiguous block of 32 x LD floats, and the slots are (or can be put)
 // in LDS in slot layout -- `slots[g * kThreads + thread]` = slots 4 g .. 4 g + 3 of the thread --, so the block goes out as
 // LD / 8 instructions of 16 bytes per lane: lane l of instruction k owns columns 4 (l % (LD / 4)) .. + 3 of row
