@@ -279,12 +279,22 @@ __global__ __launch_bounds__(256) void camera_rays_bwd_kernel(CamArgs a, const f
         if (a.grid_o && d_grid_o) scatter_grid(d_grid_o, a.gw, f.taps, a.scale_o * go);
         // R, t
         const int slot = a.extrinsic ? (a.n_ext == 1 ? 0 : i) : f.cam;
-        float* ar = lds_slots > 0 ? lacc + slot * 12 : acc + 4 + (size_t)slot * 12;
         const Vec3 dd = f.dirs;
-        atomic_add(ar + 0, gr.x * dd.x); atomic_add(ar + 1, gr.y * dd.x); atomic_add(ar + 2, gr.z * dd.x);   // d col x
-        atomic_add(ar + 3, gr.x * dd.y); atomic_add(ar + 4, gr.y * dd.y); atomic_add(ar + 5, gr.z * dd.y);   // d col y
-        atomic_add(ar + 6, gr.x * dd.z); atomic_add(ar + 7, gr.y * dd.z); atomic_add(ar + 8, gr.z * dd.z);   // d col z
-        atomic_add(ar + 9, go.x); atomic_add(ar + 10, go.y); atomic_add(ar + 11, go.z);
+        const float term[12] = {gr.x * dd.x, gr.y * dd.x, gr.z * dd.x,        // d col x
+                                gr.x * dd.y, gr.y * dd.y, gr.z * dd.y,        // d col y
+                                gr.x * dd.z, gr.y * dd.z, gr.z * dd.z,        // d col z
+                                go.x, go.y, go.z};
+        // Two branches, not one pointer chosen between LDS and global memory: through a pointer of unknown address space the adds
+        // become FLAT atomics aimed at LDS (flat_atomic_add_f32, the only ones in the library); this way they are ds_add_f32.
+        if (lds_slots > 0) {
+            float* ar = lacc + slot * 12;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) atomic_add(ar + k, term[k]);
+        } else {
+            float* ar = acc + 4 + (size_t)slot * 12;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) atomic_add(ar + k, term[k]);
+        }
         // dirs -> intrinsics
         const float gdx = dot(gr, f.R.x), gdy = dot(gr, f.R.y);
         if (!a.select) {

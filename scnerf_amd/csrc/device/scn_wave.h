@@ -202,6 +202,15 @@ __device__ __forceinline__ void block_sync() { __syncthreads(); }
 // emitted -- the call pins the order for the compiler (and is the rendezvous of the wave's fibers on the CPU interpreter).
 __device__ __forceinline__ void wave_lds_handoff() { __builtin_amdgcn_wave_barrier(); }
 
+// The kernel claims the SIMD's whole register file (256 architectural + 256 accumulation registers): no instruction is emitted, the
+// clobbers make v255 and a255 part of the kernel's allocation.  For the kernels built around ONE wave per SIMD on the fp16 matrix
+// pipe (csrc/mlp_h3.h, wgrad256_half.h, wgrad_half_narrow.h): with 425 .. 444 registers they left room for a 64-register wave of
+// ANOTHER kernel on their SIMD -- never this library's own (one stream), but a second process's or another stream's -- and such a
+// guest lost writes to lanes 48..63 of a register while the host wave ran its MFMA chain (tools/flaky_probe5.py, flaky_probe6.py,
+// profiles/r05_two_process_probe.txt: the camera backward kernel beside the data-gradient kernel, 7 % of its launches).  A full
+// allocation admits no guest; for a kernel that runs one wave per SIMD anyway it costs nothing.
+__device__ __forceinline__ void claim_whole_register_file() { asm volatile("" ::: "v255", "a255"); }
+
 // Compiler-only fence: instructions are not moved across it by the machine scheduler (used to keep
 // prefetches where they were written; no instruction is emitted).
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }

@@ -128,6 +128,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_h3_kernel(
     ChunkMaxima cm) {
     using V = Var<PD>;
     constexpr int ES = V::kES, ET = V::kET;        // encoded-point slots; 32-column tiles of the d-encoding parts
+    claim_whole_register_file();
     const int lane = lane_id();
     const int m = lane & 31, h = lane >> 5;
     const long wave_tile = (long)blockIdx.x * 4 + uniform(wave_id());      // (a scalar: what derives from it -- section bases, chunk index -- is SALU work)

@@ -170,6 +170,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_h3_kernel(
     using V = Var<PD>;
     constexpr int ES = V::kES, NE = ES / 8;
     constexpr bool COARSE = STAGE == kCoarse, FINE = STAGE == kFine;
+    claim_whole_register_file();
     float* const save = TRAIN ? save_arg : nullptr;
     const long Ppad_kernel = padded_samples(P);
 

@@ -102,6 +102,7 @@ __device__ __forceinline__ void for_each_slot(F&& f, std::integer_sequence<int, 
 
 template <int FLAGS>
 __global__ __launch_bounds__(kThreads, 1) void wgrad256_half_kernel(Args a) {
+    claim_whole_register_file();               // 444 registers left room for a 64-register guest wave (scn_wave.h)
     short* lds = dynamic_lds<short>();
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const int wn = wave >> 1, wk = wave & 1;

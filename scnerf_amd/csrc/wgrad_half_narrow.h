@@ -90,6 +90,7 @@ __device__ __forceinline__ int region_pos(int fg) {
 
 template <int WA, int WB, bool B_ROWMAJOR, int WB2 = 0>
 __global__ __launch_bounds__(kThreads, (WA == 256 && WB == 64 && WB2 == 0) ? 2 : 1) void wgrad_half_narrow_kernel(Args a) {
+    if constexpr (!(WA == 256 && WB == 64 && WB2 == 0)) claim_whole_register_file();     // the one-wave-per-SIMD shapes admit no guest (scn_wave.h)
     if (blockIdx.y == 1) { a.A = a.A_y1; a.part_w = a.part_w_y1; a.part_b = a.part_b_y1; a.a = a.a_y1; }
     constexpr int TA = WA / 64, TB = WB / 64;             // accumulator tiles per wave
     constexpr int PA = WA / 64, PB = WB / 64;             // 16-byte pieces per thread and slab

@@ -198,6 +198,7 @@ inline int popcount64(unsigned long long m) { return __builtin_popcountll(m); }
 inline void block_sync() { simt::block_barrier(); }
 inline void wave_lds_handoff() { (void)simt::wave_exchange(0); }       // every fiber of the wave has made its LDS writes
 inline void sched_fence() {}
+inline void claim_whole_register_file() {}
 inline int uniform(int v) { return v; }
 template <typename T> inline const T* uniform_ptr(const T* p) { return p; }
 inline float max_raw(float a, float b) { return a > b ? a : b; }
