@@ -56,3 +56,31 @@ def test_hot_kernels_have_no_scratch(tmp_path):
         assert any(want in k for k in seen), (want, sorted(seen))
     dirty = {k: v for k, v in seen.items() if v}
     assert not dirty, dirty
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(LLVM, "llvm-readelf")), reason="needs the ROCm LLVM tools")
+def test_one_wave_per_simd_kernels_admit_no_guest(tmp_path):
+    """The kernels built around ONE wave per SIMD on the fp16 matrix pipe declare the whole register file (512 = 256 architectural +
+    256 accumulation registers): with 425 .. 444 they left room on their SIMD for a wave of another process's or stream's kernel, and
+    such a guest lost register writes (profiles/r05_two_process_probe.txt; csrc/device/scn_wave.h claim_whole_register_file)."""
+    full = ("mlp_fwd_h3_kernel", "mlp_bwd_h3_kernel", "wgrad256_half_kernel")
+    found = {}
+    for obj in _code_objects(tmp_path):
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", obj], check=True, capture_output=True, text=True).stdout
+        for blk in notes.split("- .agpr_count:")[1:]:
+            nm = re.search(r"\.name:\s+(\S+)", blk)
+            vg = re.search(r"\.vgpr_count:\s+(\d+)", blk)
+            if not (nm and vg):
+                continue
+            name, regs = nm.group(1), int(vg.group(1))
+            if any(k in name for k in full):
+                found[name] = regs
+            elif "wgrad_half_narrow_kernel" in name:
+                # the 256 x 64 pair runs two waves per SIMD (2 x 256 registers after allocation granularity: no room either);
+                # the other shapes run one
+                found[name] = regs
+                assert regs == 512 or regs > 248, (name, regs)
+                continue
+    assert len([k for k in found if "h3_kernel" in k]) >= 8 and any("wgrad256_half" in k for k in found), sorted(found)
+    short = {k: v for k, v in found.items() if any(f in k for f in full) and v != 512}
+    assert not short, short
