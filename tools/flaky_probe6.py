@@ -136,7 +136,25 @@ def run(seconds, rounds, lib=None, only=None):
             print("%-28s %-34s %12d   %d" % (name, lib or "product", calls[i], counts[i]), flush=True)
 
 
+def run_external(seconds, label):
+    """the victim alone, counted for `seconds` once it is ready; the neighbour is whatever else the shell started on the GPU"""
+    ctx = mp.get_context("spawn")
+    mode, stop = ctx.Value("i", -3), ctx.Value("i", 0)
+    counts, calls = ctx.Array("i", len(MODES)), ctx.Array("i", len(MODES))
+    p = ctx.Process(target=victim, args=(mode, stop, counts, calls))
+    p.start()
+    while mode.value != -2: time.sleep(0.05)
+    mode.value = 0
+    time.sleep(seconds)
+    stop.value = 1
+    p.join()
+    print("%-28s %-34s %12d   %d" % ("external", label, calls[0], counts[0]), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--external":       # python tools/flaky_probe6.py --external SECONDS LABEL
+        run_external(float(sys.argv[2]), sys.argv[3] if len(sys.argv) > 3 else "?")
+        sys.exit(0)
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     print("neighbour mode               neighbour's library                victim calls   calls whose per-ray dump moved")
