@@ -248,6 +248,128 @@ def cpu_baseline(n_rays=4096, port_rays=512):
     return cpu_baseline_reference(n_rays) or cpu_baseline_port(port_rays)
 
 
+METRIC = "rays/sec (64+128 samples/ray) train-step"
+
+
+def metric_for(cfg):
+    """the metric label of `--config k` (the headline's label is BASELINE.json's; the other configurations say what they time)"""
+    return {1: METRIC, 2: METRIC + " (configs[2]: rays from the learnable camera model)",
+            3: METRIC + " (configs[3]: learnable camera + projected-ray-distance term)",
+            4: "rays/sec NeRF++ train-step (configs[4]: two cascade levels x fg + bg network)"}[cfg]
+
+
+class Guard:
+    """First contact with RCCL at N > 1 must not hang the driver: every stage of the run that can block on another rank
+    (rendezvous, communicator start-up, the first collective, the step loops) runs under a deadline.  A deadline that
+    passes, an exception, or the launcher's SIGTERM (another rank died) makes rank 0 print ONE JSON line with an `error`
+    field -- the contract's keys, `value` null -- and the process exits non-zero; other ranks say the same on stderr."""
+
+    def __init__(self, json_out, rank, world, args):
+        self.json_out, self.rank, self.world, self.args = json_out, rank, world, args
+        self.stage, self.done = "start", False
+        import threading
+        self._lock = threading.Lock()
+
+    def error_line(self, stage, err):
+        a = self.args
+        return json.dumps({"metric": metric_for(getattr(a, "config", 1)), "value": None, "unit": "rays/s", "n_gpus": self.world,
+                           "steps": a.steps, "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True,
+                           "scaling": "weak", "vs_baseline": None, "data": "synthetic", "error": str(err)[:1500],
+                           "stage": stage, "rank": self.rank, "backend": a.backend})
+
+    def fail(self, stage, err, code=3):
+        with self._lock:
+            if not self.done:
+                self.done = True
+                text = self.error_line(stage, err)
+                sys.stderr.write("[bench rank %d] FAILED in stage '%s': %s\n" % (self.rank, stage, err))
+                sys.stderr.flush()
+                if self.rank == 0:
+                    self.json_out.write(text + "\n")
+                    self.json_out.flush()
+        os._exit(code)            # (not sys.exit: a thread blocked inside a collective never returns to unwind)
+
+    def deadline(self, stage, seconds):
+        guard = self
+
+        class _D:
+            def __enter__(self_):
+                import threading
+                guard.stage = stage
+                self_.t = threading.Timer(seconds, lambda: guard.fail(stage, "no progress within %.0f s (deadline of this stage; "
+                                                                      "SCNERF_BENCH_TIMEOUT_SCALE stretches all of them)" % seconds))
+                self_.t.daemon = True
+                self_.t.start()
+
+            def __exit__(self_, et, ev, tb):
+                self_.t.cancel()
+                return False
+        return _D()
+
+    def install_sigterm(self):
+        """SIGTERM (torch.distributed.run sends it to the surviving ranks when one dies) is answered by a thread of its own:
+        a Python-level handler only runs once the main thread returns from the C call it is blocked in -- which, inside a
+        collective whose peer is gone, is never.  The interpreter's C-level handler writes the signal number to the wake-up
+        descriptor at once, in whichever thread the kernel picked; the watcher thread reads it there."""
+        import signal
+        import socket
+        import threading
+        try:
+            r, w = socket.socketpair()
+            w.setblocking(False)
+            signal.signal(signal.SIGTERM, lambda signum, frame: None)
+            signal.set_wakeup_fd(w.fileno(), warn_on_full_buffer=False)
+        except (ValueError, OSError):
+            return
+        self._wake = (r, w)
+
+        def waiter():
+            while True:
+                b = r.recv(1)
+                if b and b[0] == signal.SIGTERM:
+                    self.fail(self.stage, "SIGTERM from the launcher while in this stage (another rank failed or the job was cancelled)", code=4)
+        threading.Thread(target=waiter, daemon=True).start()
+
+
+def init_distributed(a, guard, rank, local_rank, world):
+    """-> (dist module, device).  Rendezvous on 127.0.0.1 + communicator + one small collective that also proves the ranks
+    sit on `world` DISTINCT devices; every part under a deadline (`--init-timeout`, default 180 s: a fresh box's first
+    `import torch` alone can take two minutes, and that happens before this)."""
+    import datetime
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("NCCL_DEBUG", "WARN")          # RCCL's warnings reach stderr (stdout is redirected there)
+    dev = None
+    sys.stderr.write("[bench rank %d] entering init_process_group(%s), world_size %d, deadline %.0f s\n" % (rank, a.backend, world, a.init_timeout))
+    sys.stderr.flush()
+    with guard.deadline("init_process_group(%s), world_size %d" % (a.backend, world), a.init_timeout):
+        if a.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dev = torch.device("cuda", local_rank)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=a.init_timeout))
+        else:
+            dist.init_process_group(a.backend, timeout=datetime.timedelta(seconds=a.init_timeout))
+            torch.cuda.set_device(local_rank)
+            dev = torch.device("cuda", local_rank)
+    if dist.get_world_size() != world or (a.gpus > 1 and dist.get_world_size() != a.gpus):
+        guard.fail("world size", "process group has %d ranks, --gpus %d, WORLD_SIZE %d" % (dist.get_world_size(), a.gpus, world))
+    with guard.deadline("first collective (all_gather of device identities + barrier)", a.init_timeout):
+        small = dev if a.backend == "nccl" else torch.device("cpu")
+        pr = torch.cuda.get_device_properties(dev)
+        mine = torch.tensor([torch.cuda.current_device(), getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0),
+                             getattr(pr, "pci_device_id", 0)], dtype=torch.int64, device=small)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        dist.barrier()
+        torch.cuda.synchronize()
+    ids = [tuple(int(v) for v in e.tolist()) for e in every]
+    info = {"world_size": dist.get_world_size(), "devices": [i[0] for i in ids], "pci": ["%04x:%02x:%02x" % i[1:] for i in ids],
+            "distinct_devices": len(set(ids)) == world}
+    if not info["distinct_devices"] and not a.one_device:
+        guard.fail("device placement", "ranks share a device: %s (LOCAL_RANK not honoured?)" % (info,))
+    return dist, dev, info
+
+
 IMG_H, IMG_W, N_CAMS = 378, 504, 17      # LLFF 'fern' at factor 8: the image size / view count of configs[1..3]
 
 
@@ -495,15 +617,21 @@ def self_launch(n, json_out):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               NCCL_DEBUG=os.environ.get("NCCL_DEBUG", "WARN"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if lines:
         json_out.write(lines[-1] + "\n")
-        json_out.flush()
-    return r.returncode if r.returncode else (0 if lines else 1)
+    else:                                            # (rank 0 died without a word: the launcher's status is all there is)
+        json_out.write(json.dumps({"metric": METRIC, "value": None, "unit": "rays/s", "n_gpus": n, "error":
+                                   "no JSON line from rank 0; torch.distributed.run exited with status %d" % r.returncode,
+                                   "stage": "launch"}) + "\n")
+    json_out.flush()
+    bad = (not lines) or ("\"error\"" in lines[-1])
+    return r.returncode if r.returncode else (1 if bad else 0)
 
 
 class Telemetry:
@@ -530,6 +658,39 @@ class Telemetry:
                 return float(fh.read().strip())
         except Exception:
             return None
+
+    def start(self, period=0.010):
+        """samples in a thread until stop(): used AROUND THE TIMED STEPS themselves (two small sysfs reads every 10 ms in
+        another thread; the launches are asynchronous and queued far ahead, the GPU never waits for the host here)"""
+        import threading
+        self._stop, self._power, self._clock = threading.Event(), [], []
+        if self.dir is None:
+            return
+
+        def sampler():
+            while not self._stop.is_set():
+                pw, ck = self._read("power1_input"), self._read("freq1_input")
+                if pw is not None:
+                    self._power.append(pw * 1e-6)
+                if ck is not None:
+                    self._clock.append(ck * 1e-9)
+                time.sleep(period)
+        self._th = threading.Thread(target=sampler, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        if self.dir is None:
+            return None
+        self._stop.set()
+        self._th.join()
+        power, clock = sorted(self._power), sorted(self._clock)
+        if len(power) < 4 or len(clock) < 4:
+            return None
+        cap = self._read("power1_cap")
+        return {"socket_power_w": power[len(power) // 2], "clock_ghz": clock[len(clock) // 2],
+                "power_cap_w": cap * 1e-6 if cap else None, "samples": len(power),
+                "source": "amdgpu hwmon power1_input / freq1_input (sclk), median of %d samples taken every 10 ms DURING the "
+                          "timed steps" % len(power)}
 
     def sample_while(self, fn, seconds):
         """runs fn() repeatedly for `seconds`, sampling beside it -> dict or None"""
@@ -610,6 +771,10 @@ def compact_record(full, detail_path):
             line[k] = [r4(x) for x in full[k]] if isinstance(full[k], list) else r4(full[k])
     if full.get("all_reduce_alone"):
         line["all_reduce_alone"] = rounded(pick(full["all_reduce_alone"], ("ms_per_all_reduce", "floats", "world_size", "backend", "error")))
+    if full.get("ranks"):
+        line["ranks"] = pick(full["ranks"], ("world_size", "devices", "distinct_devices"))
+    if "infer_rays_per_s" in full:
+        line["infer_rays_per_s"] = r4(full["infer_rays_per_s"])
     line["detail"] = detail_path
     text = json.dumps(line)
     if len(text) >= COMPACT_LIMIT:                  # (cannot happen with the fields above; never emit an unparseable tail)
@@ -667,27 +832,43 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0 (functional check, with --backend gloo)")
     ap.add_argument("--telemetry-seconds", type=float, default=1.5,
                     help="N = 1: socket power and shader clock sampled over this many seconds of steps after the timed region (0: off)")
+    ap.add_argument("--init-timeout", type=float, default=float(os.environ.get("SCNERF_BENCH_INIT_TIMEOUT", "180")),
+                    help="N > 1: seconds the rendezvous + communicator start-up, and then the first collective, may take before "
+                         "rank 0 prints an error line and every rank exits non-zero")
     a = ap.parse_args()
+    scale = float(os.environ.get("SCNERF_BENCH_TIMEOUT_SCALE", "1"))
+    a.init_timeout *= scale
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started without a launcher: one process per GPU through torch.distributed.run (what the driver's own command
         # line does), rendezvous on 127.0.0.1; rank 0's JSON line is the only thing on the children's stdout
         raise SystemExit(self_launch(a.gpus, json_out))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = 0 if a.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    guard = Guard(json_out, rank, world, a)
+    guard.install_sigterm()
+    try:
+        run(a, json_out, guard, rank, world, scale)
+    except SystemExit:
+        raise
+    except BaseException as e:                       # (every failure leaves a parseable line and a non-zero status)
+        import traceback
+        traceback.print_exc()
+        guard.fail(guard.stage, "%s: %s" % (type(e).__name__, e), code=1)
+
+
+def run(a, json_out, guard, rank, world, scale):
+    local_rank = 0 if a.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit("--gpus %d under a launcher that started %d ranks" % (a.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
+        guard.fail("launch", "--gpus %d under a launcher that started %d ranks" % (a.gpus, world), code=2)
+    dist, ranks_info = None, None
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(a.backend)
+        dist, dev, ranks_info = init_distributed(a, guard, rank, local_rank, world)
+    else:
+        guard.stage = "device"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    guard.stage = "build the workload"
 
     from scnerf_amd import ops
     from scnerf_amd.parallel import FlatGradAllReduce
@@ -725,16 +906,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    sync()
-    ops.PROFILE.reset(enabled=True)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
-    ops.PROFILE.enabled = False
+    # (deadlines: 60 s + 2 s per step is two orders of magnitude above a healthy run; a rank stuck in the collective ends here)
+    with guard.deadline("warm-up steps (the first all-reduce of the flat gradient buffer is in here)", (60 + 2 * a.warmup) * scale):
+        for _ in range(a.warmup):
+            step()
+        sync()
+    live = Telemetry(dev) if (rank == 0 and a.telemetry_seconds > 0) else None
+    with guard.deadline("timed steps", (60 + 2 * a.steps) * scale):
+        ops.PROFILE.reset(enabled=True)
+        if live:
+            live.start()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        sync()
+        dt = time.perf_counter() - t0
+        in_loop = live.stop() if live else None
+        ops.PROFILE.enabled = False
     per_rank_ms, allreduce_info = None, None
     if world > 1:
         small = dev if a.backend == "nccl" else torch.device("cpu")      # (gloo gathers host tensors)
@@ -745,8 +933,10 @@ def main():
         tt = torch.tensor([dt], device=small, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        allreduce_info = rccl_allreduce_probe(dev, int(reducer.flat.numel()))       # the step's collective on its own
+        with guard.deadline("the collective on its own", 120 * scale):
+            allreduce_info = rccl_allreduce_probe(dev, int(reducer.flat.numel()))       # the step's collective on its own
     ms = dt / a.steps * 1e3
+    guard.stage = "after the timed region"
 
     # the same K steps without the event pairs (outside the reported figure)
     sync()
@@ -755,7 +945,11 @@ def main():
         step()
     sync()
     ms_off = (time.perf_counter() - t0) / a.steps * 1e3
-    telemetry = Telemetry(dev).sample_while(step, a.telemetry_seconds) if (rank == 0 and world == 1 and a.telemetry_seconds > 0) else None
+    # clock / power: the samples taken during the timed steps when there are enough of them (>= 4: ~40 ms of steps), else
+    # a loop of its own after the timed region (labelled as such)
+    telemetry = in_loop
+    if telemetry is None and rank == 0 and world == 1 and a.telemetry_seconds > 0:
+        telemetry = Telemetry(dev).sample_while(step, a.telemetry_seconds)
 
     if rank == 0:
         kern = ops.PROFILE.summary()
@@ -814,6 +1008,8 @@ def main():
                 roof["clock_ghz"] = telemetry["clock_ghz"]
                 roof["socket_power_w"] = telemetry["socket_power_w"]
                 roof["power_cap_w"] = telemetry["power_cap_w"]
+                # (an ESTIMATE beside `frac`, never instead of it: frac_mfma rescaled from 2.4 GHz to the median shader clock
+                #  sampled over the same timed steps -- or, on runs too short for four samples, over a loop after them)
                 roof["frac_at_measured_clock"] = roof["frac_mfma"] * 2.4 / telemetry["clock_ghz"] if not hbm else None
                 roof["telemetry"] = telemetry
         workload = {
@@ -829,7 +1025,7 @@ def main():
         collective = ("no collective at N = 1" if world == 1 else
                       "1 %s all-reduce/step of %d floats" % ("RCCL" if a.backend == "nccl" else a.backend, int(reducer.flat.numel())))
         out = {
-            "metric": "rays/sec (64+128 samples/ray) train-step", "value": n * world / (ms * 1e-3),
+            "metric": metric_for(cfg), "value": n * world / (ms * 1e-3),
             "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
             "ms_per_step_events_off": ms_off,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -869,11 +1065,20 @@ def main():
         if per_rank_ms is not None:
             out["per_rank_ms_per_step"] = per_rank_ms
             out["all_reduce_alone"] = allreduce_info
+            out["ranks"] = ranks_info
         if world == 1 and not a.no_extras and cfg == 1:
+            guard.stage = "extras (other configurations, inference, PSNR)"
             out["extras"] = extras_single_gpu(w, dev, sync)
+            # SURVEY section 8(d)'s secondary metric: forward-only rays/s of full-image inference (render_path, 378 x 504,
+            # 64 + 128 samples, incl. ray generation and the D2H copy of the finished images)
+            inf = out["extras"].get("full_image_inference") or {}
+            if inf.get("value"):
+                out["infer_rays_per_s"] = inf["value"]
             if a.backend == "nccl":
                 out["extras"]["rccl_allreduce_single_rank"] = rccl_allreduce_probe(dev, 1202945)
-        if world == 1 and not a.no_cpu:
+        # the CPU leg IS configs[1]'s render_rays: only the headline configuration is compared with it
+        if world == 1 and not a.no_cpu and cfg == 1:
+            guard.stage = "cpu_baseline"
             out["cpu_baseline"] = cpu_baseline(a.cpu_rays)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         # the full record goes to a file; stdout carries the compact line only (a 26 KB line once outgrew the driver's tail)
@@ -884,10 +1089,14 @@ def main():
                 json.dump(out, fh, indent=1)
         except OSError as e:
             detail = "not written: %r" % (e,)
-        json_out.write(compact_record(out, detail) + "\n")
-        json_out.flush()
+        with guard._lock:
+            guard.done = True                       # (from here on a SIGTERM must not add a second line)
+            json_out.write(compact_record(out, detail) + "\n")
+            json_out.flush()
     if world > 1:
-        dist.destroy_process_group()
+        with guard.deadline("destroy_process_group", 60 * scale):
+            dist.barrier()
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -148,3 +148,83 @@ def test_gpu_bench_single_line(tmp_path):
         assert k in line, k
     assert line["n_gpus"] == 1 and line["cpu_baseline"] is None
     assert line["roofline"]["bound"] in ("mfma", "hbm") and 0 < line["roofline"]["frac"] < 1
+
+
+# ---- first contact at N > 1 must fail LOUDLY, never hang (no GPU needed: the failures happen before any kernel) ----------
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _rank_env(rank, world, port):
+    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port))
+    return env
+
+
+def _error_line(stdout):
+    lines = [ln for ln in stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "error", "stage"):
+        assert k in line, k
+    assert line["value"] is None and line["error"]
+    return line
+
+
+def test_missing_peer_ends_in_an_error_line_not_a_hang():
+    """rank 0 of a two-rank job whose peer never shows up: the rendezvous deadline passes, ONE JSON line with `error` and the
+    stage's name comes out on stdout, the status is non-zero -- in seconds, not at the driver's own timeout"""
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--init-timeout", "4",
+                        "--steps", "1", "--warmup", "0", "--no-cpu"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=300, env=_rank_env(0, 2, _free_port()), cwd=ROOT)
+    assert r.returncode != 0
+    line = _error_line(r.stdout)
+    assert line["n_gpus"] == 2 and "init_process_group" in line["stage"] and line["rank"] == 0
+    assert time.time() - t0 < 240
+    assert "FAILED in stage" in r.stderr
+
+
+def test_sigterm_from_the_launcher_ends_in_an_error_line():
+    """what torch.distributed.run does to the surviving ranks when one dies: SIGTERM while rank 0 is blocked inside the
+    rendezvous (a C call) -- the sigwait thread answers with the error line and status 4"""
+    import signal
+    import time
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--init-timeout",
+                          "600", "--no-cpu"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         env=_rank_env(0, 2, _free_port()), cwd=ROOT)
+    # wait until the process says it is in the rendezvous (stderr is line-buffered through sys.stderr.write + flush)
+    t0 = time.time()
+    while time.time() - t0 < 240:
+        ln = p.stderr.readline()
+        if "entering" in ln or p.poll() is not None:
+            break
+    time.sleep(1.0)
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=60)
+    assert p.returncode == 4, (p.returncode, err[-2000:])
+    line = _error_line(out)
+    assert "SIGTERM" in line["error"] and "init_process_group" in line["stage"]
+
+
+def test_two_ranks_without_a_gpu_fail_through_the_self_launcher():
+    """`python bench.py --gpus 2` on a machine without a GPU: both ranks meet over gloo, the device step raises, rank 0's
+    error line is handed through by the self-launcher, status non-zero"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine WITHOUT a GPU (the failure is the missing device)")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device",
+                        "--steps", "1", "--warmup", "0", "--no-cpu", "--init-timeout", "120"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    line = _error_line(r.stdout)
+    assert line["n_gpus"] == 2
