@@ -417,6 +417,7 @@ def build_world(dev, rank, n):
         net.flat_parameters()
         return net
     cam, _ = synth.camera_model(IMG_H, IMG_W, n_cams=N_CAMS, seed=4)
+    cam.share_matrix_node = True                      # (one backward per step: K and E of a parameter version share a node)
     g = torch.Generator().manual_seed(100 + rank)
     kps = torch.stack([torch.randint(0, IMG_W, (n,), generator=g), torch.randint(0, IMG_H, (n,), generator=g)], -1)
     idx = torch.randint(0, N_CAMS, (n,), generator=g)

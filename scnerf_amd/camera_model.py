@@ -117,10 +117,12 @@ class CameraModel(nn.Module):
 
 
 class _PinholeRotNoise(CameraModel):
-    # get_intrinsic() and get_extrinsic() of one parameter version share ONE autograd node (one launch each way for the
-    # pair).  A script that backpropagates a loss through K and, separately, another through E of the same getter pair
-    # either passes retain_graph=True to the first backward or sets this to False (per instance or on the class).
-    share_matrix_node = True
+    # False (the default) = the reference's structure: every getter call builds a graph of its own, so a script may
+    # backpropagate one loss through K and, separately, another through E.  True: get_intrinsic() and get_extrinsic() of one
+    # parameter version share ONE autograd node (one launch each way for the pair instead of one per call) -- for loops that
+    # run ONE backward per step, as run_nerf.py's train() does: scnerf_amd.dropin.install() and bench.py opt in
+    # (per instance or on the class).
+    share_matrix_node = False
 
     def focal_xy(self):
         """[fx, fy] of get_intrinsic() without building the 4x4 matrix (what the NDC warp needs per step)."""

@@ -25,21 +25,26 @@ class _QueryFunction(torch.autograd.Function):
     """raw = network(pts, viewdirs) as one differentiable node (fused PE + MLP)."""
 
     @staticmethod
-    def forward(ctx, pts, viewdirs, net, *params):
+    def forward(ctx, pts, viewdirs, net, track, *params):
         shape = pts.shape
         spr = int(shape[-2]) if pts.dim() >= 3 else 1
         p = pts.reshape(-1, 3).contiguous().float()
         v = viewdirs.reshape(-1, 3).contiguous().float()
         if p.shape[0] != v.shape[0] * spr:
             raise ValueError("pts [..., S, 3] and viewdirs [..., 3] disagree: %s vs %s" % (tuple(shape), tuple(viewdirs.shape)))
-        train = any(ctx.needs_input_grad)
+        # (`track`: torch.is_grad_enabled() at the call; needs_input_grad alone stays True under torch.no_grad())
+        train = track and any(ctx.needs_input_grad)
         flat = net.flat_parameters()
         save = ops.save_workspace(p.shape[0], p.device) if train else None
         # the arithmetic in force (ops.mlp_arithmetic), as in render_rays: the resident kernels' streams + the chunk maxima
         # their weight-gradient GEMMs scale by, or the fused fp32-MFMA kernels
-        planes = ops.pack_for_arithmetic(flat, train) if p.shape[0] > 0 else None
+        if train or p.shape[0] == 0:
+            wf = ops.pack_weights(flat, "fwd")
+            planes = ops.pack_for_arithmetic(flat, train) if p.shape[0] > 0 else None
+        else:
+            wf, planes = ops.inference_packs(net, flat)       # (forward-only: packed once per weight version)
         maxima = ops.ChunkMaxima(p.shape[0], p.device) if (train and isinstance(planes, ops.ResidentWeights)) else None
-        raw = ops.mlp_fwd(p, v, spr, ops.pack_weights(flat, "fwd"), save, planes=planes, maxima=maxima)
+        raw = ops.mlp_fwd(p, v, spr, wf, save, planes=planes, maxima=maxima)
         ctx.state = (p, v, spr, save, ops.pack_weights(flat, "bwd") if train else None, shape, viewdirs.shape, planes, maxima)
         return raw.view(*shape[:-1], 4)
 
@@ -53,7 +58,7 @@ class _QueryFunction(torch.autograd.Function):
         gs = [flat_grad[ML.PARAM_OFFSETS[n]: ML.PARAM_OFFSETS[n] + int(torch.Size(s).numel())].view(s)
               for n, s in ML.PARAM_SHAPES]
         ctx.state = None
-        return (d_pts.view(shape), d_v, None, *gs)
+        return (d_pts.view(shape), d_v, None, None, *gs)
 
 
 def _fused_applies(net, embed_fn, embeddirs_fn, viewdirs_given=True) -> bool:
@@ -70,7 +75,7 @@ def run_network(inputs, viewdirs, fn, embed_fn=None, embeddirs_fn=None, netchunk
     (the stand-alone encoding kernel), concatenate, `batchify(fn, netchunk)`."""
     net = _unwrap(fn)
     if _fused_applies(net, embed_fn, embeddirs_fn, viewdirs is not None):
-        return _QueryFunction.apply(inputs, viewdirs, net, *net.ordered_parameters())
+        return _QueryFunction.apply(inputs, viewdirs, net, torch.is_grad_enabled(), *net.ordered_parameters())
     inputs_flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
     embedded = embed_fn(inputs_flat)
     if viewdirs is not None:

@@ -86,6 +86,12 @@ def install_nerfplusplus():
     return sorted(names + ["nerf_sample_ray_split"])
 
 
-def install():
-    """Registers the mirrors under the reference's module names (see the module docstring)."""
-    return _register(_MAP)
+def install(share_matrix_node=True):
+    """Registers the mirrors under the reference's module names (see the module docstring).  run_nerf.py's train() runs ONE
+    backward per step (NeRF/run_nerf.py:598), so the camera model's K / E pair may share one autograd node there
+    (`share_matrix_node`: camera_model._PinholeRotNoise); pass False for a script that backpropagates through K and E
+    separately."""
+    names = _register(_MAP)
+    from . import camera_model
+    camera_model._PinholeRotNoise.share_matrix_node = bool(share_matrix_node)
+    return names

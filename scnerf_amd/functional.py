@@ -25,6 +25,10 @@ class RenderConfig:
     n_importance: int
     lindisp: bool
     white_bkgd: bool
+    # torch.is_grad_enabled() where render_rays was CALLED: inside Function.forward grad mode is always off, and
+    # ctx.needs_input_grad stays True for parameters that require grad under torch.no_grad() -- without this flag a
+    # forward-only call (render_path) would run the training instantiation and store every activation
+    track: bool = True
 
 
 _host_cache = {}
@@ -65,17 +69,20 @@ class RenderRaysFunction(torch.autograd.Function):
         n = rays.shape[0]
         dev = rays.device
         sc, sf = cfg.n_samples, cfg.n_importance
-        # (grad mode is always off inside Function.forward; needs_input_grad is the real signal)
-        train = any(ctx.needs_input_grad)
+        train = cfg.track and any(ctx.needs_input_grad)
         viewdirs = rays[:, 8:11]
 
         net_c.require_standard()
         flat_c = net_c.flat_parameters()
-        wf_c = ops.pack_weights(flat_c, "fwd")
         save_c = ops.save_workspace(n * sc, dev) if train else None
-        # what the arithmetic in force (ops.mlp_arithmetic) needs besides the packed fp32 buffer: the resident kernels'
-        # streams, or nothing (the fused fp32-MFMA kernels)
-        pl_c = ops.pack_for_arithmetic(flat_c, train) if n > 0 else None
+        # the packed fp32 tables + what the arithmetic in force (ops.mlp_arithmetic) needs besides them: the resident
+        # kernels' streams, or nothing (the fused fp32-MFMA kernels).  Training packs per call (the weights change every
+        # step); a forward-only call takes them from the network's version-keyed cache (ops.inference_packs)
+        if train or n == 0:
+            wf_c = ops.pack_weights(flat_c, "fwd")
+            pl_c = ops.pack_for_arithmetic(flat_c, train) if n > 0 else None
+        else:
+            wf_c, pl_c = ops.inference_packs(net_c, flat_c)
         resident = isinstance(pl_c, ops.ResidentWeights)
         # (resident kernels, training: they leave the chunk maxima the fp16 weight-gradient GEMMs scale by)
         mx_c = ops.ChunkMaxima(n * sc, dev) if (train and resident) else None
@@ -107,9 +114,14 @@ class RenderRaysFunction(torch.autograd.Function):
         tot = sc + sf
         fine_net.require_standard()
         flat_f = fine_net.flat_parameters()
-        wf_f = wf_c if fine_net is net_c else ops.pack_weights(flat_f, "fwd")
         save_f = ops.save_workspace(n * tot, dev) if train else None
-        pl_f = pl_c if fine_net is net_c else (ops.pack_for_arithmetic(flat_f, train) if n > 0 else None)
+        if fine_net is net_c:
+            wf_f, pl_f = wf_c, pl_c
+        elif train or n == 0:
+            wf_f = ops.pack_weights(flat_f, "fwd")
+            pl_f = ops.pack_for_arithmetic(flat_f, train) if n > 0 else None
+        else:
+            wf_f, pl_f = ops.inference_packs(fine_net, flat_f)
         mx_f = ops.ChunkMaxima(n * tot, dev) if (train and resident) else None
         if ops.fused_fine_stage() and resident and sc == ops.COARSE_STAGE_SAMPLES and sf in ops.FINE_STAGE_IMPORTANCE and n > 0:
             # the whole fine stage -- inverse-cdf sampler, merge, network, compositing -- as one launch (opt-in: measured

@@ -45,7 +45,7 @@ class _NerfNetFunction(torch.autograd.Function):
     of NerfNet.forward (_OUT_KEYS order)."""
 
     @staticmethod
-    def forward(ctx, ray_o, ray_d, fg_z_max, fg_z, bg_z, fg_net, bg_net, *params):
+    def forward(ctx, ray_o, ray_d, fg_z_max, fg_z, bg_z, fg_net, bg_net, track, *params):
         sf, sb = fg_z.shape[-1], bg_z.shape[-1]
         dots = ray_d.shape[:-1]
         o = ray_o.reshape(-1, 3).contiguous().float()
@@ -55,7 +55,8 @@ class _NerfNetFunction(torch.autograd.Function):
         zb = bg_z.reshape(-1, sb).contiguous().float()
         n, dev = o.shape[0], o.device
         lib = _capi.load()
-        train = any(ctx.needs_input_grad)
+        # (`track`: torch.is_grad_enabled() at the call; needs_input_grad alone stays True under torch.no_grad())
+        train = track and any(ctx.needs_input_grad)
         fg_pts = torch.empty((n * sf, 3), dtype=torch.float32, device=dev)
         bg_pts = torch.empty((n * sb, 4), dtype=torch.float32, device=dev)
         views = torch.empty((n, 3), dtype=torch.float32, device=dev)
@@ -65,15 +66,19 @@ class _NerfNetFunction(torch.autograd.Function):
         save_f = ops.save_workspace(n * sf, dev, 3) if train else None
         save_b = ops.save_workspace(n * sb, dev, 4) if train else None
         # the arithmetic in force (ops.mlp_arithmetic): the resident kernels' streams, as in the SCNeRF step
-        pl_f = ops.pack_for_arithmetic(flat_f, train, 3, remap=fg_net.pack_remap()) if n > 0 else None
-        pl_b = ops.pack_for_arithmetic(flat_b, train, 4, remap=bg_net.pack_remap()) if n > 0 else None
+        if train or n == 0:
+            pl_f = ops.pack_for_arithmetic(flat_f, train, 3, remap=fg_net.pack_remap()) if n > 0 else None
+            pl_b = ops.pack_for_arithmetic(flat_b, train, 4, remap=bg_net.pack_remap()) if n > 0 else None
+            wf_f = ops.pack_weights(flat_f, "fwd", pd=3, remap=fg_net.pack_remap())
+            wf_b = ops.pack_weights(flat_b, "fwd", pd=4, remap=bg_net.pack_remap())
+        else:                                          # (forward-only: packed once per weight version)
+            wf_f, pl_f = ops.inference_packs(fg_net, flat_f, 3, remap=fg_net.pack_remap())
+            wf_b, pl_b = ops.inference_packs(bg_net, flat_b, 4, remap=bg_net.pack_remap())
         resident = train and isinstance(pl_f, ops.ResidentWeights)
         mx_f = ops.ChunkMaxima(n * sf, dev) if resident else None        # (for the fp16 weight-gradient GEMMs)
         mx_b = ops.ChunkMaxima(n * sb, dev) if resident else None
-        raw_f = ops.mlp_fwd(fg_pts, views, sf, ops.pack_weights(flat_f, "fwd", pd=3, remap=fg_net.pack_remap()),
-                            save_f, pd=3, planes=pl_f, maxima=mx_f)
-        raw_b = ops.mlp_fwd(bg_pts, views, sb, ops.pack_weights(flat_b, "fwd", pd=4, remap=bg_net.pack_remap()),
-                            save_b, pd=4, planes=pl_b, maxima=mx_b)
+        raw_f = ops.mlp_fwd(fg_pts, views, sf, wf_f, save_f, pd=3, planes=pl_f, maxima=mx_f)
+        raw_b = ops.mlp_fwd(bg_pts, views, sb, wf_b, save_b, pd=4, planes=pl_b, maxima=mx_b)
         out = {"rgb": (n, 3), "fg_weights": (n, sf), "bg_weights": (n, sb), "fg_rgb": (n, 3), "fg_depth": (n,),
                "bg_rgb": (n, 3), "bg_depth": (n,), "bg_lambda": (n,)}
         t = {k: torch.empty(sh, dtype=torch.float32, device=dev) for k, sh in out.items()}
@@ -129,7 +134,7 @@ class _NerfNetFunction(torch.autograd.Function):
             by_module = {canonical_to_module_name(k): v for k, v in by_canon.items()}
             return [by_module[name] for name, _ in net.named_parameters()]
 
-        return (g_o.view(o_shape), g_d.view(o_shape), d_zmax.view(zmax_shape), g_z.view(fgz_shape), None, None, None,
+        return (g_o.view(o_shape), g_d.view(o_shape), d_zmax.view(zmax_shape), g_z.view(fgz_shape), None, None, None, None,
                 *per_param(fg_net, flat_gf, 3), *per_param(bg_net, flat_gb, 4))
 
 
@@ -164,7 +169,7 @@ class NerfNet(nn.Module):
         fg_params = [p for _, p in self.fg_net.named_parameters()]
         bg_params = [p for _, p in self.bg_net.named_parameters()]
         outs = _NerfNetFunction.apply(ray_o, ray_d, fg_z_max, fg_z_vals, bg_z_vals, self.fg_net, self.bg_net,
-                                      *fg_params, *bg_params)
+                                      torch.is_grad_enabled(), *fg_params, *bg_params)
         return OrderedDict(zip(_OUT_KEYS, outs))
 
 

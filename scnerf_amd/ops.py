@@ -117,14 +117,50 @@ def sample_pdf(bins: Tensor, weights: Tensor, u: Tensor, want_inds=False, want_c
     return samples, inds, cdf
 
 
-_random_calls = [0]
+_random_state = {"shard": None, "draw": None}
+_MASK64 = 0xFFFFFFFFFFFFFFFF
+
+
+def random_shard(shard: Optional[int] = None) -> int:
+    """Which slice of the Philox counter space this PROCESS draws from.  Ray-parallel ranks share the seed and make the
+    same sequence of calls: without it ray i of every rank would get the same jitter.  Default: torch.distributed's rank
+    once a process group is up (else $RANK, else 0); `random_shard(k)` pins it."""
+    if shard is not None:
+        _random_state["shard"] = int(shard) & 0xFFFFFFFF
+    if _random_state["shard"] is not None:
+        return _random_state["shard"]
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return int(dist.get_rank())
+    except Exception:
+        pass
+    return int(os.environ.get("RANK", "0") or 0)
+
+
+def next_random_call(device) -> tuple:
+    """-> (seed, call) of the next render_randoms launch.  There is no hidden counter: `call` is one 63-bit draw from
+    torch's DEFAULT (CPU) generator (1.4 us on the host, no device work), so torch.manual_seed(s) -- at the start or in the
+    middle of a process -- reproduces everything that follows, as it does for the reference's torch.rand calls; the
+    process's shard (random_shard) is folded in so that ranks draw apart.  `seed` is torch.initial_seed(); where the device
+    generator was seeded on its own (torch.cuda.manual_seed, which the reference's on-device torch.rand would honour) its
+    seed is mixed in."""
+    seed = torch.initial_seed() & _MASK64
+    if torch.device(device).type == "cuda":
+        cs = torch.cuda.initial_seed() & _MASK64
+        if cs != seed:
+            seed = (seed * 0x9E3779B97F4A7C15 + cs) & _MASK64
+    if _random_state["draw"] is None:
+        _random_state["draw"] = torch.empty((), dtype=torch.int64, device="cpu")
+    call = int(_random_state["draw"].random_()) ^ ((random_shard() * 0x9E3779B97F4A7C15) & _MASK64)
+    return seed, call
 
 
 def render_randoms(n: int, n_samples: int, n_importance: int, raw_noise_std: float, device, want_t_rand=True, want_u=True):
     """The draws of one render_rays call in ONE launch (csrc/randoms.hip; reference NeRF/render.py:252-257, :329-330,
     :425-429): -> (t_rand [n, S] | None, u [n, N_importance] | None, noise_c [n, S] | None, noise_f [n, S + N_importance] |
-    None), the noises already multiplied by raw_noise_std.  Philox4x32-10 keyed by torch.initial_seed(), counter = (element,
-    stream, a per-process call counter): reproducible from torch.manual_seed for a given sequence of calls."""
+    None), the noises already multiplied by raw_noise_std.  Philox4x32-10, key and call id from `next_random_call`:
+    reproducible from torch.manual_seed, different on every rank."""
     S, F = int(n_samples), int(n_importance)
     sizes = [n * S if want_t_rand else 0, n * F if (want_u and F > 0) else 0,
              n * S if raw_noise_std > 0 else 0, n * (S + F) if (raw_noise_std > 0 and F > 0) else 0]
@@ -134,9 +170,10 @@ def render_randoms(n: int, n_samples: int, n_importance: int, raw_noise_std: flo
     for z, pz in zip(sizes, padded):
         outs.append(buf[o:o + z] if z else None)
         o += pz
-    _random_calls[0] += 1
-    st = _capi.load().scnerf_render_randoms(torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, _random_calls[0],
-                                            _p(outs[0]), sizes[0], _p(outs[1]), sizes[1], _p(outs[2]), sizes[2],
+    if sum(sizes) == 0:
+        return (None, None, None, None)
+    seed, call = next_random_call(device)
+    st = _capi.load().scnerf_render_randoms(seed, call, _p(outs[0]), sizes[0], _p(outs[1]), sizes[1], _p(outs[2]), sizes[2],
                                             _p(outs[3]), sizes[3], float(max(raw_noise_std, 0.0)), _stream())
     _capi.check(st, "scnerf_render_randoms")
     shapes = [(n, S), (n, F), (n, S), (n, S + F)]
@@ -254,6 +291,47 @@ def pack_for_arithmetic(flat_params: Tensor, train: bool, pd: int = 3, remap=Non
         return pack_resident(flat_params, pd, remap=remap)
     return None
 
+
+
+_PACK_CACHE = [os.environ.get("SCNERF_PACK_CACHE", "1") != "0"]
+PACK_CACHE_STATS = {"hits": 0, "packs": 0}
+
+
+def weight_pack_cache(on: Optional[bool] = None) -> bool:
+    """Inference keeps the packed weights of a network between calls (a version-keyed cache):
+    render_path renders an image in ~24 chunks of rays with the SAME weights, and re-packing per chunk was 2 x 5 launches
+    of nothing.  The key is everything autograd knows about the weights' identity: the flat buffer's address and version
+    and every parameter's version (in-place optimizer steps, load_state_dict and FusedAdam.step all bump them).  Writes
+    that by-pass version counting (`p.data.mul_(...)`) are invisible to it -- switch the cache off around them
+    (`weight_pack_cache(False)`, SCNERF_PACK_CACHE=0) or call `forget_packs(net)`.  Training never uses it."""
+    if on is not None:
+        _PACK_CACHE[0] = bool(on)
+    return _PACK_CACHE[0]
+
+
+def forget_packs(net) -> None:
+    if hasattr(net, "_infer_packs"):
+        net._infer_packs = None
+
+
+def inference_packs(net, flat_params: Tensor, pd: int = 3, remap=None):
+    """-> (packed fp32 forward tables, what the arithmetic in force needs besides them) for a forward-only call, packed
+    once per weight version (weight_pack_cache)."""
+    def build():
+        PACK_CACHE_STATS["packs"] += 1
+        return (pack_weights(flat_params, "fwd", pd=pd, remap=remap), pack_for_arithmetic(flat_params, False, pd, remap=remap))
+    if not _PACK_CACHE[0]:
+        return build()
+    key = (flat_params.data_ptr(), flat_params._version, tuple(p._version for p in net.parameters()), _MLP_ARITHMETIC[0], pd,
+           torch.cuda.current_stream(flat_params.device).cuda_stream if flat_params.is_cuda else 0)
+    hit = getattr(net, "_infer_packs", None)
+    if hit is not None and hit[0] == key:
+        PACK_CACHE_STATS["hits"] += 1
+        return hit[1]
+    packs = build()
+    # (a plain attribute, not a buffer: it must not travel in state_dict() or follow .to())
+    object.__setattr__(net, "_infer_packs", (key, packs))
+    return packs
 
 _canon_cache = {}
 

@@ -104,7 +104,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         return _render_rays_opaque(ray_batch, network_fn, network_query_fn, int(N_samples), retraw, bool(lindisp),
                                    int(N_importance), network_fine, bool(white_bkgd), t_rand, u, noise_c, noise_f,
                                    CHECK_NUMERICS or verbose)
-    cfg = RenderConfig(int(N_samples), int(N_importance), bool(lindisp), bool(white_bkgd))
+    cfg = RenderConfig(int(N_samples), int(N_importance), bool(lindisp), bool(white_bkgd), torch.is_grad_enabled())
     params = list(net_c.ordered_parameters()) + (list(net_f.ordered_parameters()) if net_f is not None else [])
     (rgb_map, disp_map, acc_map, depth_map, raw, rgb0, disp0, acc0, depth0, z_std, z_vals,
      z_samples) = RenderRaysFunction.apply(ray_batch, cfg, t_rand, u, noise_c, noise_f, net_c, net_f, *params)

@@ -215,7 +215,7 @@ class NeRF(nn.Module):
                 raise ValueError("NeRF.forward: x is not the positional encoding (multires %d / %d, include_input) of "
                                  "its own leading columns (max deviation %g)" % (ML.L_PTS, ML.L_VIEWS, err))
         from .create_nerf import _QueryFunction
-        raw = _QueryFunction.apply(pts.reshape(-1, 1, 3), views, self, *self.ordered_parameters())
+        raw = _QueryFunction.apply(pts.reshape(-1, 1, 3), views, self, torch.is_grad_enabled(), *self.ordered_parameters())
         return raw.reshape(*lead, 4)
 
     def _forward_layer_by_layer(self, x):

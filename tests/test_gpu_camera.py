@@ -356,9 +356,11 @@ def test_combined_config3_step_gradients_with_decisions_aligned(M):
 
 def test_separate_backward_passes_through_K_and_E(M):
     """In the reference get_intrinsic() and get_extrinsic() build independent graphs: loss_K.backward(); loss_E.backward()
-    works.  Here the pair shares one node by default (the second backward needs retain_graph on the first);
-    `share_matrix_node = False` restores the reference's structure, with the same gradients."""
+    works, and so it does here by default.  With `share_matrix_node = True` (dropin.install(), bench.py: loops with one
+    backward per step) the pair shares one node and the second backward needs retain_graph on the first; same gradients."""
     cm, _, _ = make_camera(M, "pinhole_rot_noise_10k_rayo_rayd", True)
+    assert cm.share_matrix_node is False or type(cm).share_matrix_node is True     # (True only after dropin.install() in this process)
+    cm.share_matrix_node = True
     K, E = cm.get_intrinsic(), cm.get_extrinsic()
     (K.sum() * 2.0).backward(retain_graph=True)
     (E ** 2).sum().backward()

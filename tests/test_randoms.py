@@ -48,6 +48,17 @@ def philox_numpy(ctr, k0, k1):
     return c.astype(np.uint32)
 
 
+def _cpu_generator_draws(seed, k):
+    """the first k 63-bit draws of torch's default generator after manual_seed(seed) (what ops.next_random_call consumes)"""
+    state = torch.get_rng_state()
+    torch.manual_seed(seed)
+    t = torch.empty((), dtype=torch.int64)
+    out = [int(t.random_()) for _ in range(k)]
+    torch.set_rng_state(state)
+    torch.manual_seed(seed)
+    return out
+
+
 def expected_uniforms(seed, call, stream, n):
     quads = (n + 3) // 4
     ctr = np.zeros((quads, 4), np.uint32)
@@ -102,12 +113,13 @@ def test_distributions_on_the_interpreter():
 @pytest.mark.gpu
 def test_gpu_draws_equal_the_interpreters_uniforms_and_are_well_distributed():
     from scnerf_amd import ops
+    ops.random_shard(0)
     torch.manual_seed(1234)
-    ops._random_calls[0] = 10
+    call = _cpu_generator_draws(1234, 1)[0]       # (the call id IS the default generator's next 63-bit draw)
     t_rand, u, noise_c, noise_f = ops.render_randoms(4096, 64, 128, 1.0, torch.device("cuda"))
     assert t_rand.shape == (4096, 64) and u.shape == (4096, 128) and noise_c.shape == (4096, 64) and noise_f.shape == (4096, 192)
-    np.testing.assert_array_equal(t_rand.cpu().numpy().reshape(-1), expected_uniforms(1234, 11, 0, 4096 * 64))
-    np.testing.assert_array_equal(u.cpu().numpy().reshape(-1), expected_uniforms(1234, 11, 1, 4096 * 128))
+    np.testing.assert_array_equal(t_rand.cpu().numpy().reshape(-1), expected_uniforms(1234, call, 0, 4096 * 64))
+    np.testing.assert_array_equal(u.cpu().numpy().reshape(-1), expected_uniforms(1234, call, 1, 4096 * 128))
     _distribution_checks(*(x.cpu().numpy().reshape(-1) for x in (t_rand, u, noise_c, noise_f)), std=1.0)
     # nothing wanted, nothing drawn
     assert ops.render_randoms(16, 64, 0, 0.0, torch.device("cuda"), want_t_rand=False, want_u=False) == (None, None, None, None)
@@ -131,7 +143,6 @@ def test_gpu_render_rays_draws_in_one_launch_of_its_own():
         with torch.no_grad():
             return render_rays(rays, net, query, 64, perturb=1.0, N_importance=128, network_fine=net, raw_noise_std=1.0)["rgb_map"]
     torch.manual_seed(5)
-    ops._random_calls[0] = 0
     with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
         a = run()
         torch.cuda.synchronize()
@@ -139,7 +150,43 @@ def test_gpu_render_rays_draws_in_one_launch_of_its_own():
     assert not any("distribution" in k or "philox" in k.lower() and "render_randoms" not in k for k in names), names
     assert any("render_randoms_kernel" in k for k in names), names
     b = run()
-    torch.manual_seed(5)
-    ops._random_calls[0] = 0
+    torch.manual_seed(6)
+    d = run()
+    torch.manual_seed(5)                          # re-seeding alone reproduces the run (the call counter restarts with the seed)
     c = run()
-    assert torch.equal(a, c) and not torch.equal(a, b)
+    assert torch.equal(a, c) and not torch.equal(a, b) and not torch.equal(a, d)
+    # ray-parallel ranks share the seed and the sequence of calls: the process's shard of the counter space keeps their draws apart
+    torch.manual_seed(5)
+    ops.random_shard(3)
+    try:
+        e = run()
+    finally:
+        ops.random_shard(0)
+    assert not torch.equal(a, e)
+
+
+def test_call_ids_come_from_the_default_generator_and_ranks_draw_apart():
+    """the host-side bookkeeping on the interpreter: no hidden counter -- (seed, shard, the default generator's state) is
+    the whole state, so re-seeding with the SAME seed mid-process reproduces what follows"""
+    from scnerf_amd import ops
+    from tests.emu.host_on_emu import emulated_device
+    with emulated_device():
+        ops.random_shard(0)
+        c1, c2 = _cpu_generator_draws(77, 2)
+        torch.manual_seed(77)
+        a1 = ops.render_randoms(8, 64, 8, 0.0, "cpu")[0].clone()
+        a2 = ops.render_randoms(8, 64, 8, 0.0, "cpu")[0].clone()
+        torch.manual_seed(77)
+        b1 = ops.render_randoms(8, 64, 8, 0.0, "cpu")[0].clone()
+        np.testing.assert_array_equal(a1.numpy().reshape(-1), expected_uniforms(77, c1, 0, 8 * 64))
+        np.testing.assert_array_equal(a2.numpy().reshape(-1), expected_uniforms(77, c2, 0, 8 * 64))
+        assert torch.equal(a1, b1) and not torch.equal(a1, a2)
+        torch.manual_seed(77)
+        ops.random_shard(5)
+        try:
+            d1 = ops.render_randoms(8, 64, 8, 0.0, "cpu")[0].clone()
+        finally:
+            ops._random_state["shard"] = None
+        want = c1 ^ ((5 * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+        np.testing.assert_array_equal(d1.numpy().reshape(-1), expected_uniforms(77, want, 0, 8 * 64))
+        assert ops.random_shard() == 0            # (no process group, no $RANK: shard 0)
