@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 # everything the parity tests measured; tests/conftest.py writes it at the end of the session to
-# gpurun_out/parity_r05.json (travels back from the GPU box; the copy committed under profiles/ is this file)
+# gpurun_out/parity_r06.json (travels back from the GPU box; the copy committed under profiles/ is this file)
 # and to profiles/ in the tree the tests ran in
 REPORT = {}
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,7 +29,7 @@ def write_report():
         return
     merged = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "parity_r05.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "parity_r06.json")) as f:
             merged = json.load(f)
     except (OSError, ValueError):
         pass
@@ -37,7 +37,7 @@ def write_report():
     for d in ("gpurun_out", "profiles"):
         try:
             os.makedirs(os.path.join(ROOT, d), exist_ok=True)
-            with open(os.path.join(ROOT, d, "parity_r05.json"), "w") as f:
+            with open(os.path.join(ROOT, d, "parity_r06.json"), "w") as f:
                 json.dump(merged, f, indent=1, sort_keys=True)
         except OSError:
             pass

@@ -264,8 +264,9 @@ def test_render_through_camera_model_config3(M, n):
         assert v["kernels_vs_fp64_max"] <= 5e-2, (name, v)
 
 
-def test_combined_config3_step_gradients_with_decisions_aligned(M):
-    """ONE training step of BASELINE configs[3] as run_nerf.py forms it (:503-598): rays from the learnable camera model ->
+@pytest.mark.parametrize("n,n_pairs", [(256, 512), (4096, 1024)], ids=["256rays", "4096rays"])
+def test_combined_config3_step_gradients_with_decisions_aligned(M, n, n_pairs):
+    """(At 256 rays and at the headline batch bench.py --config 3 runs: 4096 rays + 1024 matches.)  ONE training step of BASELINE configs[3] as run_nerf.py forms it (:503-598): rays from the learnable camera model ->
     coarse + fine render -> img2mse of both stages, PLUS ray_dist_loss_weight x the projected-ray-distance loss of one
     image pair whose rays come from the same camera model (model/ray_dist_loss.py:22-246), one backward into both networks
     and the four camera tensors.  Compared per gradient with the fp32 oracle evaluating the same combined loss on the GPU
@@ -276,7 +277,7 @@ def test_combined_config3_step_gradients_with_decisions_aligned(M):
     from tests import parity_attribution as PA
     from tests.test_gpu_render import _kernel_gates, _render_node
     import types
-    n, sc, sf, weight = 256, 64, 128, 1e-4 * 50          # (the demo's weight x 50: the PRD share of the camera gradients is visible)
+    sc, sf, weight = 64, 128, 1e-4 * 50                   # (the demo's weight x 50: the PRD share of the camera gradients is visible)
     kps, idx = synth.keypoints(HH, WW, n, n_cams=17, seed=9, integer=True)
     rnd = synth.render_randoms(n, sc, sf, seed=3)
     rnd_d = {k: v.cuda() for k, v in rnd.items()}
@@ -285,7 +286,7 @@ def test_combined_config3_step_gradients_with_decisions_aligned(M):
     i0, i1 = 2, 5
     with torch.no_grad():
         k0, k1 = synth.matched_keypoints(HH, WW, cm.get_intrinsic().cpu(), cm.get_extrinsic()[i0].cpu(),
-                                         cm.get_extrinsic()[i1].cpu(), 512, seed=6)
+                                         cm.get_extrinsic()[i1].cpu(), n_pairs, seed=6)
 
     def net(seed):
         m = M.h.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
@@ -296,7 +297,7 @@ def test_combined_config3_step_gradients_with_decisions_aligned(M):
     # ---- the step on the GPU, as the script runs it
     ro, rd = M.gr.get_rays_kps_use_camera(HH, WW, cm, kps.cuda(), idx_in_camera_param=idx.cuda())
     rgb, _, _, extras = M.render.render(
-        H=HH, W=WW, chunk=8192, rays=torch.stack([ro, rd]), retraw=True, camera_model=cm, mode="train",
+        H=HH, W=WW, chunk=1 << 15, rays=torch.stack([ro, rd]), retraw=True, camera_model=cm, mode="train",
         network_query_fn=query, perturb=1.0, N_importance=sf, network_fine=net_f, N_samples=sc, network_fn=net_c,
         use_viewdirs=True, white_bkgd=False, raw_noise_std=1.0, near=0., far=1., _randoms=rnd_d)
     node = _render_node(rgb)
@@ -333,9 +334,11 @@ def test_combined_config3_step_gradients_with_decisions_aligned(M):
     ref_total = ref_loss + weight * ref_prd
     ref_total.backward()
     assert n_match == ref_match and n_match > 100
-    np.testing.assert_allclose(float(prd.detach()), float(ref_prd.detach()), rtol=2e-5)
+    # (the loss is a mean of per-match distances that are themselves ill-conditioned in fp32 -- near-parallel rays; measured
+    #  1.1e-5 at 512 pairs, 2.1e-5 at 1024)
+    np.testing.assert_allclose(float(prd.detach()), float(ref_prd.detach()), rtol=5e-5)
     np.testing.assert_allclose(float(loss.detach()), float(ref_loss.detach()), rtol=5e-6)
-    rep = {"n_match": n_match, "prd_loss": float(prd.detach()), "render_loss": float(loss.detach())}
+    rep = {"n_match": n_match, "prd_loss_rel_err": abs(float(prd.detach()) - float(ref_prd.detach())) / abs(float(ref_prd.detach())), "prd_loss": float(prd.detach()), "render_loss": float(loss.detach())}
     for name in ("intrinsics_noise", "extrinsics_noise", "ray_o_noise", "ray_d_noise"):
         got, ref = getattr(cm, name).grad.cpu().numpy(), cam[name].grad.numpy()
         rep[name] = {"max": float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30)),
@@ -346,7 +349,7 @@ def test_combined_config3_step_gradients_with_decisions_aligned(M):
             ref = p[pn].grad.numpy()
             worst = max(worst, float(np.abs(prm.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30)))
     rep["network_parameters_worst_max"] = worst
-    PA.REPORT["config3_combined_step_256x(64+128)+prd/decisions_aligned"] = rep
+    PA.REPORT["config3_combined_step_%dx(64+128)+prd/decisions_aligned" % n] = rep
     assert worst <= 1e-4, worst
     for name in ("intrinsics_noise", "extrinsics_noise", "ray_o_noise", "ray_d_noise"):
         # the render's share at the aligned test's bound; the PRD term is ill-conditioned in fp32 (near-parallel rays:

@@ -128,13 +128,15 @@ def test_mlp_forward_matches_oracle(ops, n_rays, spr, save, pd, resident):
 
 
 @pytest.mark.parametrize("resident", [False, True], ids=["fused_fp32", "resident"])
-@pytest.mark.parametrize("pd", [3, 4])
-def test_mlp_backward_and_weight_gradients_match_autograd(ops, pd, resident):
-    """train forward -> dgrad -> 12 wgrad GEMMs for both network variants vs torch autograd on the oracle; forward and
+@pytest.mark.parametrize("pd,kind", [(3, "xavier"), (4, "xavier"), (3, "trained")])
+def test_mlp_backward_and_weight_gradients_match_autograd(ops, pd, resident, kind):
+    """(`kind`: tests/trained_weights.py)  train forward -> dgrad -> 12 wgrad GEMMs for both network variants vs torch autograd on the oracle; forward and
     data gradients on the fused fp32 kernels or on the resident-arithmetic ones."""
     from tests.emu_mlp_util import network_params
     lay = ML.layout(pd)
-    p = {k: v.clone().requires_grad_(True) for k, v in network_params(4 if pd == 3 else 779, pd).items()}
+    from tests import trained_weights as TW
+    src = network_params(4 if pd == 3 else 779, pd) if kind == "xavier" else TW.weights(kind, 4)
+    p = {k: v.clone().requires_grad_(True) for k, v in src.items()}
     flat = dev(_flat({k: v.detach() for k, v in p.items()}, pd))
     n_rays, spr = 21, 50                       # 1050 samples: ragged last workgroup
     P = n_rays * spr
@@ -389,30 +391,34 @@ def test_narrow_weight_gradient_gemms_are_fp32_grade(ops, shape):
     assert err["half"]["max"] <= 2.0 * err["fp32"]["max"] + 1e-9 and err["half"]["rms"] <= 2.0 * err["fp32"]["rms"], err
 
 
-def test_resident_layers_are_fp32_grade(ops):
-    """Every layer of the resident-arithmetic forward (three fp16 products, per-sample scale from the row 1-norm bound;
+@pytest.mark.parametrize("kind", ["xavier", "trained", "adversarial"])
+def test_resident_layers_are_fp32_grade(ops, kind):
+    """(`kind`: the weight distribution, tests/trained_weights.py -- the reference's initialisation, a network trained for
+    5000 steps, and hand-made layers aimed at the per-sample scale bound.)  Every layer of the resident-arithmetic forward (three fp16 products, per-sample scale from the row 1-norm bound;
     csrc/mlp_h3.h) over 131 072 samples against fp64 ON ITS OWN INPUT (what the kernel saved for the layer below),
     beside the fused fp32-MFMA kernel judged the same way: the error relative to sum |w x| + |b| must be that of the
     exact-fp32 path (accumulation-order noise), for layer 0 (encoded point), the trunk, the skip layer, the linear
     feature layer and the views layer alike.  Also: the scales never overflow fp16 (no inf / nan anywhere) on inputs
     whose magnitude varies over 2^20 between samples."""
     from tests import parity_attribution as PA
-    from tests.emu_mlp_util import network_params
+    from tests import trained_weights as TW
     lay = ML.layout(3)
-    p = network_params(4, 3)
+    p = TW.weights(kind, 4)
     flat = dev(_flat(p, 3))
     n_rays, spr = 2048, 64
     P = n_rays * spr
     g = torch.Generator().manual_seed(8)
     pts = torch.rand(P, 3, generator=g) * 2.4 - 1.2
     pts[: P // 8] *= torch.exp2(torch.randint(-10, 10, (P // 8, 1), generator=g).float())      # far / tiny points
+    pts_host = pts.clone()
     pts = dev(pts)
     vd = torch.randn(n_rays, 3, generator=g)
     vd = dev(vd / vd.norm(dim=-1, keepdim=True))
     wf = ops.pack_weights(flat, "fwd")
     saves = {"fp32": ops.save_workspace(P, "cuda").zero_(), "resident": ops.save_workspace(P, "cuda").zero_()}
     raw32 = ops.mlp_fwd(pts, vd, spr, wf, saves["fp32"])
-    raw16 = ops.mlp_fwd(pts, vd, spr, wf, saves["resident"], planes=ops.pack_resident(flat))
+    planes = ops.pack_resident(flat)
+    raw16 = ops.mlp_fwd(pts, vd, spr, wf, saves["resident"], planes=planes)
     assert bool(torch.isfinite(raw16).all()) and bool(torch.isfinite(saves["resident"][: lay.save_floats_per_sample * ML.padded_samples(P)]).all())
     Pp = ML.padded_samples(P)
     off, _ = ML.section_offsets(lay.save_sections, P)
@@ -434,7 +440,7 @@ def test_resident_layers_are_fp32_grade(ops):
         return x, dev(p["pts_linears.%d.weight" % l]), dev(p["pts_linears.%d.bias" % l]), rows(save, "act%d" % l), True
 
     report = {}
-    for l in (0, 1, 2, 5, 7, "feat", "views"):
+    for l in (0, 1, 2, 3, 4, 5, 7, "feat", "views"):
         for mode in ("fp32", "resident"):
             x, W, b, z, relu = layer_io(saves[mode], l)
             ref = x.double() @ W.double().T + b.double()
@@ -445,23 +451,36 @@ def test_resident_layers_are_fp32_grade(ops):
             report.setdefault("layer_%s" % l, {})[mode] = {"max": float(e.max()), "rms": float((e * e).mean().sqrt())}
     e_raw = (raw16 - raw32).abs().max(1)[0] / raw32.abs().max(1)[0].clamp_min(1.0)
     report["raw_vs_fused_fp32_relative_max"] = float(e_raw.max())
-    PA.REPORT["resident_layer_arithmetic_131072_samples_error_over_sum_abs_products_vs_fp64"] = report
+    # where the per-sample scales put the values they cut: (largest |value| of a sample's layer output) x S, log2
+    margins = TW.scale_margins(ops, planes, saves["resident"], P, pts_host.cuda())
+    report["per_sample_scale_margins_log2_of_max_abs_z_times_S"] = margins
+    suffix = "" if kind == "xavier" else "_%s_weights" % kind
+    PA.REPORT["resident_layer_arithmetic_131072_samples_error_over_sum_abs_products_vs_fp64" + suffix] = report
+    for layer, m in margins.items():
+        # fp32 grade needs max|z| S in [2^-3, 2^13) (csrc/mlp_h3.h:23-25): never above (fp16 would overflow), and below only
+        # for samples whose whole layer is (nearly) dead
+        assert m["log2_max"] < 13.0, (layer, m)
+    if kind == "adversarial":
+        # the cancellation row did what it was built for: layer 3's scales sit ~ten octaves lower than layer 2's
+        assert margins["layer_3"]["log2_max"] < margins["layer_2"]["log2_max"] - 6.0, margins
     for layer, r in report.items():
-        if not isinstance(r, dict):
+        if not isinstance(r, dict) or "resident" not in r:
             continue
         assert r["resident"]["rms"] <= 2.0 * r["fp32"]["rms"] and r["resident"]["max"] <= 3.0 * r["fp32"]["max"] + 1e-9, (layer, r)
         assert r["resident"]["max"] < 1e-6, (layer, r)
     assert report["raw_vs_fused_fp32_relative_max"] <= 2e-5, report
 
 
-def test_resident_data_gradients_follow_the_fused_chain_row_by_row(ops):
-    """The resident data-gradient chain against the fused fp32 chain on the SAME saved activations, with every
+@pytest.mark.parametrize("kind", ["xavier", "trained", "adversarial"])
+def test_resident_data_gradients_follow_the_fused_chain_row_by_row(ops, kind):
+    """(`kind`: tests/trained_weights.py; the hand-made layers of "adversarial" inflate the column-1-norm bounds of the
+    transposed layers just as they inflate the forward's row bounds.)  The resident data-gradient chain against the fused fp32 chain on the SAME saved activations, with every
     sample's incoming gradient scaled by its own power of ten between 1e-30 and 1e+10 (and some exactly zero): every
     gradient section agrees row by row to 2e-5 of the row's size -- the per-sample scales carry forty orders of
     magnitude -- and zero rows stay exactly zero."""
-    from tests.emu_mlp_util import network_params
+    from tests import trained_weights as TW
     lay = ML.layout(3)
-    p = network_params(4, 3)
+    p = TW.weights(kind, 4)
     flat = dev(_flat(p, 3))
     n_rays, spr = 1024, 192
     P = n_rays * spr

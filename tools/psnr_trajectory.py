@@ -86,7 +86,7 @@ def run_oracle(steps, every, threads, perturb=0.0, perturb_seed=0):
     return curve
 
 
-def run_gpu(steps, every, arithmetic, perturb=0.0, perturb_seed=0, wgrad=None):
+def run_gpu(steps, every, arithmetic, perturb=0.0, perturb_seed=0, wgrad=None, return_nets=False):
     from scnerf_amd import ops
     from scnerf_amd.create_nerf import FusedNetworkQuery
     from scnerf_amd.optim import FusedAdam
@@ -132,6 +132,8 @@ def run_gpu(steps, every, arithmetic, perturb=0.0, perturb_seed=0, wgrad=None):
         opt.step()
         if (k + 1) % every == 0 or k + 1 == steps:
             curve.append({"step": k + 1, "psnr": psnr_of(evaluate()), "loss": float(loss.detach())})
+    if return_nets:
+        return curve, (net_c, net_f)
     return curve
 
 

@@ -18,7 +18,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LAYERS, W, SECTIONS = 8, 256, 9
-KINDS = {"h3": 0, "h3p": 1, "h3-infer": 2, "h3p-infer": 3, "lds": 4, "lds-infer": 5}
+KINDS = {"h3": 0, "h3p": 1, "h3-infer": 2, "h3p-infer": 3, "lds": 4, "lds-infer": 5, "h3-compact": 6}
 
 
 def lab_input(p, f):
@@ -146,6 +146,25 @@ def untile(block, P):
     """tile-native section [P/32][t 8][q 4][lane 64][4] -> [P, 256]"""
     b = block.reshape(-1, 8, 4, 2, 32, 4)          # tile, t, q, h, m, j
     return b.transpose(0, 4, 1, 2, 3, 5).reshape(-1, 256)[:P]
+
+
+def uncompact(block, words, P):
+    """kind "h3-compact": a section whose wave-tile blocks hold only the non-zero values, packed in ballot order, + the gate
+    words [tiles][lane 64][4] (word 64 r + lane = half (w & 1) of ballot w >> 1; ballot b = ((4 T + q) 4 + e)) -> dense
+    [P, 256] and the packed bytes per tile"""
+    tiles = (P + 31) // 32
+    blk = block.reshape(-1, 32 * 256)[:tiles]
+    wd = words.reshape(-1, 64, 4)[:tiles]
+    flat = wd.transpose(0, 2, 1).reshape(tiles, 256)                   # word index 64 r + lane
+    masks = flat[:, 0::2].astype(np.uint64) | (flat[:, 1::2].astype(np.uint64) << np.uint64(32))      # [tiles, 128]
+    lane = np.arange(64, dtype=np.uint64)
+    bits = ((masks[:, :, None] >> lane[None, None, :]) & np.uint64(1)).astype(np.int64)                # [tiles, 128, 64]
+    order = np.cumsum(bits.reshape(tiles, -1), 1).reshape(tiles, 128, 64) - bits                      # slot of (ballot, lane)
+    vals = np.take_along_axis(blk, np.minimum(order.reshape(tiles, -1), 32 * 256 - 1), 1).reshape(tiles, 128, 64) * bits
+    # ballot b = (4 T + q) 4 + e, lane = m + 32 h -> feature 32 T + 8 q + 4 h + e of sample m
+    v = vals.reshape(tiles, 8, 4, 4, 2, 32)                            # T, q, e, h, m
+    dense = v.transpose(0, 5, 1, 2, 4, 3).reshape(tiles * 32, 256)[:P]
+    return dense.astype(np.float32), bits.reshape(tiles, -1).sum(1) * 4
 
 
 def reference(wts, bias, samples):
@@ -302,7 +321,17 @@ def main():
                 hip.download(d_save, (LAYERS - 1) * W * Ppad * 4, sect)
             else:
                 sect[:] = save[(LAYERS - 1) * W * Ppad:LAYERS * W * Ppad]
-            got = untile(sect, P)[check_rows].astype(np.float64)
+            if name == "h3-compact":
+                words = np.zeros(8 * Ppad, np.uint32)
+                if hip:
+                    hip.download(d_save, (SECTIONS * W * Ppad + (LAYERS - 1) * 8 * Ppad) * 4, words)
+                else:
+                    words[:] = save[SECTIONS * W * Ppad + (LAYERS - 1) * 8 * Ppad:][:8 * Ppad].view(np.uint32)
+                dense, packed_bytes = uncompact(sect, words, P)
+                got = dense[check_rows].astype(np.float64)
+                rec["packed_bytes_over_dense_last_layer"] = float(packed_bytes.sum()) / (32.0 * 256 * 4 * len(packed_bytes))
+            else:
+                got = untile(sect, P)[check_rows].astype(np.float64)
             err = np.abs(got - ref) / mag
             rec["check_rows"] = int(len(check_rows))
             rec["max_err_over_sum_abs"] = float(err.max())

@@ -196,10 +196,68 @@ __global__ __launch_bounds__(h3p::kThreadsP, 2) void chain16_kernel(const short*
     if (!TRAIN || sum == 0x12345u) out[(long)blockIdx.x * kThreadsP + threadIdx.x] = sum;
 }
 
+
+// ---- kind 6: today's residency with GATE-COMPACTED training stores (round 6 lab: fewer HBM bytes per sample?) ----------------
+// A layer's post-ReLU output is ~half zeros and its gate bits are stored anyway.  Here a wave tile's block of a section holds
+// only the non-zero values, densely: per accumulator register (= one feature group of the 64 lanes) the ballot of `v > 0` is
+// the gate word pair, a lane's slot is the running count + the number of set bits below it (v_mbcnt), and the store runs
+// with exec = the ballot -- 4-byte stores into consecutive addresses.  The 128 ballots of a layer are the mask words
+// (collected with v_writelane: word 2 b + half of ballot b = (tile, quarter, element)).  What it costs the epilogue is what
+// this lab measures (tools/residency_lab.py --kinds h3,h3-compact; bytes under --pmc).
+#ifndef SCNERF_SIMT_EMU_BUILD
+struct CompactEpi {
+    float os, s_next, am;
+    const float* bias;
+    global_bytes_rw save;      // this wave tile's block of the layer's section: the packed values from its start
+    unsigned lane16;
+    unsigned run;              // bytes written so far (wave-uniform)
+    unsigned words[4];
+    f32x4 bq;
+    float v[4];
+    unsigned hp;
+
+    template <int P, int PIECE, int SUB, int NS>
+    __device__ __forceinline__ void sub(f32x16 (&acc)[2], h3::u32x4 (&oh)[NS], h3::u32x4 (&ol)[NS]) {
+        constexpr int x = PIECE >> 2, q = PIECE & 3, T = 2 * P + x;
+        constexpr int sl = 2 * T + (q >> 1), c0 = 2 * (q & 1);
+        if constexpr (SUB == 0) {
+            bq = *reinterpret_cast<const f32x4*>(bias + (4 * T + q) * 8);
+            if constexpr (P == 0 && PIECE == 0) { run = 0u; words[0] = words[1] = words[2] = words[3] = 0u; }
+        } else if constexpr (SUB <= 4) {
+            constexpr int e = SUB - 1;
+            constexpr int b = (4 * T + q) * 4 + e;               // ballot index within the layer: 0 .. 127
+            v[e] = relu_raw(__builtin_fmaf(acc[x][4 * q + e], os, bq[e]));
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(v[e] > 0.f);
+            const unsigned lo = (unsigned)mask, hi = (unsigned)(mask >> 32);
+            const unsigned below = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+            const global_bytes_rw at = uniform_global_rw(save + run);
+            asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dword %1, %2, %3 nt\n\ts_mov_b64 exec, -1"
+                         :: "s"(mask), "v"(below * 4u), "v"(v[e]), "s"(at) : "memory");
+            run += 4u * (unsigned)__builtin_popcountll(mask);
+            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(words[(2 * b) >> 6]) : "s"(lo), "n"((2 * b) & 63));
+            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(words[(2 * b + 1) >> 6]) : "s"(hi), "n"((2 * b + 1) & 63));
+        } else if constexpr (SUB == 5) {
+            am = max3(am, v[0], v[1]);
+            am = max3(am, v[2], v[3]);
+        } else if constexpr (SUB == 6) {
+            hp = pack_f16_scaled(v[0], v[1], s_next);
+        } else if constexpr (SUB == 7) {
+            oh[sl][c0] = hp;
+            ol[sl][c0] = pack_f16(residual_f16<0>(v[0], s_next, hp), residual_f16<1>(v[1], s_next, hp));
+        } else if constexpr (SUB == 8) {
+            hp = pack_f16_scaled(v[2], v[3], s_next);
+        } else if constexpr (SUB == 9) {
+            oh[sl][c0 + 1] = hp;
+            ol[sl][c0 + 1] = pack_f16(residual_f16<0>(v[2], s_next, hp), residual_f16<1>(v[3], s_next, hp));
+        }
+    }
+};
+#endif
+
 // ---- kind 0: today's residency (mlp_h3.h, mlp_fwd_h3_kernel.h's epilogue) ----------------------------------------------
 constexpr unsigned kLds32 = h3::kStreamLds + kSections * 256 * 4;
 
-template <bool TRAIN>
+template <bool TRAIN, class EPI = h3f::FwdEpi<TRAIN, 0>>
 __global__ __launch_bounds__(kThreads, 1) void chain32_kernel(const short* __restrict__ wstream, const float* __restrict__ bias,
                                                               const float* __restrict__ sc, float* __restrict__ save_arg,
                                                               unsigned* __restrict__ out, long P) {
@@ -237,7 +295,7 @@ __global__ __launch_bounds__(kThreads, 1) void chain32_kernel(const short* __res
     auto section = [&](int sect) { return uniform_global_rw(save + (long)sect * 256 * Ppad + wave_tile * (32L * 256)); };
     auto scale_of = [&](int layer, int what) { return sc[layer * kScaleStride + what]; };
     auto amax_of = [&](float a) { return fmaxf(a, shfl_xor(a, 32)); };
-    using Relu = h3f::FwdEpi<TRAIN, 0>;
+    using Relu = EPI;
     auto make_relu = [&](int l, float s_in) {
         Relu e;
         e.os = inv_pow2(s_in) * scale_of(l, kSwInv);
@@ -336,6 +394,9 @@ extern "C" int residency_lab_run(int kind, const void* wstream, const void* bias
         case 1: return launch_timed(chain16_kernel<true>, kLdsP, scn::h3p::kThreadsP, ws, b, s, sv, o, P, reps, ms);
         case 2: return launch_timed(chain32_kernel<false>, kLds32, scn::mlp::kThreads, ws, b, s, sv, o, P, reps, ms);
         case 3: return launch_timed(chain16_kernel<false>, kLdsP, scn::h3p::kThreadsP, ws, b, s, sv, o, P, reps, ms);
+#ifndef SCNERF_SIMT_EMU_BUILD
+        case 6: return launch_timed(chain32_kernel<true, CompactEpi>, kLds32, scn::mlp::kThreads, ws, b, s, sv, o, P, reps, ms);
+#endif
     }
     return SCN_EINVAL;
 }
