@@ -12,18 +12,16 @@ if ROOT not in sys.path:
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
-def _unpack_shipped_reference():
-    """TEST INFRASTRUCTURE.  The reference tree exists only in the build container.  `tools/ship_reference.sh pack` puts its
-    sources into `.ref_ship.tgz` beside the repository (git-ignored: outside the history), which travels to the GPU box
-    with the snapshot; where /root/reference is absent and the archive present, oracle/ref_ship.py unpacks it into a
-    0700 directory of this checkout and points SCNERF_REFERENCE_ROOT at it, so that the unmodified run_nerf.py can train on
-    the device (tests/test_dropin_run_nerf.py::test_gpu_unmodified_train).  Only tests/dropin_support.py, oracle/ref_import.py
-    and bench.py's cpu_baseline leg read that root."""
+def _locate_reference():
+    """TEST INFRASTRUCTURE.  The reference tree exists only in the build container (or where a maintainer points
+    SCNERF_REFERENCE_ROOT at a checkout): oracle/ref_ship.py finds it for the tests that import the unmodified reference
+    (tests/dropin_support.py, oracle/ref_import.py).  On the GPU box there is none -- nothing of the reference travels --
+    and those tests skip; everything else runs on the committed golden vectors."""
     from oracle import ref_ship
     ref_ship.ensure()
 
 
-_unpack_shipped_reference()
+_locate_reference()
 
 if torch.cuda.is_available():
     # The GPU suite runs serially and most of its wall time is the CPU oracle (torch-CPU at up to 4096 rays): on the GPU box's

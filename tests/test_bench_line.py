@@ -228,3 +228,29 @@ def test_two_ranks_without_a_gpu_fail_through_the_self_launcher():
     assert r.returncode != 0
     line = _error_line(r.stdout)
     assert line["n_gpus"] == 2
+
+
+@pytest.mark.gpu
+def test_gpu_two_rccl_ranks_on_one_device_end_with_a_line_not_a_hang():
+    """First contact with RCCL at N > 1 as far as a one-GPU box allows: `bench.py --gpus 2 --backend nccl --one-device` -- a
+    real rendezvous, a real ncclCommInitRank with world size 2.  RCCL normally refuses two ranks on one device ("Duplicate GPU
+    detected"): then rank 0's error line comes out, status non-zero, in seconds.  (Should a build accept it, the run is a
+    genuine two-rank all-reduce and must produce the normal line.)  What must never happen is a hang up to the driver's limit."""
+    import time
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "nccl", "--one-device",
+                        "--init-timeout", "90", "--steps", "2", "--warmup", "1", "--no-cpu", "--rays", "256"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-1000:], r.stderr[-3000:])
+    line = json.loads(lines[0])
+    assert time.time() - t0 < 600
+    if r.returncode == 0:
+        assert line["n_gpus"] == 2 and line["all_reduce_alone"]["backend"] == "nccl" and line["ranks"]["world_size"] == 2
+    else:
+        assert line["value"] is None and line["error"] and line["n_gpus"] == 2, line
+        assert "init_process_group" in line["stage"] or "collective" in line["stage"] or "warm-up" in line["stage"], line
+    print("\ntwo RCCL ranks on one device:", "ran" if r.returncode == 0 else "refused in stage '%s': %s" % (line["stage"], line["error"][:300]))

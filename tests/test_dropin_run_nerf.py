@@ -215,8 +215,9 @@ def test_gpu_training_loop_through_the_mirrored_api(tmp_path, batching, monkeypa
 @needs_reference
 def test_gpu_unmodified_train(tmp_path, monkeypatch):
     """The UNMODIFIED NeRF/run_nerf.py trains on the MI355X under dropin.install(): five iterations of its own train().
-    Needs the reference's sources beside a GPU: /root/reference, SCNERF_REFERENCE_ROOT, or the archive
-    `tools/ship_reference.sh pack` leaves beside the repository (tests/conftest.py unpacks it on the GPU box)."""
+    Needs the reference's sources beside a GPU (/root/reference or SCNERF_REFERENCE_ROOT: a maintainer's machine) -- the pool's
+    GPU boxes have neither, nothing of the reference travels there, and the test skips; the same train() runs on the CPU
+    interpreter in the build container (test_unmodified_train_on_the_interpreter) and the mirrored loop on the GPU above."""
     mod = S.import_reference_run_nerf()
     argv = _prepare(mod, tmp_path, 5, device="cuda", n_rand=256)
     monkeypatch.setattr(sys, "argv", argv)

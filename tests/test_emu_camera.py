@@ -283,6 +283,9 @@ def test_intrinsic_and_extrinsic_share_one_node_until_its_backward():
         with torch.no_grad():
             cm.intrinsics_noise.copy_(spec["intrinsics_noise"])
             cm.extrinsics_noise.copy_(spec["extrinsics_noise"])
+        # the default is the reference's structure: a graph per getter call
+        assert cm.get_intrinsic().grad_fn is not cm.get_extrinsic().grad_fn
+        cm.share_matrix_node = True                                       # (what dropin.install() and bench.py opt into)
         K, E = cm.get_intrinsic(), cm.get_extrinsic()
         assert K.grad_fn is E.grad_fn and K.grad_fn is not None
         assert cm.get_intrinsic() is K and cm.get_extrinsic() is E

@@ -79,7 +79,11 @@ def test_one_wave_per_simd_kernels_admit_no_guest(tmp_path):
                 # the 256 x 64 pair runs two waves per SIMD (2 x 256 registers after allocation granularity: no room either);
                 # the other shapes run one
                 found[name] = regs
-                assert regs == 512 or regs > 248, (name, regs)
+                granulated = (regs + 7) // 8 * 8           # gfx950 allocates the unified register file in blocks of 8
+                # one wave per SIMD with the whole file, or the pair's two waves with half of it EACH (2 x 256 = 512: full
+                # while both workgroups are resident; a lone workgroup of the pair -- the launch's tail -- leaves 256 free,
+                # beside a kernel the stand-alone reproducer found harmless: profiles/r06_guest_write_lab.txt, mode 2)
+                assert granulated in (256, 512), (name, regs, granulated)
                 continue
     assert len([k for k in found if "h3_kernel" in k]) >= 8 and any("wgrad256_half" in k for k in found), sorted(found)
     short = {k: v for k, v in found.items() if any(f in k for f in full) and v != 512}

@@ -2,7 +2,7 @@
 Process 0 (victim) calls the dump kernel of tools/ubench/camera_bwd_lab.hip (alone: no memsets, no LDS stage, no finish kernel) on
 fixed inputs in a tight loop and compares every dump with the first; process 1 (neighbour) cycles through modes, a few seconds each --
 idle, ATen copies, a bf16 matmul, each of this library's heavy kernels on its own, the whole training step -- and publishes the mode
-in shared memory.  Events are counted per mode.    python tools/flaky_probe6.py [SECONDS_PER_MODE] [ROUNDS]"""
+in shared memory.  Events are counted per mode.    python tools/guest_probe.py [SECONDS_PER_MODE] [ROUNDS]"""
 import ctypes, os, sys, time
 import numpy as np
 import torch
@@ -152,13 +152,13 @@ def run_external(seconds, label):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--external":       # python tools/flaky_probe6.py --external SECONDS LABEL
+    if len(sys.argv) > 1 and sys.argv[1] == "--external":       # python tools/guest_probe.py --external SECONDS LABEL
         run_external(float(sys.argv[2]), sys.argv[3] if len(sys.argv) > 3 else "?")
         sys.exit(0)
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     print("neighbour mode               neighbour's library                victim calls   calls whose per-ray dump moved")
-    if len(sys.argv) > 3:                                       # python tools/flaky_probe6.py 3 1 "resident dgrad,resident fwd" lib1.so lib2.so ...
+    if len(sys.argv) > 3:                                       # python tools/guest_probe.py 3 1 "resident dgrad,resident fwd" lib1.so lib2.so ...
         only = sys.argv[3].split(",")
         for lib in sys.argv[4:] or [None]:
             run(seconds, rounds, None if lib == "product" else lib, only)
