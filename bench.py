@@ -763,7 +763,8 @@ def compact_record(full, detail_path):
         "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic",
         "traffic_over_survey_algorithmic", "avg_launch_ms", "frac_mfma", "frac_hbm", "algorithmic_bytes_per_launch",
         "survey_algorithmic_bytes_per_launch", "flop_per_launch", "step_traffic_bytes", "step_traffic_over_survey_algorithmic",
-        "clock_ghz", "socket_power_w", "power_cap_w", "mfma_busy", "clock_ghz_under_counters", "frac_at_measured_clock")))
+        "clock_ghz", "socket_power_w", "power_cap_w", "mfma_busy", "clock_ghz_under_counters", "frac_at_measured_clock",
+        "traffic_measured_live")))
     line["cpu_baseline"] = rounded(pick(full.get("cpu_baseline"), (
         "value", "unit", "cores", "kind", "sample", "best_ms", "median_ms", "value_median", "os_cpu_count",
         "rays_per_s_1024_rays_anomaly_on_as_shipped")))
@@ -809,6 +810,67 @@ def latest_pmc_traffic():
     return None, None, stale
 
 
+def live_pmc_traffic(dominant_region, rays, steps=3, timeout=150):
+    """HBM traffic measured in THIS run, as MI355X_MICROARCH.md's HBM / rocprofv3 section prescribes: two separate passes of
+    `rocprofv3 --kernel-trace --pmc <ONE counter>` (FETCH_SIZE, WRITE_SIZE; nothing else traced) over `steps` plain steps of
+    the headline workload in a child process (tools/profile_steps.py pmc), bytes = WRITE_SIZE KB x 1024 + 2 x FETCH_SIZE KB x
+    1024 (gfx950 tallies wide coalesced reads at half their size).  -> (dict | None, note): per launch of the dominant kernel
+    and per step (every dispatch of the child / steps: a few MB of set-up kernels are in the sum)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.isfile(exe):
+        return None, "rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from pmc_summary import REGIONS
+    except Exception as e:
+        return None, "tools/pmc_summary.py: %r" % (e,)
+    import re
+    anyp = lambda name: re.sub(r"/P=\d+", "/P=*", name)         # (the table names its regions at the headline's sample counts)
+    patterns = [pat for pat, region in REGIONS.items() if anyp(region) == anyp(dominant_region)]
+    tmp = tempfile.mkdtemp(prefix="scnerf_pmc_", dir="/tmp")
+    total, per_launch = {}, {}
+    t0 = time.perf_counter()
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, c)
+            env = dict(os.environ, TMPDIR="/tmp", PMC_STEPS=str(steps), PMC_RAYS=str(rays))
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k, None)
+            try:
+                r = subprocess.run([exe, "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", d, "-o", c, "--",
+                                    sys.executable, os.path.join(ROOT, "tools", "profile_steps.py"), "pmc"],
+                                   cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=timeout)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 --pmc %s did not finish within %d s" % (c, timeout)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, "rocprofv3 --pmc %s left no counter file (status %d): %s" % (c, r.returncode, (r.stderr or "")[-300:])
+            tot, mine = 0.0, []
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != c:
+                    continue
+                v = float(row["Counter_Value"])
+                tot += v
+                if any(pat in row["Kernel_Name"] for pat in patterns):
+                    mine.append(v)
+            total[c] = tot
+            per_launch[c] = sum(mine) / len(mine) if mine else None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {"bytes_per_step": int((total["WRITE_SIZE"] * 1024 + 2 * total["FETCH_SIZE"] * 1024) / steps),
+           "bytes_per_launch": (int(per_launch["WRITE_SIZE"] * 1024 + 2 * per_launch["FETCH_SIZE"] * 1024)
+                                if per_launch["FETCH_SIZE"] is not None and per_launch["WRITE_SIZE"] is not None else None),
+           "seconds": time.perf_counter() - t0}
+    return out, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two separate passes, one counter "
+                 "each) over %d plain steps of the headline workload in a child process (tools/profile_steps.py pmc); bytes = "
+                 "WRITE_SIZE KB x 1024 + 2 x FETCH_SIZE KB x 1024" % steps)
+
+
 def main():
     # stdout carries exactly ONE line, the JSON record: everything else that writes to file descriptor 1 (RCCL prints a
     # version banner there when its first communicator comes up, progress bars, ...) is sent to stderr
@@ -839,6 +901,9 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0 (functional check, with --backend gloo)")
     ap.add_argument("--telemetry-seconds", type=float, default=1.5,
                     help="N = 1: socket power and shader clock sampled over this many seconds of steps after the timed region (0: off)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="N = 1, --config 1: do not run the two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE; ~40 s) that measure "
+                         "`roofline.traffic` in this run; the newest committed summary at the same kernel sources is quoted instead")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --rays is the TOTAL batch, split evenly over the ranks (SURVEY section 8d, C4's second "
                          "figure); default: weak scaling, --rays per GPU")
@@ -1000,7 +1065,28 @@ def run(a, json_out, guard, rank, world, scale):
             P_dom = int(_re.search(r"/P=(\d+)", dom).group(1))
             roof["survey_algorithmic_bytes_per_launch"] = (4 * pd + 16) * P_dom
             rec, path, stale = latest_pmc_traffic()
-            if rec:
+            live, live_note = (None, "not requested")
+            if world == 1 and cfg == 1 and not a.no_pmc:
+                guard.stage = "rocprofv3 counter passes (HBM traffic of this run)"
+                try:
+                    live, live_note = live_pmc_traffic(dom, n)
+                except Exception as e:                # (never fatal to the line)
+                    live, live_note = None, "failed: %r" % (e,)
+            if live and live.get("bytes_per_launch"):
+                # measured in THIS run; the committed summary stays the source of the matrix-pipe utilisation below
+                roof["traffic"] = live["bytes_per_launch"]
+                roof["traffic_source"] = live_note
+                roof["traffic_over_algorithmic"] = roof["traffic"] / f["algorithmic_bytes_per_launch"]
+                roof["traffic_over_survey_algorithmic"] = roof["traffic"] / roof["survey_algorithmic_bytes_per_launch"]
+                roof["step_traffic_bytes"] = live["bytes_per_step"]
+                roof["step_traffic_over_survey_algorithmic"] = live["bytes_per_step"] / (5000.0 * n)
+                roof["traffic_measured_live"] = True
+                roof["traffic_pass_seconds"] = live["seconds"]
+                if rec and rec.get("bytes_per_launch", {}).get(dom):
+                    roof["traffic_committed_summary"] = rec["bytes_per_launch"][dom]
+            elif rec:
+                roof["traffic_measured_live"] = False
+                roof["traffic_live_note"] = live_note
                 roof["traffic"] = rec.get("bytes_per_launch", {}).get(dom)
                 roof["traffic_source"] = "%s: %s" % (path, rec.get("_source"))
                 if roof["traffic"]:

@@ -206,9 +206,11 @@ __device__ __forceinline__ void wave_lds_handoff() { __builtin_amdgcn_wave_barri
 // clobbers make v255 and a255 part of the kernel's allocation.  For the kernels built around ONE wave per SIMD on the fp16 matrix
 // pipe (csrc/mlp_h3.h, wgrad256_half.h, wgrad_half_narrow.h): with 425 .. 444 registers they left room for a 64-register wave of
 // ANOTHER kernel on their SIMD -- never this library's own (one stream), but a second process's or another stream's -- and such a
-// guest lost writes to lanes 48..63 of a register while the host wave ran its MFMA chain (tools/flaky_probe5.py, flaky_probe6.py,
+// guest lost writes to lanes 48..63 of a register while the host wave ran its MFMA chain (tools/guest_probe.py,
 // profiles/r05_two_process_probe.txt: the camera backward kernel beside the data-gradient kernel, 7 % of its launches).  A full
-// allocation admits no guest; for a kernel that runs one wave per SIMD anyway it costs nothing.
+// allocation admits no guest; for a kernel that runs one wave per SIMD anyway it costs nothing.  A MITIGATION, not a root cause: a
+// synthetic host of the same shape does not reproduce the loss (tools/ubench/guest_write_lab.hip, profiles/r06_guest_write_lab.txt:
+// 0 of ~112 000 guest launches), so what in these kernels' instruction streams does it is open.
 __device__ __forceinline__ void claim_whole_register_file() { asm volatile("" ::: "v255", "a255"); }
 
 // Compiler-only fence: instructions are not moved across it by the machine scheduler (used to keep

@@ -468,7 +468,21 @@ def test_resident_layers_are_fp32_grade(ops, kind):
             continue
         assert r["resident"]["rms"] <= 2.0 * r["fp32"]["rms"] and r["resident"]["max"] <= 3.0 * r["fp32"]["max"] + 1e-9, (layer, r)
         assert r["resident"]["max"] < 1e-6, (layer, r)
-    assert report["raw_vs_fused_fp32_relative_max"] <= 2e-5, report
+    if kind == "adversarial":
+        # an ill-conditioned network by construction: two correct fp32 evaluations of it differ by more than 2e-5 at the
+        # output -- judged against fp64 instead (the oracle in double precision on a slice of the samples): the resident
+        # arithmetic may be no further from it than the fused fp32 kernels are
+        n_sub = 256
+        p64 = {k: v.double() for k, v in p.items()}
+        ref64 = O.query_network(p64, pts_host[: n_sub * spr].double().reshape(n_sub, spr, 3), vd[:n_sub].cpu().double()).reshape(-1, 4)
+        size = ref64.abs().max(1)[0].clamp_min(1.0)
+        e32 = float(((raw32[: n_sub * spr].cpu().double() - ref64).abs().max(1)[0] / size).max())
+        e16 = float(((raw16[: n_sub * spr].cpu().double() - ref64).abs().max(1)[0] / size).max())
+        report["raw_vs_fp64_relative_max"] = {"fp32": e32, "resident": e16}
+        PA.REPORT["resident_layer_arithmetic_131072_samples_error_over_sum_abs_products_vs_fp64" + suffix] = report
+        assert e16 <= 3.0 * e32 + 1e-6, report["raw_vs_fp64_relative_max"]
+    else:
+        assert report["raw_vs_fused_fp32_relative_max"] <= 2e-5, report
 
 
 @pytest.mark.parametrize("kind", ["xavier", "trained", "adversarial"])
@@ -503,6 +517,42 @@ def test_resident_data_gradients_follow_the_fused_chain_row_by_row(ops, kind):
     def rows(gr, name, width):
         return gr[goff[name]: goff[name] + width * Pp].view(Pp // 32, width // 32, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(Pp, width)[:P]
     zero = (d_raw.abs().sum(1) == 0)
+    if kind == "adversarial":
+        # The hand-made layers make the CHAIN ill-conditioned (pts_linears.3's +c / -c row meets pts_linears.2's identical row
+        # pairs: terms 2^10 larger than their sum cancel in W_2^T dZ_2), so two correct fp32 evaluations differ from each other
+        # by more than 2e-5 of a row.  The yardstick is fp64 instead: the same chain, on the same saved gates, in double
+        # precision (torch on the device) -- the resident chain may be no further from it than the fused fp32 chain is.
+        off, _ = ML.section_offsets(lay.save_sections, P)
+
+        def srows(name, width=256):
+            return save[off[name]: off[name] + width * Pp].view(Pp // 32, width // 32, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(Pp, width)[:P]
+        W = lambda name: dev(p[name]).double()
+        dr = d_raw.double()
+        ref = {}
+        ref["dzv"] = (dr[:, :3] @ W("rgb_linear.weight")) * (srows("hv", 128) > 0)
+        ref["dfeat"] = (ref["dzv"] @ W("views_linears.0.weight"))[:, :256]
+        d = (ref["dfeat"] @ W("feature_linear.weight") + dr[:, 3:4] * W("alpha_linear.weight")) * (srows("act7") > 0)
+        ref["dz7"] = d
+        for l in range(7, 0, -1):
+            w_l = W("pts_linears.%d.weight" % l)
+            if l == 5:
+                w_l = w_l[:, lay.in_pts:]                       # (the skip layer's activation columns)
+            d = (d @ w_l) * (srows("act%d" % (l - 1)) > 0)
+            ref["dz%d" % (l - 1)] = d
+        rep = {}
+        for name, width in ML.GRAD_SECTIONS:
+            a, b = rows(ga, name, width).double(), rows(gb, name, width).double()
+            assert bool(torch.isfinite(b).all()), name
+            size = ref[name].abs().max(1)[0].clamp_min(1e-300)
+            ea, eb = ((a - ref[name]).abs().max(1)[0] / size)[~zero], ((b - ref[name]).abs().max(1)[0] / size)[~zero]
+            rep[name] = {"fp32_max": float(ea.max()), "resident_max": float(eb.max()),
+                         "fp32_q999": float(torch.quantile(ea[:1 << 20], 0.999)), "resident_q999": float(torch.quantile(eb[:1 << 20], 0.999))}
+            assert rep[name]["resident_max"] <= 3.0 * rep[name]["fp32_max"] + 1e-7, (name, rep[name])
+            assert rep[name]["resident_q999"] <= 2.0 * rep[name]["fp32_q999"] + 1e-7, (name, rep[name])
+            assert bool((b[zero] == 0).all()), name
+        from tests import parity_attribution as PA
+        PA.REPORT["resident_data_gradient_chain_adversarial_weights_row_error_vs_fp64"] = rep
+        return
     for name, width in ML.GRAD_SECTIONS:
         a, b = rows(ga, name, width).double(), rows(gb, name, width).double()
         assert bool(torch.isfinite(b).all()), name

@@ -11,7 +11,7 @@ from scnerf_amd.parallel import FlatGradAllReduce                               
 from torch.profiler import profile, ProfilerActivity                           # noqa: E402
 
 dev = torch.device("cuda:0")
-w = bench.build_world(dev, 0, 4096)
+w = bench.build_world(dev, 0, int(os.environ.get("PMC_RAYS", "4096")))
 if len(sys.argv) > 1 and sys.argv[1] == "camera":
     for name in ("intrinsics_noise", "extrinsics_noise", "ray_o_noise", "ray_d_noise"):
         getattr(w["cam"], name).requires_grad_(True)

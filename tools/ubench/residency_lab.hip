@@ -216,13 +216,15 @@ struct CompactEpi {
     float v[4];
     unsigned hp;
 
+    // (an epilogue that only ever runs its pending pair -- the "layer" in front of the chain -- starts here too)
+    __device__ __forceinline__ void prime() { run = 0u; words[0] = words[1] = words[2] = words[3] = 0u; }
+
     template <int P, int PIECE, int SUB, int NS>
     __device__ __forceinline__ void sub(f32x16 (&acc)[2], h3::u32x4 (&oh)[NS], h3::u32x4 (&ol)[NS]) {
         constexpr int x = PIECE >> 2, q = PIECE & 3, T = 2 * P + x;
         constexpr int sl = 2 * T + (q >> 1), c0 = 2 * (q & 1);
         if constexpr (SUB == 0) {
             bq = *reinterpret_cast<const f32x4*>(bias + (4 * T + q) * 8);
-            if constexpr (P == 0 && PIECE == 0) { run = 0u; words[0] = words[1] = words[2] = words[3] = 0u; }
         } else if constexpr (SUB <= 4) {
             constexpr int e = SUB - 1;
             constexpr int b = (4 * T + q) * 4 + e;               // ballot index within the layer: 0 .. 127
@@ -304,6 +306,7 @@ __global__ __launch_bounds__(kThreads, 1) void chain32_kernel(const short* __res
         e.bias = tables + 256 * l + 4 * h;
         e.save = TRAIN ? section(l) : nullptr;
         e.lane16 = w.lane16;
+        e.prime();
         return e;
     };
     auto store_mask = [&](Relu& epi, int sect) {
