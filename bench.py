@@ -457,7 +457,7 @@ def fixed_camera_step(w, reducer):
 PRD_WEIGHT = 1e-4          # args.ray_dist_loss_weight of the reference's demo configuration
 
 
-def learnable_camera_step(w, reducer, prd=False):
+def learnable_camera_step(w, reducer, prd=False, prd_sync=False):
     """configs[2] (and with `prd` configs[3]): key-point rays through the learnable camera model, NDC through its
     intrinsics, render fwd + bwd down to the camera parameters, + the projected-ray-distance term of one image pair
     (+ the all-reduce over networks AND camera)"""
@@ -487,9 +487,11 @@ def learnable_camera_step(w, reducer, prd=False):
             k0, k1, i0, i1 = w["matches"]
             r0 = get_rays_kps_use_camera(H=IMG_H, W=IMG_W, camera_model=w["cam"], idx_in_camera_param=i0, kps_list=k0)
             r1 = get_rays_kps_use_camera(H=IMG_H, W=IMG_W, camera_model=w["cam"], idx_in_camera_param=i1, kps_list=k1)
+            # (the match count stays on the device: the reference's python float is a host sync in the middle of the step, and
+            #  its caller only logs it -- ray_dist_loss.py `_sync`; profiles/r06_bench_n1_config3*.json carry both)
             loss, _ = proj_ray_dist_loss_single(kps0_list=k0, kps1_list=k1, img_idx0=i0, img_idx1=i1, rays0=r0, rays1=r1,
                                                 mode="train", device=k0.device, H=IMG_H, W=IMG_W, args=prd_args,
-                                                camera_model=w["cam"], method="NeRF", i_map=i_map)
+                                                camera_model=w["cam"], method="NeRF", i_map=i_map, _sync=prd_sync)
             outs.append(loss)
             grads.append(one * PRD_WEIGHT)
         torch.autograd.backward(outs, grads)
@@ -904,6 +906,9 @@ def main():
     ap.add_argument("--no-pmc", action="store_true",
                     help="N = 1, --config 1: do not run the two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE; ~40 s) that measure "
                          "`roofline.traffic` in this run; the newest committed summary at the same kernel sources is quoted instead")
+    ap.add_argument("--prd-sync", action="store_true",
+                    help="--config 3: proj_ray_dist_loss_single returns the match count as a python float, as the reference does "
+                         "(a host sync per step); default: it stays on the device")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --rays is the TOTAL batch, split evenly over the ranks (SURVEY section 8d, C4's second "
                          "figure); default: weak scaling, --rays per GPU")
@@ -976,7 +981,7 @@ def run(a, json_out, guard, rank, world, scale):
             step = fixed_camera_step(w, reducer)
         else:
             reducer = FlatGradAllReduce([w["net_c"], w["net_f"], w["cam"]], world)
-            step = learnable_camera_step(w, reducer, prd=(cfg == 3))
+            step = learnable_camera_step(w, reducer, prd=(cfg == 3), prd_sync=a.prd_sync)
 
     def sync():
         if world > 1:
@@ -1117,7 +1122,8 @@ def run(a, json_out, guard, rank, world, scale):
                "%dx%d: intrinsics, extrinsics, ray-o / ray-d noise), fwd+bwd down to the camera parameters" % (n, N_CAMS, IMG_H, IMG_W),
             3: "configs[3]: %d rays x (64 + 128) per GPU, coarse+fine NeRF, rays from the learnable camera model (%d views, "
                "%dx%d) + the projected-ray-distance loss of one image pair (1024 matches) in every step, fwd+bwd down to the "
-               "camera parameters" % (n, N_CAMS, IMG_H, IMG_W),
+               "camera parameters; match count %s" % (n, N_CAMS, IMG_H, IMG_W, "read on the host per step as the reference does"
+                                                      if a.prd_sync else "left on the device"),
             4: "configs[4]: NeRF++ step, %d rays per GPU, two cascade levels (64, then 64+128 samples) x (foreground + "
                "background network), fwd+bwd" % n}[cfg]
         collective = ("no collective at N = 1" if world == 1 else

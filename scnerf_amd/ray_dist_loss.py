@@ -45,12 +45,17 @@ class _PrdLossFunction(torch.autograd.Function):
 
 def proj_ray_dist_loss_single(kps0_list, kps1_list, img_idx0, img_idx1, rays0, rays1, mode, device, H, W, args,
                               camera_model=None, intrinsic=None, extrinsic=None, eps=1e-10, i_map=None,
-                              method="NeRF"):
+                              method="NeRF", _sync=True):
     """(model/ray_dist_loss.py:22-246)  kps*_list [M,2] matched key points of images img_idx0 / img_idx1,
     rays0 / rays1 = (rays_o, rays_d) [M,3] of those key points.  Parameter sources per mode as the
     reference: train + camera_model -> its current K and the two poses looked up through `i_map`
     (:51-64); train without -> the given (noisy) intrinsic / extrinsic (:66-75); val / test -> the
-    ground-truth extrinsic, K from the camera model if there is one (:77-95)."""
+    ground-truth extrinsic, K from the camera model if there is one (:77-95).
+
+    `_sync` (not in the reference): the reference returns the match count as a python float (:223-227) -- a host read of a device
+    scalar in the middle of the step, behind which the GPU idles until the backward pass has been launched (~1 ms of a 12 ms step).
+    run_nerf.py only logs the number.  `_sync=False` returns it as a 0-dim device tensor instead, for loops that do not want the
+    stall (bench.py --config 3); the default keeps the reference's return type."""
     assert mode in ["train", "val", "test"]
     assert method in ["NeRF", "NeRF++"]
     # (:47-50) `kps*_list[:, 0].max() < W`, `[:, 1].max() < H`: four host reads of device scalars in the reference; here
@@ -83,7 +88,7 @@ def proj_ray_dist_loss_single(kps0_list, kps1_list, img_idx0, img_idx1, rays0, r
     if mode == "train":
         loss, n_match = _PrdLossFunction.apply(kps0, kps1, rays0[0], rays0[1], rays1[0], rays1[1], K, E2,
                                                float(eps), threshold, negate_fx)
-        return loss, n_match.item()          # the reference returns a python float too (:226-229)
+        return loss, (n_match.item() if _sync else n_match)      # the reference returns a python float (:226-229)
     with torch.no_grad():
         tens = [t.contiguous().float() for t in (kps0, kps1, rays0[0], rays0[1], rays1[0], rays1[1], K, E2)]
         loss, _, _ = ops.prd_loss_fwd(*tens, float(eps), threshold, negate_fx, True)
