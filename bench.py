@@ -859,9 +859,12 @@ def live_pmc_traffic(dominant_region, rays, steps=3, timeout=150):
                 v = float(row["Counter_Value"])
                 tot += v
                 if any(pat in row["Kernel_Name"] for pat in patterns):
-                    mine.append(v)
+                    mine.append((int(row.get("Grid_Size") or 0), v))
             total[c] = tot
-            per_launch[c] = sum(mine) / len(mine) if mine else None
+            # (a kernel that serves both passes under one name -- the data-gradient kernel -- is launched at two sizes per step:
+            #  the dominant REGION is the larger one, the fine pass)
+            big = [v for g, v in mine if g == max(g_ for g_, _ in mine)] if mine else []
+            per_launch[c] = sum(big) / len(big) if big else None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     out = {"bytes_per_step": int((total["WRITE_SIZE"] * 1024 + 2 * total["FETCH_SIZE"] * 1024) / steps),
@@ -1029,9 +1032,19 @@ def run(a, json_out, guard, rank, world, scale):
     ms_off = (time.perf_counter() - t0) / a.steps * 1e3
     # clock / power: the samples taken during the timed steps when there are enough of them (>= 4: ~40 ms of steps), else
     # a loop of its own after the timed region (labelled as such)
-    telemetry = in_loop
-    if telemetry is None and rank == 0 and world == 1 and a.telemetry_seconds > 0:
+    telemetry = None
+    if rank == 0 and world == 1 and a.telemetry_seconds > 0:
+        # socket power: amdgpu's power1_input is a moving average over about a second -- 0.24 s of timed steps only see it
+        # ramp --, so it is read over a loop of its own; the shader clock responds at once and is the timed steps' own
         telemetry = Telemetry(dev).sample_while(step, a.telemetry_seconds)
+        if telemetry and in_loop:
+            telemetry["clock_ghz_after_the_timed_steps"] = telemetry["clock_ghz"]
+            telemetry["clock_ghz"] = in_loop["clock_ghz"]
+            telemetry["source"] = ("amdgpu hwmon: freq1_input (sclk) = median of %d samples taken every 10 ms DURING the timed steps; "
+                                   "power1_input (a ~1 s moving average) over %.1f s of back-to-back steps after them"
+                                   % (in_loop["samples"], a.telemetry_seconds))
+    elif in_loop:
+        telemetry = in_loop
 
     if rank == 0:
         kern = ops.PROFILE.summary()

@@ -68,7 +68,10 @@ def proj_ray_dist_loss_single(kps0_list, kps1_list, img_idx0, img_idx1, rays0, r
         intrinsic = camera_model.get_intrinsic()
         c0 = int(np.where(np.asarray(i_map) == img_idx0)[0][0])
         c1 = int(np.where(np.asarray(i_map) == img_idx1)[0][0])
-        extrinsic = camera_model.get_extrinsic()[[c0, c1]]
+        # (two views + one stack: indexing with the python list [c0, c1] builds an index tensor on the host and copies it
+        #  over -- from pageable memory that copy waits for everything queued on the stream, a host sync in the middle of the step)
+        E = camera_model.get_extrinsic()
+        extrinsic = torch.stack([E[c0], E[c1]])
     else:
         assert extrinsic is not None
         if camera_model is not None:
@@ -77,7 +80,8 @@ def proj_ray_dist_loss_single(kps0_list, kps1_list, img_idx0, img_idx1, rays0, r
         assert intrinsic is not None
         if mode == "train":
             assert isinstance(intrinsic, torch.Tensor) and isinstance(extrinsic, torch.Tensor)
-        extrinsic = torch.as_tensor(extrinsic)[[img_idx0, img_idx1]]
+        extrinsic = torch.as_tensor(extrinsic)
+        extrinsic = torch.stack([extrinsic[img_idx0], extrinsic[img_idx1]])
     dev = rays0[0].device
     K = torch.as_tensor(intrinsic).to(dev)
     E2 = extrinsic.to(dev)

@@ -74,7 +74,8 @@ def test_training_call_chain_through_camera_model(M):
     # `_sync=False`: the same call without the host read -- the count comes back as a 0-dim device tensor, the loss is the same
     loss2, nm2 = R.proj_ray_dist_loss_single(k0, k1, int(i_map[i0]), int(i_map[i1]), r0, r1, "train", "cuda", HH, WW,
                                              args, camera_model=cm, method="NeRF", i_map=i_map, _sync=False)
-    assert torch.is_tensor(nm2) and nm2.is_cuda and nm2.dim() == 0 and float(nm2) == nm and torch.equal(loss2.detach(), loss.detach())
+    assert torch.is_tensor(nm2) and nm2.is_cuda and nm2.dim() == 0 and float(nm2) == nm
+    assert abs(float(loss2) - float(loss)) <= 1e-6 * abs(float(loss))           # (masked means summed with atomics: last-bit order effects)
     loss.backward()
     for name in ("intrinsics_noise", "extrinsics_noise", "ray_o_noise", "ray_d_noise"):
         got = getattr(cm, name).grad.cpu().numpy()
