@@ -125,8 +125,17 @@ class _NerfNetFunction(torch.autograd.Function):
                                               _p(d_views_b), _p(d_norm), _p(d_z), _p(g_o), _p(g_d), _p(g_z), n, sf, sb,
                                               _stream()), "scnerf_npp_points_bwd")
         ctx.state = None
+        n_fg = len(list(fg_net.parameters()))
+        need = ctx.needs_input_grad[8:]
 
-        def per_param(net, flat, pd):
+        def per_param(net, flat, pd, wanted):
+            # networks whose .grad tensors are views of one flat buffer (FusedAdam / FlatGradAllReduce) take the whole flat
+            # gradient with ONE scatter-add (every target index occurs once: deterministic) -- returned tensor by tensor,
+            # autograd accumulates them with 24 tiny launches per network and level
+            into = net.attached_flat_grad() if all(wanted) else None
+            if into is not None:
+                into.index_add_(0, net.canonical_to_module_index(flat.device), flat)
+                return [None] * len(wanted)
             lay = ML.layout(pd)
             by_canon = {name: flat[lay.param_offsets[name]: lay.param_offsets[name] + int(torch.Size(shape).numel())].view(shape)
                         for name, shape in lay.param_shapes}
@@ -135,7 +144,7 @@ class _NerfNetFunction(torch.autograd.Function):
             return [by_module[name] for name, _ in net.named_parameters()]
 
         return (g_o.view(o_shape), g_d.view(o_shape), d_zmax.view(zmax_shape), g_z.view(fgz_shape), None, None, None, None,
-                *per_param(fg_net, flat_gf, 3), *per_param(bg_net, flat_gb, 4))
+                *per_param(fg_net, flat_gf, 3, need[:n_fg]), *per_param(bg_net, flat_gb, 4, need[n_fg:]))
 
 
 class NerfNet(nn.Module):

@@ -129,6 +129,33 @@ class MLPNet(nn.Module):
             self._remap = ("npp%d" % self.pt_dims, table)
         return self._remap
 
+    def attached_flat_grad(self) -> Optional[torch.Tensor]:
+        """The flat gradient buffer when every parameter's .grad is a view of ONE contiguous fp32 buffer in registration
+        order (FusedAdam / FlatGradAllReduce attach them so), else None: NerfNet's backward then adds the weight gradients
+        into it with one launch per network instead of returning 24 tensors each for autograd to accumulate one by one
+        (as run_nerf_helpers.NeRF.attached_flat_grad)."""
+        from .. import _capi
+        params = [p for _, p in self.named_parameters()]
+        g0 = params[0].grad
+        if g0 is None or g0.dtype != torch.float32 or not _capi.on_device(g0):
+            return None
+        base, off = g0.data_ptr(), 0
+        for p in params:
+            g = p.grad
+            if g is None or not p.requires_grad or g.dtype != torch.float32 or not g.is_contiguous() \
+                    or g.data_ptr() != base + 4 * off:
+                return None
+            off += p.numel()
+        return torch.as_strided(g0, (off,), (1,))
+
+    def canonical_to_module_index(self, device) -> torch.Tensor:
+        """int64 [n_params] on `device`: where entry i of the kernels' flat gradient (mlp_layout order) lives in this
+        module's flat buffer (pack_remap's table)."""
+        key = str(device)
+        if getattr(self, "_remap_dev", None) is None or self._remap_dev[0] != key:
+            self._remap_dev = (key, torch.from_numpy(self.pack_remap()[1]).to(device))
+        return self._remap_dev[1]
+
     def canonical_parameters(self):
         """the parameters in mlp_layout order (what the wgrad kernels' flat gradient is split into)"""
         sd = dict(self.named_parameters())

@@ -321,6 +321,44 @@ def test_two_level_cascade_training_step_vs_reference():
         check_fingerprints("step/gproj1/", nets[1], rtol=0.15)
 
 
+def test_nerfnet_weight_gradients_accumulate_into_attached_flat_buffers():
+    """With every .grad a view of one flat buffer (FusedAdam / FlatGradAllReduce attach them so) NerfNet's backward adds each
+    network's flat gradient with ONE scatter-add instead of returning 24 tensors for autograd to accumulate: the result is
+    bit for bit the ordinary accumulation, also over two backward passes and into a pre-filled buffer."""
+    from scnerf_amd.nerfplusplus import ddp_train_nerf as TR
+    from scnerf_amd.parallel import FlatGradAllReduce
+    g = torch.Generator().manual_seed(15)
+    n, s = 96, 64
+    o, d, _ = (t_.cuda() for t_ in synth.nerfpp_rays(n, seed=16))          # (origins inside the unit sphere)
+    frac = torch.sort(torch.rand(n, s, generator=g), -1)[0].cuda()
+    bg_z = torch.sort(torch.rand(n, s, generator=g), -1)[0].cuda()
+    target = torch.rand(n, 3, generator=g).cuda()
+
+    def run(net, times):
+        for _ in range(times):
+            far = TR.intersect_sphere(o, d)
+            ret = net(o, d, far, 1e-4 + frac * (far - 1e-4)[:, None], bg_z)
+            (((ret["rgb"] - target) ** 2).mean() + 0.1 * ret["bg_depth"].mean()).backward()
+
+    plain, attached = make_net(781), make_net(781)
+    run(plain, 2)
+    red = FlatGradAllReduce([attached], 1)
+    red.flat.fill_(0.5)
+    assert attached.fg_net.attached_flat_grad() is not None and attached.bg_net.attached_flat_grad() is not None
+    run(attached, 2)
+    for (name, a), (_, b) in zip(plain.named_parameters(), attached.named_parameters()):
+        # (0.5 + g1) + g2 against 0.5 + (g1 + g2): one rounding apart at most
+        np.testing.assert_allclose(b.grad.cpu().numpy(), 0.5 + a.grad.cpu().numpy(), rtol=0, atol=2e-7 * (1.0 + float(a.grad.abs().max())), err_msg=name)
+        assert b.grad.data_ptr() >= red.flat.data_ptr() and b.grad.data_ptr() < red.flat.data_ptr() + 4 * red.flat.numel()
+    # one pass into a zeroed buffer: exactly the plain gradient
+    plain2, attached2 = make_net(782), make_net(782)
+    run(plain2, 1)
+    red2 = FlatGradAllReduce([attached2], 1)
+    run(attached2, 1)
+    for (name, a), (_, b) in zip(plain2.named_parameters(), attached2.named_parameters()):
+        assert torch.equal(a.grad, b.grad), name
+
+
 def _find_npp_node(t):
     node, todo, seen = None, [t.grad_fn], set()
     while todo and node is None:

@@ -19,8 +19,15 @@ def main():
     ap.add_argument("--prd-sync", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    w = bench.build_world(dev, 0, 4096)
-    if a.config == 1:
+    if a.config == 4:
+        from tools import bench_nerfpp
+        step, _, _ = bench_nerfpp.build(2048, device=dev)
+        w = None
+    else:
+        w = bench.build_world(dev, 0, 4096)
+    if a.config == 4:
+        pass
+    elif a.config == 1:
         red = FlatGradAllReduce([w["net_c"], w["net_f"]], 1)
         step = bench.fixed_camera_step(w, red)
     else:
