@@ -1102,7 +1102,7 @@ def run(a, json_out, guard, rank, world, scale):
                 roof["traffic_pass_seconds"] = live["seconds"]
                 if rec and rec.get("bytes_per_launch", {}).get(dom):
                     roof["traffic_committed_summary"] = rec["bytes_per_launch"][dom]
-            elif rec:
+            elif rec and cfg == 1 and n == 4096:        # (the committed summary was taken on the headline workload: quoted for it alone)
                 roof["traffic_measured_live"] = False
                 roof["traffic_live_note"] = live_note
                 roof["traffic"] = rec.get("bytes_per_launch", {}).get(dom)
@@ -1114,10 +1114,10 @@ def run(a, json_out, guard, rank, world, scale):
                     roof["step_traffic_bytes"] = rec["bytes_per_step"]
                     roof["step_traffic_over_survey_algorithmic"] = rec["bytes_per_step"] / (5000.0 * n)
             else:
-                roof["traffic_source"] = stale or "no profiles/pmc_traffic_r*.json"
+                roof["traffic_source"] = live_note if (cfg != 1 or n != 4096 or world > 1) else (stale or "no profiles/pmc_traffic_r*.json")
             # the power-capped ceiling: the chip's 16-bit MFMA peak is quoted at 2.4 GHz; under these kernels the socket sits at
             # its power cap and clocks lower, so the same kernel is also priced against the peak AT THE CLOCK IT RAN AT
-            if rec and rec.get("mfma_busy", {}).get(dom) is not None:
+            if rec and cfg == 1 and n == 4096 and rec.get("mfma_busy", {}).get(dom) is not None:
                 roof["mfma_busy"] = rec["mfma_busy"][dom]
                 roof["clock_ghz_under_counters"] = rec.get("clock_ghz", {}).get(dom)
             if telemetry:
