@@ -18,7 +18,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LAYERS, W, SECTIONS = 8, 256, 9
-KINDS = {"h3": 0, "h3p": 1, "h3-infer": 2, "h3p-infer": 3, "lds": 4, "lds-infer": 5, "h3-compact": 6}
+KINDS = {"h3": 0, "h3p": 1, "h3-infer": 2, "h3p-infer": 3, "lds": 4, "lds-infer": 5, "h3-compact": 6, "h3-st-default": 7, "h3-st-nt": 8, "h3-st-sc0sc1nt": 9, "h3-st-sc1": 10, "h3-st-sc0sc1": 11}
 
 
 def lab_input(p, f):

@@ -256,6 +256,33 @@ struct CompactEpi {
 };
 #endif
 
+
+// ---- kinds 7 .. 11: today's residency with the activation stores under another cache policy (round 6: do the 8 GB of stores of a
+// training forward cost less energy -- the launch is power-bound -- when they by-pass / write through some level?).  The product
+// stores with `nt` (__builtin_nontemporal_store); gfx950's store modifiers are sc0, sc1 (scope) and nt.
+#ifndef SCNERF_SIMT_EMU_BUILD
+template <int POLICY>
+struct PolicyEpi : h3f::FwdEpi<true, 0> {
+    using Base = h3f::FwdEpi<true, 0>;
+    template <int P, int PIECE, int SUB, int NS>
+    __device__ __forceinline__ void sub(f32x16 (&acc)[2], h3::u32x4 (&oh)[NS], h3::u32x4 (&ol)[NS]) {
+        if constexpr (SUB == 10) {
+            constexpr int q = PIECE & 3, T = 2 * P + (PIECE >> 2);
+            const global_bytes_rw at = uniform_global_rw(this->save + (4 * T + q) * 1024);
+            const f32x4 val = {this->v[0], this->v[1], this->v[2], this->v[3]};
+            const unsigned off = pinned_here(this->lane16);
+            if constexpr (POLICY == 0) asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(off), "v"(val), "s"(at) : "memory");
+            else if constexpr (POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, %2 nt" :: "v"(off), "v"(val), "s"(at) : "memory");
+            else if constexpr (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1 nt" :: "v"(off), "v"(val), "s"(at) : "memory");
+            else if constexpr (POLICY == 3) asm volatile("global_store_dwordx4 %0, %1, %2 sc1" :: "v"(off), "v"(val), "s"(at) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" :: "v"(off), "v"(val), "s"(at) : "memory");
+        } else {
+            Base::template sub<P, PIECE, SUB, NS>(acc, oh, ol);
+        }
+    }
+};
+#endif
+
 // ---- kind 0: today's residency (mlp_h3.h, mlp_fwd_h3_kernel.h's epilogue) ----------------------------------------------
 constexpr unsigned kLds32 = h3::kStreamLds + kSections * 256 * 4;
 
@@ -399,6 +426,11 @@ extern "C" int residency_lab_run(int kind, const void* wstream, const void* bias
         case 3: return launch_timed(chain16_kernel<false>, kLdsP, scn::h3p::kThreadsP, ws, b, s, sv, o, P, reps, ms);
 #ifndef SCNERF_SIMT_EMU_BUILD
         case 6: return launch_timed(chain32_kernel<true, CompactEpi>, kLds32, scn::mlp::kThreads, ws, b, s, sv, o, P, reps, ms);
+        case 7: return launch_timed(chain32_kernel<true, PolicyEpi<0>>, kLds32, scn::mlp::kThreads, ws, b, s, sv, o, P, reps, ms);
+        case 8: return launch_timed(chain32_kernel<true, PolicyEpi<1>>, kLds32, scn::mlp::kThreads, ws, b, s, sv, o, P, reps, ms);
+        case 9: return launch_timed(chain32_kernel<true, PolicyEpi<2>>, kLds32, scn::mlp::kThreads, ws, b, s, sv, o, P, reps, ms);
+        case 10: return launch_timed(chain32_kernel<true, PolicyEpi<3>>, kLds32, scn::mlp::kThreads, ws, b, s, sv, o, P, reps, ms);
+        case 11: return launch_timed(chain32_kernel<true, PolicyEpi<4>>, kLds32, scn::mlp::kThreads, ws, b, s, sv, o, P, reps, ms);
 #endif
     }
     return SCN_EINVAL;
