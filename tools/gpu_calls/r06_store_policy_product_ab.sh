@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of the activation stores' cache policy in the PRODUCT: lib_scnerf_store_nt.so (nt, round 5) vs libscnerf_hip.so (sc0 sc1 nt)
+# A/B of the activation stores' cache policy in the PRODUCT: lib_scnerf_store_nt.so (a copy of the product build: nt) vs a build whose store_stream_at emits `sc0 sc1 nt` (reverted since)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r06m; mkdir -p $O
 for rep in 1 2 3; do
