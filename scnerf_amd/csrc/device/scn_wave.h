@@ -164,6 +164,19 @@ template <typename V>
 __device__ __forceinline__ void store_stream_at(global_bytes_rw base, unsigned lane_off, V v) {
     __builtin_nontemporal_store(v, reinterpret_cast<__attribute__((address_space(1))) V*>(base + lane_off));
 }
+// The activation / gradient workspaces of the resident kernels: 16 bytes per lane, written once, read once by a LATER launch (the
+// weight-gradient GEMMs).  Stored with system scope + non-temporal (`sc0 sc1 nt`: written through, nothing left behind in the
+// cache hierarchy of a socket that is power-bound while these kernels run): 3 % less time per eight-layer chain than `nt` alone
+// in the lab, 1.5 % per training step in the product on one box (profiles/r06_lab_store_policy.txt).  Visibility to the next
+// launch is the kernel boundary's, as before (the whole GPU suite passes, incl. the bit-reproducibility tests).
+// Inline asm because no builtin emits this policy -- which makes two things the CALLER's business that the compiler otherwise
+// handles: (1) the hardware's "store of more than 8 bytes, then a write of its data registers" hazard -- the hazard recogniser
+// does not look inside an asm, hence the `s_nop 1` (without it one stored value in a thousand is the NEXT value written to that
+// register: found by the parity tests, not by the lab's sampled check); (2) `v` must come out of VALU instructions: pending LDS /
+// memory loads into asm operands are not waited for (the encodings' tile, gathered from LDS, stays on store_stream_at).
+__device__ __forceinline__ void store_written_through_at(global_bytes_rw base, unsigned lane_off, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1 nt\n\ts_nop 1" :: "v"(lane_off), "v"(v), "s"(base) : "memory");
+}
 template <typename V>
 __device__ __forceinline__ V load_at(global_bytes base, unsigned lane_off) {
     return *reinterpret_cast<const __attribute__((address_space(1))) V*>(base + lane_off);

@@ -109,7 +109,7 @@ struct BwdEpi : std::conditional_t<KIND == 1, Rank1, NoRank1>, std::conditional_
             ol[sl][c0 + 1] = pack_f16(residual_f16<0>(v[2], s_next, hp), residual_f16<1>(v[3], s_next, hp));
         } else if constexpr (SUB == 10) {
             if constexpr (!lab::kNoStore)
-                store_stream_at(uniform_global_rw(save + (4 * T + q) * 1024), pinned_here(lane16), f32x4{v[0], v[1], v[2], v[3]});
+                store_written_through_at(uniform_global_rw(save + (4 * T + q) * 1024), pinned_here(lane16), f32x4{v[0], v[1], v[2], v[3]});
         }
     }
 };

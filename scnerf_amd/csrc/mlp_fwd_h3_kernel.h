@@ -121,7 +121,7 @@ struct FwdEpi : std::conditional_t<KIND == 1, Density, NoDensity>, MaskBits<TRAI
             if constexpr (TRAIN && !lab::kNoStore) {
                 // (wave-uniform base + the lane's 32-bit offset: as 64-bit per-lane pointers the eight piece bases of a
                 //  layer are hoisted into sixteen long-lived registers)
-                store_stream_at(uniform_global_rw(save + (4 * T + q) * 1024), pinned_here(lane16), f32x4{v[0], v[1], v[2], v[3]});
+                store_written_through_at(uniform_global_rw(save + (4 * T + q) * 1024), pinned_here(lane16), f32x4{v[0], v[1], v[2], v[3]});
             }
         } else {
             if constexpr (KIND == 1) {

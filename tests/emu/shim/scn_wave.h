@@ -140,6 +140,7 @@ template <typename V>
 inline void store_at(global_bytes_rw base, unsigned lane_off, V v) { std::memcpy(base + lane_off, &v, sizeof(V)); }
 template <typename V>
 inline void store_stream_at(global_bytes_rw base, unsigned lane_off, V v) { std::memcpy(base + lane_off, &v, sizeof(V)); }
+inline void store_written_through_at(global_bytes_rw base, unsigned lane_off, f32x4 v) { std::memcpy(base + lane_off, &v, sizeof(v)); }
 template <typename V>
 inline V load_at(global_bytes base, unsigned lane_off) {
     V v;
