@@ -169,13 +169,16 @@ __device__ __forceinline__ void store_stream_at(global_bytes_rw base, unsigned l
 // cache hierarchy of a socket that is power-bound while these kernels run): 3 % less time per eight-layer chain than `nt` alone
 // in the lab, 1.5 % per training step in the product on one box (profiles/r06_lab_store_policy.txt).  Visibility to the next
 // launch is the kernel boundary's, as before (the whole GPU suite passes, incl. the bit-reproducibility tests).
-// Inline asm because no builtin emits this policy -- which makes two things the CALLER's business that the compiler otherwise
-// handles: (1) the hardware's "store of more than 8 bytes, then a write of its data registers" hazard -- the hazard recogniser
-// does not look inside an asm, hence the `s_nop 1` (without it one stored value in a thousand is the NEXT value written to that
-// register: found by the parity tests, not by the lab's sampled check); (2) `v` must come out of VALU instructions: pending LDS /
-// memory loads into asm operands are not waited for (the encodings' tile, gathered from LDS, stays on store_stream_at).
+// Emitted as a raw BUFFER store: the global-store builtins cannot carry this policy, the buffer builtin takes it as its cache-policy
+// immediate (sc0 = 1, nt = 2, sc1 = 16), and -- unlike an inline asm, the first form of this function -- the compiler sees the
+// instruction: it keeps the hardware's "store of more than 8 bytes, then a write of its data registers" hazard and the wait for
+// pending loads into `v` itself.  (The asm form needed an `s_nop 1` behind every store -- without it one stored value in a
+// thousand was the NEXT value written to that register, found by the parity tests -- and could not take LDS-sourced data.)
+// The descriptor: base = the wave-uniform address, stride 0, 2 GB window, the raw 32-bit format word of gfx9.
+typedef unsigned scn_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_written_through_at(global_bytes_rw base, unsigned lane_off, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1 nt\n\ts_nop 1" :: "v"(lane_off), "v"(v), "s"(base) : "memory");
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(scn_u32x4, v), rsrc, (int)lane_off, 0, 1 | 2 | 16);
 }
 template <typename V>
 __device__ __forceinline__ V load_at(global_bytes base, unsigned lane_off) {

@@ -18,7 +18,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LAYERS, W, SECTIONS = 8, 256, 9
-KINDS = {"h3": 0, "h3p": 1, "h3-infer": 2, "h3p-infer": 3, "lds": 4, "lds-infer": 5, "h3-compact": 6, "h3-st-default": 7, "h3-st-nt": 8, "h3-st-sc0sc1nt": 9, "h3-st-sc1": 10, "h3-st-sc0sc1": 11}
+KINDS = {"h3": 0, "h3p": 1, "h3-infer": 2, "h3p-infer": 3, "lds": 4, "lds-infer": 5, "h3-compact": 6, "h3-st-default": 7, "h3-st-nt": 8, "h3-st-sc0sc1nt": 9, "h3-st-sc1": 10, "h3-st-sc0sc1": 11, "h3-st-sc1nt": 12, "h3-st-sc0nt": 13}
 
 
 def lab_input(p, f):
@@ -255,6 +255,8 @@ def main():
         run_lds.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
     check_rows = np.unique(np.concatenate([np.arange(0, min(P, 64)), np.arange(max(0, P - 64), P),
                                           (np.arange(16) * 7919 * 32) % max(P - 32, 1)]))
+    if os.environ.get("LAB_CHECK_ROWS"):          # (a denser check: every k-th row -- the sampled one misses a 1e-3 corruption rate)
+        check_rows = np.unique(np.concatenate([check_rows, np.arange(0, P, int(os.environ["LAB_CHECK_ROWS"]))]))
     ref, mag = (None, None) if args.no_check else reference(wts, bias, check_rows)
     hip = None if args.emu else Hip()
     if hip:
