@@ -88,3 +88,34 @@ def test_one_wave_per_simd_kernels_admit_no_guest(tmp_path):
     assert len([k for k in found if "h3_kernel" in k]) >= 8 and any("wgrad256_half" in k for k in found), sorted(found)
     short = {k: v for k, v in found.items() if any(f in k for f in full) and v != 512}
     assert not short, short
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(LLVM, "llvm-objdump")), reason="needs the ROCm LLVM tools")
+def test_resident_kernels_write_their_workspaces_through(tmp_path):
+    """The training instantiations of the resident kernels store their activation / gradient workspaces as raw buffer stores
+    under `sc0 sc1 nt` (csrc/device/scn_wave.h store_written_through_at; profiles/r06_lab_store_policy.txt): a compiler-visible
+    instruction, NOT an inline asm -- the asm route to the same policy corrupted one stored value in a thousand (the hazard
+    recogniser does not look inside an asm).  The inference instantiation stores none."""
+    per_kernel = {}
+    for obj in _code_objects(tmp_path):
+        dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", obj], check=True,
+                             capture_output=True, text=True).stdout
+        name = None
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                name = m.group(1)
+                continue
+            if name and ("mlp_fwd_h3_kernel" in name or "mlp_bwd_h3_kernel" in name):
+                c = per_kernel.setdefault(name, {"through": 0, "global16": 0})
+                if "buffer_store_dwordx4" in line and all(w in line for w in ("sc0", "sc1", "nt")):
+                    c["through"] += 1
+                elif "global_store_dwordx4" in line:
+                    c["global16"] += 1
+    train = {k: v for k, v in per_kernel.items() if "mlp_bwd_h3_kernel" in k or "kernelILi3ELb1E" in k or "kernelILi4ELb1E" in k}
+    infer = {k: v for k, v in per_kernel.items() if "mlp_fwd_h3_kernel" in k and "Lb0E" in k}
+    assert len(train) >= 6 and infer, sorted(per_kernel)
+    for k, v in train.items():
+        assert v["through"] >= 64, (k, v)                 # >= 8 sections x 8 pieces in the straight-line code
+    for k, v in infer.items():
+        assert v["through"] == 0, (k, v)
