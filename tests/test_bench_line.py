@@ -271,3 +271,41 @@ def test_gpu_two_rccl_ranks_on_one_device_end_with_a_line_not_a_hang():
         assert line["value"] is None and line["error"] and line["n_gpus"] == 2, line
         assert "init_process_group" in line["stage"] or "collective" in line["stage"] or "warm-up" in line["stage"], line
     print("\ntwo RCCL ranks on one device:", "ran" if r.returncode == 0 else "refused in stage '%s': %s" % (line["stage"], line["error"][:300]))
+
+
+def test_live_counter_passes_are_parsed_as_the_guide_prescribes(tmp_path, monkeypatch):
+    """bench.live_pmc_traffic without a GPU: a stand-in `rocprofv3` on PATH writes the counter CSVs the real tool writes (one
+    counter per pass); bytes = WRITE_SIZE KB x 1024 + 2 x FETCH_SIZE KB x 1024, per step over every dispatch, per launch over the
+    LARGER launches of the dominant kernel (a kernel that serves both passes under one name is launched at two sizes)."""
+    import stat
+    import bench
+    fake = tmp_path / "rocprofv3"
+    fake.write_text('''#!%s
+import csv, os, sys
+a = sys.argv[1:]
+counter, out = a[a.index("--pmc") + 1], a[a.index("-d") + 1]
+assert "--kernel-trace" in a and "--" in a and a[a.index("--") + 2].endswith("profile_steps.py")
+steps = int(os.environ["PMC_STEPS"])
+os.makedirs(os.path.join(out, "host", "123"), exist_ok=True)
+rows = []
+for s in range(steps):
+    # per step: the dominant kernel at two sizes (fine: grid 6144, coarse: grid 2048) + a small kernel
+    for name, grid, kb in (("void scn::h3b::mlp_bwd_h3_kernel<3>(float const*)", 1572864, {"FETCH_SIZE": 1000.0, "WRITE_SIZE": 7000.0}),
+                           ("void scn::h3b::mlp_bwd_h3_kernel<3>(float const*)", 524288, {"FETCH_SIZE": 300.0, "WRITE_SIZE": 2300.0}),
+                           ("vecmat_kernel(float const*)", 65536, {"FETCH_SIZE": 400.0, "WRITE_SIZE": 1.0})):
+        rows.append({"Kernel_Name": name, "Grid_Size": grid, "Counter_Name": counter, "Counter_Value": kb[counter], "Dispatch_Id": len(rows)})
+with open(os.path.join(out, "host", "123", counter + "_counter_collection.csv"), "w", newline="") as fh:
+    w = csv.DictWriter(fh, fieldnames=list(rows[0]))
+    w.writeheader()
+    w.writerows(rows)
+''' % sys.executable)
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    got, note = bench.live_pmc_traffic("mlp_bwd_h3_kernel/P=98304", 512, steps=3)
+    assert got is not None, note
+    assert got["bytes_per_launch"] == int(7000.0 * 1024 + 2 * 1000.0 * 1024)                     # the fine launches only
+    assert got["bytes_per_step"] == int((7000 + 2300 + 1) * 1024 + 2 * (1000 + 300 + 400) * 1024)
+    assert "two separate passes" in note and "FETCH_SIZE" in note
+    # a region the table does not know: the per-step figure is still there, the per-launch one is None
+    got2, _ = bench.live_pmc_traffic("some_other_kernel/P=1", 512, steps=3)
+    assert got2["bytes_per_launch"] is None and got2["bytes_per_step"] == got["bytes_per_step"]
